@@ -1,0 +1,216 @@
+"""Oracle (CPU, numpy) for the KV4 paged cache: prefill writer, decode
+attention, padding offsets.  Test infrastructure only.
+
+Restates (citations relative to the upstream checkout, kernels/csrc/fused_attention/):
+
+* page layout        omniserve/worker/cache_engine.py:73-88,117-136 ; common/kvCacheUtils.h:53-164
+* RoPE (neox)        common/decoderMaskedMultiheadAttentionUtils.h:1147-1165,2565-2620
+* KV4 quantize/pack  fused_attention_pure_dense/decoderMaskedMultiheadAttentionUtils.h:1838-1884,2070-2077
+* KV4 dequant        same file :2120-2213 (fp16 fma(u4, scale, -scale*zero))
+* prefill writer     fused_attention_fine_grained/fine_grained_common/applyBiasRopeUpdateKVCache.h:101-503
+* decode attention   fused_attention_pure_dense/decoderMaskedMultiheadAttentionTemplate.hpp:743-2222
+* padding offsets    common/input_metadata_helper.cu:16-50
+
+A K or V page of one layer is ``int4 data [H_kv][tokens_per_block][Dh/2 bytes]``
+followed by ``fp16 scale [H_kv][tokens_per_block]`` and
+``fp16 zero [H_kv][tokens_per_block]``; byte j of a token holds element 2j in
+its low nibble and element 2j+1 in its high nibble.  In these oracles a page
+pool is a numpy uint8 array [num_pages, page_bytes] and a block table holds
+page *indices* (the product passes raw device pointers = base + idx*page_bytes,
+as omniserve/utils/block_table_utils.py:62-93 builds them).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+F16 = np.float16
+
+
+def page_bytes(num_kv_heads: int, head_dim: int, tokens_per_block: int = 64) -> int:
+    return num_kv_heads * tokens_per_block * (head_dim // 2) + 2 * num_kv_heads * tokens_per_block * 2
+
+
+def compute_padding_offsets(cu_seqlens: np.ndarray, max_len: int) -> np.ndarray:
+    """pad_off[tok] = b*max_len - cu_seqlens[b] for tokens of sequence b."""
+    out = np.zeros(int(cu_seqlens[-1]), np.int32)
+    for b in range(len(cu_seqlens) - 1):
+        out[cu_seqlens[b]:cu_seqlens[b + 1]] = b * max_len - cu_seqlens[b]
+    return out
+
+
+def rope_neox(x_h: np.ndarray, pos: np.ndarray, base: float, scale: float = 1.0) -> np.ndarray:
+    """x fp16 [..., D], pos broadcastable to x.shape[:-1].  Pair (i, i+D/2):
+    angle = (pos*scale) / base**(2i/D) in f32; out = h(cos*x - sin*y), h(cos*y + sin*x).
+    """
+    x = np.asarray(x_h, F16).astype(F32)
+    D = x.shape[-1]
+    half = D // 2
+    i = np.arange(half, dtype=F32)
+    denom = np.power(F32(base), (F32(2.0) * i / F32(D)).astype(F32)).astype(F32)
+    t = (np.asarray(pos, F32)[..., None] * F32(scale)).astype(F32)
+    ang = (t / denom).astype(F32)
+    c = np.cos(ang).astype(F32)
+    s = np.sin(ang).astype(F32)
+    a, b = x[..., :half], x[..., half:]
+    ra = ((c * a).astype(F32) - (s * b).astype(F32)).astype(F32)
+    rb = ((c * b).astype(F32) + (s * a).astype(F32)).astype(F32)
+    return np.concatenate([ra, rb], axis=-1).astype(F16)
+
+
+def kv4_quant_params(x_h: np.ndarray):
+    """Per (token, head) asymmetric params over the last axis:
+    scale = h((max-min)/15), zero = h(-15*min/(max-min)); both re-read as fp16."""
+    x = np.asarray(x_h, F16).astype(F32)
+    mx = x.max(axis=-1)
+    mn = x.min(axis=-1)
+    rng = (mx - mn).astype(F32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        scale = (rng / F32(15.0)).astype(F32).astype(F16)
+        zero = ((F32(-15.0) * mn).astype(F32) / rng).astype(F32).astype(F16)
+    return scale, zero
+
+
+def kv4_quantize(x_h, scale_h, zero_h) -> np.ndarray:
+    """u4 = rni_sat_u8( x * (1/f32(scale)) + f32(zero) ) & 0xF  -> packed bytes [..., D/2]."""
+    x = np.asarray(x_h, F16).astype(F32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = (F32(1.0) / np.asarray(scale_h, F16).astype(F32)).astype(F32)
+    z = np.asarray(zero_h, F16).astype(F32)
+    v = ((x * inv[..., None]).astype(F32) + z[..., None]).astype(F32)
+    r = np.rint(v)
+    r = np.where(np.isnan(r), 0.0, r)
+    q = np.clip(r, 0, 255).astype(np.uint8) & 0xF
+    return (q[..., 0::2] | (q[..., 1::2] << 4)).astype(np.uint8)
+
+
+def kv4_dequant(packed: np.ndarray, scale_h, zero_h, fp16_math: bool = True) -> np.ndarray:
+    """-> float32 values.  fp16_math: the reference's h(fma(h(u4), h(scale), h(-scale*zero)))
+    (single fp16 rounding of the fma); else plain f32 (u4 - zero)*scale."""
+    p = np.asarray(packed, np.uint8)
+    u = np.empty(p.shape[:-1] + (p.shape[-1] * 2,), F32)
+    u[..., 0::2] = p & 0xF
+    u[..., 1::2] = p >> 4
+    s = np.asarray(scale_h, F16).astype(F32)[..., None]
+    z = np.asarray(zero_h, F16).astype(F32)[..., None]
+    if fp16_math:
+        c = (-(s) * z).astype(F32).astype(F16).astype(np.float64)
+        # u (<=15) * s is exact in f64; one rounding to fp16 = fused fma
+        return (u.astype(np.float64) * s.astype(np.float64) + c).astype(F16).astype(F32)
+    return ((u - z) * s).astype(F32)
+
+
+class PagedKV4:
+    """Page-pool view helper (numpy).  pool: uint8 [num_pages, page_bytes]."""
+
+    def __init__(self, num_pages, num_kv_heads, head_dim, tokens_per_block=64, fill=0):
+        self.H, self.D, self.TPB = num_kv_heads, head_dim, tokens_per_block
+        self.bytes_per_seq = num_kv_heads * tokens_per_block * (head_dim // 2)
+        self.page_bytes = page_bytes(num_kv_heads, head_dim, tokens_per_block)
+        self.pool = np.full((num_pages, self.page_bytes), fill, np.uint8)
+
+    def data(self, page):
+        return self.pool[page, : self.bytes_per_seq].reshape(self.H, self.TPB, self.D // 2)
+
+    def scales(self, page):
+        o = self.bytes_per_seq
+        return self.pool[page, o: o + self.H * self.TPB * 2].view(F16).reshape(self.H, self.TPB)
+
+    def zeros(self, page):
+        o = self.bytes_per_seq + self.H * self.TPB * 2
+        return self.pool[page, o: o + self.H * self.TPB * 2].view(F16).reshape(self.H, self.TPB)
+
+    def write_token(self, page, slot, head, x_h):
+        sc, ze = kv4_quant_params(x_h)
+        self.data(page)[head, slot] = kv4_quantize(x_h, sc, ze)
+        self.scales(page)[head, slot] = sc
+        self.zeros(page)[head, slot] = ze
+
+    def read_tokens(self, table_row, head, n, fp16_math=True):
+        """Dequantized [n, D] float32 for logical tokens 0..n-1 of one sequence."""
+        out = np.empty((n, self.D), F32)
+        for t in range(n):
+            pg, sl = int(table_row[t // self.TPB]), t % self.TPB
+            out[t] = kv4_dequant(self.data(pg)[head, sl], self.scales(pg)[head, sl],
+                                 self.zeros(pg)[head, sl], fp16_math)
+        return out
+
+
+def prefill_write(qkv_h, seq_lens, k_cache: PagedKV4, v_cache: PagedKV4, k_table, v_table,
+                  num_heads, num_kv_heads, head_dim, rope_base, rope_scale_factor=1.0):
+    """apply_bias_rope_update_kv_cache (dense retrieval heads, no bias, neox RoPE,
+    KV4 + zeros): RoPE q and k IN PLACE in qkv (STORE_QKV=true), quantize the
+    post-RoPE k and the raw v per (token, kv head), write pages + tails.
+    qkv fp16 [tokens, (Hq+2Hkv)*D] unpadded, sequences back to back.
+    rotary scale type is LINEAR: angle uses pos/rope_scale_factor
+    (fine_grained_common/update_kv_cache.cu:75, applyBiasRopeUpdateKVCache.h:596).
+    Returns the updated qkv."""
+    qkv = np.array(qkv_h, dtype=F16, copy=True)
+    D, Hq, Hk = head_dim, num_heads, num_kv_heads
+    tok = 0
+    for b, L in enumerate(seq_lens):
+        for p in range(int(L)):
+            row = qkv[tok]
+            q = row[: Hq * D].reshape(Hq, D)
+            k = row[Hq * D: (Hq + Hk) * D].reshape(Hk, D)
+            v = row[(Hq + Hk) * D:].reshape(Hk, D)
+            q[:] = rope_neox(q, np.full((Hq,), p), rope_base, 1.0 / rope_scale_factor)
+            k[:] = rope_neox(k, np.full((Hk,), p), rope_base, 1.0 / rope_scale_factor)
+            for h in range(Hk):
+                k_cache.write_token(int(k_table[b][p // k_cache.TPB]), p % k_cache.TPB, h, k[h])
+                v_cache.write_token(int(v_table[b][p // v_cache.TPB]), p % v_cache.TPB, h, v[h])
+            tok += 1
+    return qkv
+
+
+def decode_attention(q_h, k_h, v_h, lengths, k_cache: PagedKV4, v_cache: PagedKV4, k_table, v_table,
+                     rope_base, emulate_fp16: bool = False):
+    """single_query_attention (pure dense, KV4 + zeros, neox RoPE, Dh = rotary dim).
+
+    q fp16 [B,Hq,D], k,v fp16 [B,Hkv,D]; lengths[b] = context length INCLUDING
+    the current token; tlen = lengths[b]-1 is both the RoPE position and the
+    append slot.  Side effect: quantized post-RoPE k and raw v of the current
+    token are appended to the caches (scale/zero tails included).
+    History keys/values come from the quantized cache (fp16 dequant), the
+    current token enters un-quantized.  softmax in f32 with 1/(sum+1e-6);
+    emulate_fp16=True additionally rounds probabilities to fp16 before P.V and
+    does the history q.k products in fp16 pairs as the reference does
+    (Template.hpp:451-467,1794-1845); emulate_fp16=False is the f32 reference
+    the HIP kernel is compared against (rtol 1e-3).
+    Returns out fp16 [B,Hq,D].
+    """
+    q_h = np.asarray(q_h, F16)
+    B, Hq, D = q_h.shape
+    Hk = k_h.shape[1]
+    g = Hq // Hk
+    inv_sqrt = F32(1.0 / np.sqrt(F32(D)))
+    out = np.zeros((B, Hq, D), F16)
+    for b in range(B):
+        tlen = int(lengths[b]) - 1
+        qr = rope_neox(q_h[b], np.full((Hq,), tlen), rope_base)          # fp16
+        kr = rope_neox(k_h[b], np.full((Hk,), tlen), rope_base)          # fp16
+        vr = np.asarray(v_h[b], F16)
+        for hk in range(Hk):
+            Kc = k_cache.read_tokens(k_table[b], hk, tlen)               # history, before append
+            Vc = v_cache.read_tokens(v_table[b], hk, tlen)
+            for hq in range(hk * g, (hk + 1) * g):
+                qf = qr[hq].astype(F32)
+                if emulate_fp16 and tlen > 0:
+                    prod = (qr[hq][None, :].astype(F32) * Kc).astype(F16).astype(F32)
+                    s_hist = prod.sum(axis=1).astype(F32)
+                else:
+                    s_hist = (Kc @ qf).astype(F32) if tlen > 0 else np.zeros((0,), F32)
+                s_cur = F32(np.dot(qf.astype(np.float64), kr[hk].astype(np.float64)))
+                s = (np.concatenate([s_hist, [s_cur]]).astype(F32) * inv_sqrt).astype(F32)
+                m = s.max()
+                e = np.exp((s - m).astype(F32)).astype(F32)
+                p = (e * (F32(1.0) / (e.sum(dtype=F32) + F32(1e-6)))).astype(F32)
+                if emulate_fp16:
+                    p = p.astype(F16).astype(F32)
+                vals = np.concatenate([Vc, vr[hk][None, :].astype(F32)], axis=0)
+                o = (p[:, None].astype(np.float64) * vals.astype(np.float64)).sum(axis=0)
+                out[b, hq] = o.astype(F32).astype(F16)
+            # append current token (quantized) -- after the reads above
+            k_cache.write_token(int(k_table[b][tlen // k_cache.TPB]), tlen % k_cache.TPB, hk, kr[hk])
+            v_cache.write_token(int(v_table[b][tlen // v_cache.TPB]), tlen % v_cache.TPB, hk, vr[hk])
+    return out
