@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py -- decode tokens/s of the QServe W4A8KV4 hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one decode step (one new token for each of the 16 sequences) of Llama-3-8B
+W4A8KV4 per-channel at bs=16, 1024 cached tokens per sequence (BASELINE.json configs[1]), with
+synthetic packed weights / KV pages already resident in HBM, all kernels going through the
+C ABI (libomniserve_hip.so), the step captured in one HIP graph.  With N > 1 every rank decodes
+its own 16 sequences (independent replicas of the TP=1 config: weak scaling, no data-path
+collective); value = tokens decoded by all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel = the gate_up W4A8 GEMV (N=28672, K=4096, M=16): algorithmic
+                bytes (packed weights + activations + output) / average duration measured with
+                HIP events on the launch stream, weights rotated over all 32 layers (1.9 GB) so
+                nothing is cache resident.  peak = 8 TB/s (MI355X HBM3E).
+  cpu_baseline  the oracle restatement of the per-channel GEMMs of one decoder layer at bs=16
+                (torch._int_mm on the host cores) extrapolated to a full step -- a reported
+                baseline, not a target.
+  w4a8_gemm_4096  BASELINE.json configs[0] shape on the GPU: int8 TOPS vs the 5 PFLOP/s dense
+                int8 MFMA peak.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+INT8_PEAK_TOPS = 5000.0     # dense int8 MFMA
+
+
+def event_time_ms(fn, iters, warm=3):
+    for _ in range(warm):
+        fn(0)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for i in range(iters):
+        fn(i)
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def roofline_gate_up(runner):
+    """Event-time the gate_up GEMV alone, rotating over the layers' weights."""
+    c = runner.cfg
+    B = runner.B
+    nl = len(runner.layers)
+    lin0 = runner.layers[0]["gate_up"]
+    N, K = lin0.n, lin0.k
+    x = torch.randint(-127, 128, (B, K), dtype=torch.int8, device=runner.device)
+    sc = torch.full((B,), 0.01, dtype=torch.float16, device=runner.device)
+    sm = torch.zeros((B,), dtype=torch.float16, device=runner.device)
+    out = torch.empty((B, N), dtype=torch.float16, device=runner.device)
+
+    def fn(i):
+        runner.layers[i % nl]["gate_up"].forward(x, sc, sm, out)
+
+    ms = event_time_ms(fn, iters=max(64, 2 * nl), warm=nl)
+    # algorithmic bytes per launch: M*K + N*K/2 + 2*M*N + 4*N + 4*M (+ g128 params)
+    alg = B * K + lin0.weight_bytes() + 2 * B * N + 4 * N + 4 * B
+    achieved = alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "w4a8_gemm_kernel (gate_up GEMV M=%d N=%d K=%d, incl. split-K epilogue)" % (B, N, K),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_launch": alg, "us_per_launch": round(ms * 1e3, 2)}
+
+
+def gemm_4096(device):
+    from omniserve_amd.backend import qgemm_w4a8_per_chn
+    M = N = K = 4096
+    g = torch.Generator(device=device); g.manual_seed(0)
+    a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=device, generator=g)
+    w = torch.randint(0, 256, (N, K // 2), dtype=torch.uint8, device=device, generator=g).view(torch.int8)
+    sw = torch.full((N,), 0.01, dtype=torch.float16, device=device)
+    sz = torch.full((N,), 0.05, dtype=torch.float16, device=device)
+    sa = torch.full((M,), 0.01, dtype=torch.float16, device=device)
+    asum = torch.zeros((M,), dtype=torch.float16, device=device)
+    out = torch.empty((M, N), dtype=torch.float16, device=device)
+    ms = event_time_ms(lambda i: qgemm_w4a8_per_chn.gemm_forward_cuda(a, w, sw, sa, sz, asum, out), iters=20)
+    tops = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    return {"M": M, "N": N, "K": K, "ms": round(ms, 4), "int8_tops": round(tops, 1),
+            "frac_of_int8_mfma_peak": round(tops / INT8_PEAK_TOPS, 4), "peak_tops": INT8_PEAK_TOPS}
+
+
+def cpu_baseline(cfg, batch):
+    """Oracle port of one decoder layer's four per-channel W4A8 GEMMs at M=batch on the host cores
+    (unpack once, untimed; timed: torch._int_mm + the fp32 epilogue), extrapolated to a step."""
+    import numpy as np
+    from oracle import w4a8
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    shapes = [((cfg.heads + 2 * cfg.kv_heads) * cfg.head_dim, cfg.hidden), (cfg.hidden, cfg.hidden),
+              (2 * cfg.inter, cfg.hidden), (cfg.hidden, cfg.inter)]
+    rng = np.random.default_rng(0)
+    M = max(batch, 32)  # torch._int_mm on CPU wants M > 16; rows beyond `batch` are padding
+    mats = []
+    for (N, K) in shapes:
+        u = torch.from_numpy(rng.integers(0, 16, size=(N, K), dtype=np.int8))
+        a = torch.from_numpy(rng.integers(-127, 128, size=(M, K), dtype=np.int8))
+        sw = torch.full((N,), 0.01); sz = torch.full((N,), 0.05)
+        sa = torch.full((M, 1), 0.01); asum = torch.zeros((M, 1))
+        mats.append((a, u.t().contiguous(), sw, sz, sa, asum))
+
+    def layer():
+        for a, ut, sw, sz, sa, asum in mats:
+            acc = torch._int_mm(a, ut)
+            _ = ((acc.float() * sw) * sa - sz * asum).half()
+
+    layer()
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 12.0:
+        layer()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    step_s = dt * cfg.layers
+    return {"value": round(batch / step_s, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": "oracle port (torch._int_mm int8 + fp32 epilogue) of the 4 per-channel W4A8 GEMMs of one "
+                      "Llama-3-8B decoder layer at M=%d (rows padded to %d), %d reps in %.1f s, x%d layers; "
+                      "attention/norm/lm_head excluded" % (batch, M, reps, dt * reps, cfg.layers)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--context", type=int, default=1024)
+    ap.add_argument("--group-size", type=int, default=-1)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / gemm_4096 legs")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback: the HIP path is the product)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from omniserve_amd.runtime import DecodeRunner, LlamaConfig
+    cfg = LlamaConfig.llama3_8b(args.group_size)
+    runner = DecodeRunner(cfg, args.batch, args.context, args.steps + args.warmup + 4, device,
+                          seed=1234 + rank, use_graph=not args.no_graph)
+    for _ in range(args.warmup):
+        runner.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        elapsed = float(t.item())
+    torch.cuda.synchronize()
+    if not torch.isfinite(runner.x.float()).all():
+        raise SystemExit("non-finite activations in the decode step")
+
+    total_tokens = args.batch * args.steps * world
+    result = {
+        "metric": "decode tokens/sec/GPU Llama-3-8B W4A8KV4 bs=16" if world == 1 else
+                  "decode tokens/sec (all GPUs) Llama-3-8B W4A8KV4 bs=16 per GPU",
+        "value": round(total_tokens / elapsed, 1),
+        "unit": "tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int8 (W4A8 int32-accumulate GEMM) + fp16 (KV4 attention, fp32 softmax)",
+        "data": "synthetic (random packed int4 weights, random KV4 pages, random tokens)",
+        "config": {"workload": "Llama-3-8B W4A8KV4 %s decode, bs=%d, context=%d, TP=1 (%s)" % (
+                       "per-channel" if args.group_size == -1 else "g%d" % args.group_size, args.batch,
+                       args.context, "BASELINE.json configs[1]" if args.group_size == -1 else "configs[2]-like"),
+                   "batch_per_gpu": args.batch, "context": args.context, "layers": cfg.layers,
+                   "parallelism": "replicas x%d (no collective)" % world if world > 1 else "single GPU",
+                   "hip_graph": not args.no_graph,
+                   "gemm_weight_bytes_per_step": runner.gemm_weight_bytes_per_step(),
+                   "kv_bytes_per_step": runner.kv_bytes_per_step(args.context)},
+    }
+    if rank == 0 and not args.no_extras:
+        result["roofline"] = roofline_gate_up(runner)
+        if world == 1:
+            result["w4a8_gemm_4096"] = gemm_4096(device)
+            del runner
+            torch.cuda.empty_cache()
+            result["cpu_baseline"] = cpu_baseline(cfg, args.batch)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

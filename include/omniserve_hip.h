@@ -1,0 +1,161 @@
+/*
+ * omniserve_hip.h -- C ABI of libomniserve_hip.so, the MI355X (gfx950) implementation of the
+ * OmniServe quantized-inference hot path (QServe W4A8KV4 / LServe kernels).
+ *
+ * This is the drop-in boundary.  Upstream exposes these operations as pybind11 torch-extension
+ * modules `omniserve_backend.*` (kernels/setup.py:156-333); every entry point below cites the
+ * upstream function it replaces.  All pointers are DEVICE pointers unless stated, tensors are
+ * dense row-major with the shapes given, fp16 values are IEEE binary16 passed as `void*`,
+ * `stream` is a hipStream_t (NULL = default stream).  Every call only enqueues work on `stream`
+ * (graph-capture safe: no allocation, no synchronisation) and returns 0 on success or a negative
+ * errno-style code (-22 invalid argument, -12 workspace too small, -5 launch failure).
+ *
+ * The host-side mirror of the upstream Python API (same module / function names and positional
+ * arguments) lives in omniserve_amd/backend/ and binds this ABI through ctypes; see
+ * INTEGRATION.md for the stub a maintainer of the reference would add.
+ */
+#ifndef OMNISERVE_HIP_H
+#define OMNISERVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ABI version, bumped on any signature change. */
+int omni_abi_version(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * W4A8 / W8A8 GEMM         out[m,n] = fp16( epilogue( sum_k A[m,k] * W[n,k] ) )
+ * -------------------------------------------------------------------------------------------- */
+
+/* Bytes of int32 split-K scratch the GEMM entry points may need for an (M,N,K) problem.  Callers
+ * keep one scratch buffer per device/stream of at least this size (it is not persistent state:
+ * contents are dead after the call). */
+size_t omni_gemm_workspace_bytes(int M, int N, int K);
+
+/* Tuning / introspection hooks (tests and bench sweeps; not used by the serving path):
+ * override the decode-shape plan (waves per workgroup: 1 or 4; K splits), 0/0 restores the
+ * heuristic; query the plan the library would use. */
+void omni_gemm_set_plan_override(int waves, int sk);
+void omni_gemm_get_plan(int M, int N, int K, int kalign, int* mb, int* waves, int* sk);
+
+/* Replaces omniserve_backend.qgemm_w4a8_per_chn.gemm_forward_cuda
+ *   (kernels/csrc/qgemm/w4a8_per_chn/gemm_cuda.cu:601-657, kernel :308-599).
+ * in_feats int8 [M,K]; qweight int8 [N,K/2] in the QServe 32x32-tile nibble layout
+ * (omniserve/modeling/layers/quantized_linear/w4a8_linear.py:296-327), codes 0..15 used unsigned;
+ * wscales,w_szs fp16 [N]; ascales,a_ssums fp16 [M]; out fp16, row m at out + m*out_row_stride
+ * elements.  out = h( f32(acc)*wscales[n]*ascales[m] - w_szs[n]*a_ssums[m] ).
+ * Requires N % 64 == 0, K % 64 == 0, M >= 1. */
+int omni_w4a8_per_chn_gemm(const void* in_feats, const void* qweight, const void* wscales,
+                           const void* ascales, const void* w_szs, const void* a_ssums,
+                           void* out_feats, int M, int N, int K, int64_t out_row_stride,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces omniserve_backend.qgemm_w4a8_per_group.gemm_forward_cuda
+ *   (kernels/csrc/qgemm/w4a8_per_group/gemm_cuda.cu:635-707, dequant :276-331).
+ * zeros, scales_i8: int8 [K/128, N] in the per-32-channel permuted order of
+ * w4a8_linear.py:236-282.  w8 = int8( (u4 * s2 + z2) mod 256 ) with the reference's 32-bit-word
+ * multiply; out = h( f32(acc) * (wscales[n]*ascales[m]) ).  Requires K % 128 == 0, N % 64 == 0. */
+int omni_w4a8_per_group_gemm(const void* in_feats, const void* qweight, const void* zeros,
+                             const void* scales_i8, const void* wscales, const void* ascales,
+                             void* out_feats, int M, int N, int K, int64_t out_row_stride,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces omniserve_backend.qgemm_w8a8.w8a8_gemm_forward_cuda
+ *   (kernels/csrc/qgemm/w8a8/w8a8_gemm_cuda.cu).  weight int8 [N,K] row-major.
+ * out = h( f32(acc) * (wscales[n]*ascales[m]) ).  Requires N % 64 == 0, K % 64 == 0. */
+int omni_w8a8_gemm(const void* in_feats, const void* weight, const void* wscales,
+                   const void* ascales, void* out_feats, int M, int N, int K,
+                   int64_t out_row_stride, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Activation quantisation, norms, activation  (tokens x hidden, contiguous)
+ * -------------------------------------------------------------------------------------------- */
+
+/* Replaces omniserve_backend.fused_kernels.invoke_quant (tensor-scale overload)
+ *   (kernels/csrc/fused_kernels.cu:57-94,235-250): per-token amax -> scale=h(amax/127),
+ *   q = rni_sat_s8(x * (127/amax)). */
+int omni_quant(void* out_i8, const void* in_f16, void* scale_f16, int tokens, int hidden,
+               void* stream);
+
+/* Replaces omniserve_backend.fused_kernels.invoke_quant_fuse_sum (tensor overload)
+ *   (fused_kernels.cu:97-142,255-271): as omni_quant plus sum = h(sum_i x_i) (f32 tree). */
+int omni_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f16, void* scale_f16,
+                        int tokens, int hidden, void* stream);
+
+/* Replaces omniserve_backend.layernorm_ops.rms_norm (use_quant = false)
+ *   (kernels/csrc/layernorm_kernels.cu:335-365,409-430). */
+int omni_rms_norm(void* out_f16, const void* in_f16, const void* weight_f16, float eps,
+                  int tokens, int hidden, void* stream);
+
+/* Replaces omniserve_backend.layernorm_ops.rms_norm_general (use_per_token_quant = true)
+ *   (layernorm_kernels.cu:58-191,432-469): y=(x-mean)*rsqrt(mean(x^2)+eps)*gamma, per-token
+ *   int8 quantisation with scale=h(amax/127). */
+int omni_rms_norm_general(void* out_i8, const void* in_f16, const void* weight_f16,
+                          void* scale_f16, float eps, int tokens, int hidden, void* stream);
+
+/* Replaces omniserve_backend.layernorm_ops.rms_norm_general_fuse_sum (per-token)
+ *   (layernorm_kernels.cu:194-331,471-513): as above plus sum = h(sum_i h(y_i)) with the
+ *   reference's fp16 per-thread accumulation. */
+int omni_rms_norm_general_fuse_sum(void* out_i8, const void* in_f16, const void* weight_f16,
+                                   void* sum_f16, void* scale_f16, float eps, int tokens,
+                                   int hidden, void* stream);
+
+/* Replaces omniserve_backend.activation_ops.silu_and_mul
+ *   (kernels/csrc/activation_kernels.cu:10-30,84-97): in fp16 [tokens, 2d] -> out [tokens, d]. */
+int omni_silu_and_mul(void* out_f16, const void* in_f16, int tokens, int d, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * KV4 paged cache (page = int4 data [H_kv][tpb][Dh/2] | fp16 scale [H_kv][tpb] | fp16 zero [H_kv][tpb],
+ *   omniserve/worker/cache_engine.py:73-88, kernels/csrc/fused_attention/common/kvCacheUtils.h:53-164)
+ * Block tables are int64 [B, 2, max_blocks] of raw device pointers (K row, then V row), exactly
+ * what omniserve/utils/block_table_utils.py:62-93 builds.
+ * RoPE uses a host-built table rope_cos_sin f32 [max_pos][Dh/2][2] = {cos, sin}(pos*scale/base^(2i/Dh)).
+ * -------------------------------------------------------------------------------------------- */
+
+/* Replaces omniserve_backend.fused_attention_*.compute_padding_offsets
+ *   (kernels/csrc/fused_attention/common/input_metadata_helper.cu:16-50).
+ * out[tok] = b*max_len - cu_seqlens[b]; cu_seqlens int32 [batch+1] (device). */
+int omni_compute_padding_offsets(void* out_i32, const void* cu_seqlens_i32, int batch,
+                                 int max_len, int total_tokens, void* stream);
+
+/* Replaces omniserve_backend.fused_attention_fine_grained_dense.apply_bias_rope_update_kv_cache
+ *   for the dense (all heads retrieval) KV4+zeros configuration
+ *   (fine_grained_common/update_kv_cache.cu:27-124, applyBiasRopeUpdateKVCache.h:101-503).
+ * qkv fp16 [tokens, (Hq+2Hkv)*Dh] unpadded; neox RoPE applied to q and k IN PLACE; post-RoPE k
+ * and v quantised per (token, kv head) and written to the pages.  seq_lens int32 [B];
+ * padding_offsets int32 [tokens]; max_seq_len = padded per-sequence length used by
+ * padding_offsets.  rope_max_pos = rows in rope_cos_sin.  max_position_embeddings is the
+ * reference's cyclic_kv_cache_len (update_kv_cache.cu:75): tokens below len - that are not stored. */
+int omni_kv4_prefill_write(void* qkv_f16, const void* seq_lens_i32, const void* padding_offsets_i32,
+                           const void* kv_pointers_i64, int tokens, int batch, int max_blocks,
+                           int num_heads, int num_kv_heads, int head_dim, int max_seq_len,
+                           int tokens_per_block, const void* rope_cos_sin_f32, int rope_max_pos,
+                           int max_position_embeddings, void* stream);
+
+/* Scratch bytes for omni_kv4_decode_attention (split-KV partials). */
+size_t omni_kv4_decode_workspace_bytes(int batch, int num_heads, int head_dim, int max_context);
+
+/* Replaces omniserve_backend.fused_attention_pure_dense.single_query_attention (KV4 + zeros)
+ *   (fused_attention_pure_dense/fused_attention.cpp:150-240; kernel
+ *   decoderMaskedMultiheadAttentionTemplate.hpp:743-2222).
+ * q fp16 [B,Hq,Dh] with row stride q_stride elements, k,v fp16 [B,Hkv,Dh] with row stride
+ * kv_stride (strided views of the fused qkv buffer); lengths int32 [B] = context length
+ * INCLUDING the current token (tlen = len-1 is the RoPE position and the append slot).
+ * Applies neox RoPE to q and k, quantises + appends k,v of the current token to the pages,
+ * attends over the cached history (fp16 dequant) plus the un-quantised current token, writes
+ * out fp16 [B,Hq,Dh] contiguous.  max_context bounds lengths[] (sizes the KV split). */
+int omni_kv4_decode_attention(void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16,
+                              int64_t q_stride, int64_t kv_stride, const void* kv_pointers_i64,
+                              const void* lengths_i32, int batch, int max_blocks, int num_heads,
+                              int num_kv_heads, int head_dim, int tokens_per_block, int max_context,
+                              const void* rope_cos_sin_f32, int rope_max_pos, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMNISERVE_HIP_H */

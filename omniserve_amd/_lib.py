@@ -1,0 +1,98 @@
+"""ctypes binding of libomniserve_hip.so -- the only way the host side reaches the kernels.
+
+There is NO CPU fallback: if the library cannot be loaded every op raises.  torch is imported
+first so that the HIP runtime already mapped by PyTorch (same soname, libamdhip64.so.7) is the
+one our library binds to: stream handles and device pointers are then interchangeable.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libomniserve_hip.so")
+
+_c = ctypes
+_vp, _i, _i64, _sz, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t, _c.c_float
+
+# name -> (restype, argtypes); mirrors include/omniserve_hip.h one to one
+PROTOTYPES = {
+    "omni_abi_version": (_i, []),
+    "omni_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "omni_gemm_set_plan_override": (None, [_i, _i]),
+    "omni_gemm_get_plan": (None, [_i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
+    "omni_w4a8_per_chn_gemm": (_i, [_vp] * 7 + [_i, _i, _i, _i64, _vp, _sz, _vp]),
+    "omni_w4a8_per_group_gemm": (_i, [_vp] * 7 + [_i, _i, _i, _i64, _vp, _sz, _vp]),
+    "omni_w8a8_gemm": (_i, [_vp] * 5 + [_i, _i, _i, _i64, _vp, _sz, _vp]),
+    "omni_quant": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "omni_quant_fuse_sum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "omni_rms_norm": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp]),
+    "omni_rms_norm_general": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "omni_rms_norm_general_fuse_sum": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "omni_silu_and_mul": (_i, [_vp, _vp, _i, _i, _vp]),
+    "omni_compute_padding_offsets": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "omni_kv4_prefill_write": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _i, _i, _vp]),
+    "omni_kv4_decode_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "omni_kv4_decode_attention": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp] + [_i] * 7 + [_vp, _i, _vp, _sz, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the library.  Raises RuntimeError if it does not exist."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    "omniserve_amd: %s is missing -- run `python -m omniserve_amd.build` "
+                    "(there is no CPU fallback)" % LIB_PATH)
+            h = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+            for name, (res, args) in PROTOTYPES.items():
+                fn = getattr(h, name)  # AttributeError = header/library drift
+                fn.restype = res
+                fn.argtypes = args
+            _lib = h
+    return _lib
+
+
+_ERR = {-22: "invalid argument", -12: "workspace too small", -5: "kernel launch failed"}
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (%d)" % (what, _ERR.get(rc, "error"), rc))
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("omniserve_amd kernels need device tensors (got a %s tensor)" % t.device)
+
+
+_workspaces = {}
+
+
+def workspace(nbytes: int, device, tag: str = "gemm") -> torch.Tensor:
+    """Persistent per-(device, tag) scratch; grows geometrically, never shrinks.
+    (Pre-size it before HIP-graph capture: growing allocates.)"""
+    key = (str(device), tag)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        size = max(int(nbytes), 1 << 20)
+        if buf is not None:
+            size = max(size, 2 * buf.numel())
+        buf = torch.empty(size, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

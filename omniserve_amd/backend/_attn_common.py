@@ -1,0 +1,76 @@
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+from ..rope import rope_table
+
+
+def _check_cfg(rotary_embedding_dim, neox_rotary_style, int4_kv_cache, kv_cache_with_zeros, head_dim):
+    if not (int4_kv_cache and kv_cache_with_zeros):
+        raise NotImplementedError("only the KV4 + zeros (fine_grained) cache format is implemented")
+    if not neox_rotary_style:
+        raise NotImplementedError("only neox-style RoPE is implemented")
+    if head_dim != 128 or rotary_embedding_dim != head_dim:
+        raise NotImplementedError("head_dim = rotary_dim = 128 only")
+
+
+def compute_padding_offsets(cu_seqlens, max_seqlen, tot_num_tokens):
+    """-> int32 [tot_num_tokens], out[tok] = b*max_seqlen - cu_seqlens[b]
+    (common/input_metadata_helper.cu:38-50; callee allocates)."""
+    _lib.require_cuda(cu_seqlens)
+    out = torch.empty((tot_num_tokens,), dtype=torch.int32, device=cu_seqlens.device)
+    rc = _lib.lib().omni_compute_padding_offsets(out.data_ptr(), cu_seqlens.data_ptr(),
+                                                 cu_seqlens.shape[0] - 1, int(max_seqlen),
+                                                 int(tot_num_tokens), _lib.current_stream())
+    _lib.check(rc, "compute_padding_offsets")
+    return out
+
+
+def prefill_write(qkv, seq_lens, padding_offset, kv_pointers, head_num, kv_head_num, seq_len,
+                  tokens_per_block, size_per_token, rotary_embedding_dim, rotary_embedding_base,
+                  rope_scale, rotary_embedding_max_positions, neox, int4, zeros, what):
+    _lib.require_cuda(qkv, seq_lens, padding_offset, kv_pointers)
+    head_dim = qkv.shape[-1] // (head_num + 2 * kv_head_num)
+    _check_cfg(rotary_embedding_dim, neox, int4, zeros, head_dim)
+    if size_per_token != kv_head_num * head_dim // 2:
+        raise RuntimeError("%s: size_per_token %d != Hkv*Dh/2" % (what, size_per_token))
+    if not qkv.is_contiguous() or qkv.dtype != torch.float16:
+        raise RuntimeError("%s: qkv must be contiguous fp16" % what)
+    table = rope_table(int(seq_len), head_dim, float(rotary_embedding_base), float(rope_scale), qkv.device)
+    rc = _lib.lib().omni_kv4_prefill_write(
+        qkv.data_ptr(), seq_lens.data_ptr(), padding_offset.data_ptr(), kv_pointers.data_ptr(),
+        qkv.shape[0], seq_lens.shape[0], kv_pointers.shape[-1], head_num, kv_head_num, head_dim,
+        int(seq_len), int(tokens_per_block), table.data_ptr(), table.shape[0],
+        int(rotary_embedding_max_positions), _lib.current_stream())
+    _lib.check(rc, what)
+
+
+def decode_attention(q, k, v, kv_pointers, lengths, tokens_per_block, size_per_token, timestep,
+                     rotary_embedding_dim, rotary_base, neox, int4, zeros, what):
+    _lib.require_cuda(q, k, v, kv_pointers, lengths)
+    B, Hq, D = q.shape
+    Hkv = k.shape[1]
+    _check_cfg(rotary_embedding_dim, neox, int4, zeros, D)
+    if size_per_token != Hkv * D // 2:
+        raise RuntimeError("%s: size_per_token %d != Hkv*Dh/2" % (what, size_per_token))
+    if q.dtype != torch.float16 or q.stride(2) != 1 or q.stride(1) != D:
+        raise RuntimeError("%s: q must be fp16 [B,H,D] with contiguous heads" % what)
+    if k.stride(2) != 1 or k.stride(1) != D or v.stride(2) != 1 or v.stride(1) != D:
+        raise RuntimeError("%s: k/v heads must be contiguous" % what)      # TORCH_CHECK in the reference
+    if k.stride(0) != v.stride(0):
+        raise RuntimeError("%s: k and v must share the row stride" % what)
+    if lengths.dtype != torch.int32 or not kv_pointers.is_contiguous():
+        raise RuntimeError("%s: lengths must be int32, kv_pointers contiguous" % what)
+    max_ctx = max(int(timestep), 1)
+    table = rope_table(max_ctx + 1, D, float(rotary_base), 1.0, q.device)
+    need = _lib.lib().omni_kv4_decode_workspace_bytes(B, Hq, D, max_ctx)
+    ws = _lib.workspace(need, q.device, "attn")
+    out = torch.empty((B, Hq, D), dtype=q.dtype, device=q.device)
+    rc = _lib.lib().omni_kv4_decode_attention(
+        out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0),
+        kv_pointers.data_ptr(), lengths.data_ptr(), B, kv_pointers.shape[-1], Hq, Hkv, D,
+        int(tokens_per_block), max_ctx, table.data_ptr(), table.shape[0], ws.data_ptr(), ws.numel(),
+        _lib.current_stream())
+    _lib.check(rc, what)
+    return out

@@ -1,0 +1,78 @@
+"""Build libomniserve_hip.so (gfx950) in-tree with hipcc.
+
+    python -m omniserve_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The library lands next to this file
+(omniserve_amd/libomniserve_hip.so) so that it travels with the source tree;
+objects go to omniserve_amd/csrc/build/ (git-ignored).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libomniserve_hip.so")
+ARCH = "gfx950"
+SOURCES = ["qgemm_plan.hip", "qgemm_chn.hip", "qgemm_grp.hip", "qgemm_w8.hip",
+           "elementwise.hip", "kv_cache.hip"]
+# -ffp-contract=off: the fp32 epilogues / quantisers must round exactly like oracle/ (explicit
+# fma where wanted).  No -ffast-math anywhere.
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function", "-I" + CSRC, "-I" + os.path.join(os.path.dirname(HERE), "include")]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built")
+    return exe
+
+
+def _deps_mtime() -> float:
+    m = 0.0
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in os.listdir(root):
+            if f.endswith((".hip", ".h", ".cpp")):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return max(m, os.path.getmtime(os.path.abspath(__file__)))
+
+
+def needs_build() -> bool:
+    return not os.path.exists(LIB) or os.path.getmtime(LIB) < _deps_mtime()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    tmp = LIB + ".tmp"
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", tmp]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

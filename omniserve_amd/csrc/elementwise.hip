@@ -1,0 +1,274 @@
+// Per-token activation quantisation, (general) RMS norm and SiLU*mul for MI355X (gfx950).
+//
+// Replaces omniserve_backend.fused_kernels / layernorm_ops / activation_ops
+// (reference: kernels/csrc/fused_kernels.cu, layernorm_kernels.cu, activation_kernels.cu).
+//
+// The reference's results depend on its reduction geometry (1024 virtual threads per token,
+// thread t accumulating elements t, t+1024, ... sequentially, then a 32-lane butterfly and a
+// butterfly over 32 warp partials; the fuse_sum norm even accumulates per-thread in fp16).
+// These kernels keep that geometry -- one 1024-thread workgroup per token, virtual warp =
+// 32-lane half of a wave64 -- so sums, scales and int8 codes are bit-identical to
+// oracle/elementwise.py.  Each thread keeps its (<= VPT) elements in registers, so the row is
+// read from HBM exactly once instead of the reference's 3-4 passes.
+#include "common.h"
+
+namespace omni {
+
+constexpr int NT_MAX = 1024;
+constexpr int VPT = 16;  // elements per thread held in registers: hidden <= 16384 fast path
+
+// ------------------------------------------------------------------------------------------
+// invoke_quant / invoke_quant_fuse_sum   (fused_kernels.cu:57-142)
+// ------------------------------------------------------------------------------------------
+template <bool FUSE_SUM>
+__global__ __launch_bounds__(NT_MAX) void quant_kernel(int8_t* __restrict__ out,
+                                                        const half_t* __restrict__ in,
+                                                        half_t* __restrict__ sum_out,
+                                                        half_t* __restrict__ scale_out, int hidden) {
+  __shared__ float red[32];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const size_t row = (size_t)blockIdx.x * hidden;
+  float x[VPT];
+  float amax = 0.0f, s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int i = tid + j * nt;
+    const bool ok = i < hidden;  // branch-free: keeps x[] in registers
+    const float v = (float)in[row + (ok ? i : 0)];
+    x[j] = ok ? v : 0.0f;
+    if constexpr (FUSE_SUM) s = ok ? s + x[j] : s;
+    amax = __builtin_fmaxf(amax, __builtin_fabsf(x[j]));
+  }
+  for (int i = tid + VPT * nt; i < hidden; i += nt) {  // hidden > VPT*1024: re-read tail later
+    const float v = (float)in[row + i];
+    if constexpr (FUSE_SUM) s = s + v;
+    amax = __builtin_fmaxf(amax, __builtin_fabsf(v));
+  }
+  amax = ref_block_max(amax, red, -1e20f);
+  if constexpr (FUSE_SUM) {
+    const float tot = ref_block_sum(s, red);
+    if (tid == 0) sum_out[blockIdx.x] = (half_t)tot;
+  }
+  if (tid == 0) scale_out[blockIdx.x] = (half_t)(amax / 127.0f);
+  const float q = 127.0f / amax;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int i = tid + j * nt;
+    if (i < hidden) out[row + i] = rni_sat_s8(x[j] * q);
+  }
+  for (int i = tid + VPT * nt; i < hidden; i += nt) out[row + i] = rni_sat_s8((float)in[row + i] * q);
+}
+
+// ------------------------------------------------------------------------------------------
+// rms_norm_general[_fuse_sum], per-token quant   (layernorm_kernels.cu:58-331)
+//   y = (x - mean) * rsqrt(mean(x^2) + eps) * gamma   [mean subtracted in the output only]
+// ------------------------------------------------------------------------------------------
+template <bool FUSE_SUM>
+__global__ __launch_bounds__(NT_MAX) void general_norm_quant_kernel(
+    int8_t* __restrict__ out, const half_t* __restrict__ in, const half_t* __restrict__ gamma,
+    half_t* __restrict__ sum_out, half_t* __restrict__ scale_out, float eps, int hidden) {
+  __shared__ float red[32];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const size_t row = (size_t)blockIdx.x * hidden;
+  float x[VPT];
+  float lsum = 0.0f, lsq = 0.0f;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int i = tid + j * nt;
+    const bool ok = i < hidden;
+    const float v = (float)in[row + (ok ? i : 0)];
+    x[j] = ok ? v : 0.0f;
+    lsum = ok ? lsum + x[j] : lsum;
+    lsq = ok ? lsq + x[j] * x[j] : lsq;
+  }
+  const float mean = ref_block_sum(lsum, red) / (float)hidden;
+  const float var = ref_block_sum(lsq, red);
+  const float rstd = 1.0f / __builtin_sqrtf(var / (float)hidden + eps);
+
+  // amax / sum are fp16 quantities in the reference; fp16 values are exact in f32, so they are
+  // carried as floats and re-rounded to fp16 where the reference rounds.
+  float amax_h = (float)(half_t)1e-6f;
+  float hsum = 0.0f;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int i = tid + j * nt;
+    const bool ok = i < hidden;
+    float y = (x[j] - mean) * rstd;
+    y = y * (float)gamma[ok ? i : 0];
+    x[j] = y;
+    const float yh = ok ? (float)(half_t)y : 0.0f;
+    amax_h = __builtin_fmaxf(amax_h, __builtin_fabsf(yh));
+    if constexpr (FUSE_SUM) hsum = ok ? (float)(half_t)(hsum + yh) : hsum;
+  }
+  const float amax = ref_block_max(amax_h, red, -1e20f);
+  if constexpr (FUSE_SUM) {
+    const float tot = ref_block_sum(hsum, red);
+    if (tid == 0) sum_out[blockIdx.x] = (half_t)tot;
+  }
+  if (tid == 0) scale_out[blockIdx.x] = (half_t)(amax / 127.0f);
+  const float q = 127.0f / amax;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int i = tid + j * nt;
+    if (i < hidden) out[row + i] = rni_sat_s8(x[j] * q);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// rms_norm (fp16 out)   (layernorm_kernels.cu:335-365)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT_MAX) void rms_norm_kernel(half_t* __restrict__ out,
+                                                           const half_t* __restrict__ in,
+                                                           const half_t* __restrict__ weight,
+                                                           float eps, int hidden) {
+  __shared__ float red[32];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const size_t row = (size_t)blockIdx.x * hidden;
+  float x[VPT];
+  float lsq = 0.0f;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int i = tid + j * nt;
+    const bool ok = i < hidden;
+    const float v = (float)in[row + (ok ? i : 0)];
+    x[j] = ok ? v : 0.0f;
+    lsq = ok ? lsq + x[j] * x[j] : lsq;
+  }
+  const float var = ref_block_sum(lsq, red);
+  const float rstd = 1.0f / __builtin_sqrtf(var / (float)hidden + eps);
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int i = tid + j * nt;
+    if (i < hidden) {
+      const half_t t = (half_t)(x[j] * rstd);
+      out[row + i] = (half_t)((float)t * (float)weight[i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// silu_and_mul   (activation_kernels.cu:10-30): out = h( f32(h(x/(1+exp(-x)))) * f32(y) )
+// 8 elements (16 B) per lane, grid-stride over tokens*d/8.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void silu_and_mul_kernel(half_t* __restrict__ out,
+                                                            const half_t* __restrict__ in,
+                                                            int tokens, int d) {
+  const int vec_per_row = d / 8;
+  const size_t total = (size_t)tokens * vec_per_row;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t t = idx / vec_per_row;
+    const int c = (int)(idx % vec_per_row) * 8;
+    const v8h a = *reinterpret_cast<const v8h*>(in + t * 2 * d + c);
+    const v8h b = *reinterpret_cast<const v8h*>(in + t * 2 * d + d + c);
+    v8h o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xf = (float)a[j];
+      const half_t s = (half_t)(xf / (1.0f + expf(-xf)));
+      o[j] = (half_t)((float)s * (float)b[j]);
+    }
+    *reinterpret_cast<v8h*>(out + t * d + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void silu_and_mul_scalar_kernel(half_t* __restrict__ out,
+                                                                   const half_t* __restrict__ in,
+                                                                   int tokens, int d) {
+  const size_t total = (size_t)tokens * d;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t t = idx / d;
+    const int c = (int)(idx % d);
+    const float xf = (float)in[t * 2 * d + c];
+    const half_t s = (half_t)(xf / (1.0f + expf(-xf)));
+    out[t * d + c] = (half_t)((float)s * (float)in[t * 2 * d + d + c]);
+  }
+}
+
+static inline int norm_block(int hidden, bool round32) {
+  int b = hidden < NT_MAX ? hidden : NT_MAX;
+  if (round32) b = 32 * ((b + 31) / 32);
+  return b;
+}
+
+}  // namespace omni
+
+using namespace omni;
+
+extern "C" int omni_quant(void* out_i8, const void* in_f16, void* scale_f16, int tokens, int hidden,
+                          void* stream) {
+  if (!out_i8 || !in_f16 || !scale_f16 || tokens < 0 || hidden < 1) return OMNI_EINVAL;
+  if (hidden % 32 != 0) return OMNI_EINVAL;  // reference geometry: block = min(hidden,1024)
+  if (tokens == 0) return OMNI_OK;
+  hipLaunchKernelGGL((quant_kernel<false>), dim3(tokens), dim3(norm_block(hidden, false)), 0,
+                     (hipStream_t)stream, (int8_t*)out_i8, (const half_t*)in_f16, (half_t*)nullptr,
+                     (half_t*)scale_f16, hidden);
+  return omni_launch_status();
+}
+
+extern "C" int omni_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f16, void* scale_f16,
+                                   int tokens, int hidden, void* stream) {
+  if (!out_i8 || !in_f16 || !sum_f16 || !scale_f16 || tokens < 0 || hidden < 1) return OMNI_EINVAL;
+  if (hidden % 32 != 0) return OMNI_EINVAL;
+  if (tokens == 0) return OMNI_OK;
+  hipLaunchKernelGGL((quant_kernel<true>), dim3(tokens), dim3(norm_block(hidden, false)), 0,
+                     (hipStream_t)stream, (int8_t*)out_i8, (const half_t*)in_f16, (half_t*)sum_f16,
+                     (half_t*)scale_f16, hidden);
+  return omni_launch_status();
+}
+
+extern "C" int omni_rms_norm(void* out_f16, const void* in_f16, const void* weight_f16, float eps,
+                             int tokens, int hidden, void* stream) {
+  if (!out_f16 || !in_f16 || !weight_f16 || tokens < 0 || hidden < 1) return OMNI_EINVAL;
+  if (hidden % 32 != 0 || hidden > VPT * NT_MAX) return OMNI_EINVAL;
+  if (tokens == 0) return OMNI_OK;
+  hipLaunchKernelGGL(rms_norm_kernel, dim3(tokens), dim3(norm_block(hidden, false)), 0,
+                     (hipStream_t)stream, (half_t*)out_f16, (const half_t*)in_f16,
+                     (const half_t*)weight_f16, eps, hidden);
+  return omni_launch_status();
+}
+
+extern "C" int omni_rms_norm_general(void* out_i8, const void* in_f16, const void* weight_f16,
+                                     void* scale_f16, float eps, int tokens, int hidden,
+                                     void* stream) {
+  if (!out_i8 || !in_f16 || !weight_f16 || !scale_f16 || tokens < 0 || hidden < 1) return OMNI_EINVAL;
+  if (hidden > VPT * NT_MAX) return OMNI_EINVAL;
+  if (tokens == 0) return OMNI_OK;
+  hipLaunchKernelGGL((general_norm_quant_kernel<false>), dim3(tokens), dim3(norm_block(hidden, true)),
+                     0, (hipStream_t)stream, (int8_t*)out_i8, (const half_t*)in_f16,
+                     (const half_t*)weight_f16, (half_t*)nullptr, (half_t*)scale_f16, eps, hidden);
+  return omni_launch_status();
+}
+
+extern "C" int omni_rms_norm_general_fuse_sum(void* out_i8, const void* in_f16,
+                                              const void* weight_f16, void* sum_f16,
+                                              void* scale_f16, float eps, int tokens, int hidden,
+                                              void* stream) {
+  if (!out_i8 || !in_f16 || !weight_f16 || !sum_f16 || !scale_f16 || tokens < 0 || hidden < 1)
+    return OMNI_EINVAL;
+  if (hidden > VPT * NT_MAX) return OMNI_EINVAL;
+  if (tokens == 0) return OMNI_OK;
+  hipLaunchKernelGGL((general_norm_quant_kernel<true>), dim3(tokens), dim3(norm_block(hidden, true)),
+                     0, (hipStream_t)stream, (int8_t*)out_i8, (const half_t*)in_f16,
+                     (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden);
+  return omni_launch_status();
+}
+
+extern "C" int omni_silu_and_mul(void* out_f16, const void* in_f16, int tokens, int d, void* stream) {
+  if (!out_f16 || !in_f16 || tokens < 0 || d < 1) return OMNI_EINVAL;
+  if (tokens == 0) return OMNI_OK;
+  const size_t total = (size_t)tokens * d;
+  if (d % 8 == 0) {
+    size_t blocks = (total / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(silu_and_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (half_t*)out_f16, (const half_t*)in_f16, tokens, d);
+  } else {
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(silu_and_mul_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, (half_t*)out_f16, (const half_t*)in_f16, tokens, d);
+  }
+  return omni_launch_status();
+}

@@ -1,0 +1,597 @@
+// KV4 paged-cache kernels for MI355X (gfx950): padding offsets, prefill writer, decode attention.
+//
+// Replaces omniserve_backend.fused_attention_pure_dense.single_query_attention,
+// omniserve_backend.fused_attention_fine_grained_dense.apply_bias_rope_update_kv_cache (dense
+// heads) and compute_padding_offsets (reference: kernels/csrc/fused_attention/...).
+//
+// Page (per layer, K or V):  int4 data [H_kv][tpb][Dh/2] | fp16 scale [H_kv][tpb] | fp16 zero [H_kv][tpb]
+// A token row of one head is Dh/2 = 64 contiguous bytes, so 16 consecutive tokens of a head are
+// 1 KiB contiguous: one 16-B load per lane per wave.  Design (not a port of the TRT-LLM MMHA):
+//   * one workgroup per (kv head, sequence, KV split) serves ALL q heads of the GQA group, so the
+//     packed K/V bytes are fetched and dequantised once instead of once per q head;
+//   * 4 lanes own a token (32 dims each), dot products reduce with two xor shuffles;
+//   * scores live in LDS (two-pass softmax inside the split), partial (max, sum, O) per split are
+//     merged by a second tiny kernel (flash-decoding), so B*H_kv*S workgroups fill all 256 CUs;
+//   * dequant is the reference's fp16 fma(u4, scale, -scale*zero); dot products and P.V
+//     accumulate in fp32.
+#include "common.h"
+
+namespace omni {
+
+constexpr int DH = 128;          // head dim (the only one the QServe/LServe models use)
+constexpr int ROW_BYTES = DH / 2;
+
+struct KvLayout {
+  int tpb;            // tokens per block (power of two, multiple of 16)
+  int tpb_log2;
+  int num_kv_heads;
+  int bytes_per_seq;  // H_kv * tpb * Dh/2  (offset of the scale tail)
+};
+
+__host__ __device__ inline KvLayout make_layout(int tpb, int hkv) {
+  KvLayout l;
+  l.tpb = tpb;
+  int lg = 0;
+  while ((1 << lg) < tpb) ++lg;
+  l.tpb_log2 = lg;
+  l.num_kv_heads = hkv;
+  l.bytes_per_seq = hkv * tpb * ROW_BYTES;
+  return l;
+}
+
+// ------------------------------------------------------------------------------------------
+// compute_padding_offsets  (common/input_metadata_helper.cu:16-50)
+// ------------------------------------------------------------------------------------------
+__global__ void padding_offsets_kernel(int* __restrict__ out, const int* __restrict__ cu, int max_len) {
+  const int b = blockIdx.x;
+  const int begin = cu[b], end = cu[b + 1];
+  const int off = b * max_len - begin;
+  for (int i = begin + threadIdx.x; i < end; i += blockDim.x) out[i] = off;
+}
+
+// ------------------------------------------------------------------------------------------
+// KV4 quantisation helpers (pure_dense/decoderMaskedMultiheadAttentionUtils.h:1838-1884,2070-2077)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t kv4_code(float x, float inv_scale, float zero) {
+  float v = x * inv_scale;
+  v = v + zero;
+  return rni_sat_u8(v) & 0xFu;
+}
+
+// ------------------------------------------------------------------------------------------
+// Prefill writer.  16 lanes own one head row: lane l holds elements [4l,4l+4) and [64+4l,64+4l+4)
+// (the two halves of 4 neox RoPE pairs).  A workgroup of 256 threads handles 16 head slots;
+// slots per token = Hq (q heads: RoPE in place) + Hkv (k: RoPE in place + quantise; v: quantise).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kv4_prefill_write_kernel(
+    half_t* __restrict__ qkv, const int* __restrict__ seq_lens, const int* __restrict__ padding_offsets,
+    const int64_t* __restrict__ kv_pointers, int tokens, int max_blocks, int num_heads, int num_kv_heads,
+    int max_seq_len, KvLayout lay, const float* __restrict__ rope, int rope_max_pos, int cyclic_len) {
+  const int slots_per_token = num_heads + num_kv_heads;
+  const long long slot_id = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = threadIdx.x & 15;
+  if (slot_id >= (long long)tokens * slots_per_token) return;
+  const int tok = (int)(slot_id / slots_per_token);
+  const int hs = (int)(slot_id % slots_per_token);
+  const int g = tok + padding_offsets[tok];
+  const int b = g / max_seq_len;
+  const int pos = g % max_seq_len;
+  const int actual_len = seq_lens[b];
+  if (pos >= actual_len) return;  // padding row (cannot happen with consistent metadata)
+  const int row_elems = (num_heads + 2 * num_kv_heads) * DH;
+  half_t* row = qkv + (size_t)tok * row_elems;
+  const bool is_kv = hs >= num_heads;
+  const int hk = hs - num_heads;
+  half_t* x = is_kv ? row + (size_t)(num_heads + hk) * DH : row + (size_t)hs * DH;
+
+  // RoPE (neox): pair (i, i+64), coefficients from the host table [pos][64][2]
+  const int rp = pos < rope_max_pos ? pos : rope_max_pos - 1;
+  const float* cs = rope + ((size_t)rp * (DH / 2) + 4 * l) * 2;
+  const v4f cs0 = *reinterpret_cast<const v4f*>(cs);
+  const v4f cs1 = *reinterpret_cast<const v4f*>(cs + 4);
+  const float c[4] = {cs0[0], cs0[2], cs1[0], cs1[2]};
+  const float s[4] = {cs0[1], cs0[3], cs1[1], cs1[3]};
+  typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+  const v4h lo = *reinterpret_cast<const v4h*>(x + 4 * l);
+  const v4h hi = *reinterpret_cast<const v4h*>(x + 64 + 4 * l);
+  v4h rlo, rhi;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = (float)lo[j], bb = (float)hi[j];
+    const float t0 = c[j] * a, t1 = s[j] * bb;
+    const float t2 = c[j] * bb, t3 = s[j] * a;
+    rlo[j] = (half_t)(t0 - t1);
+    rhi[j] = (half_t)(t2 + t3);
+  }
+  *reinterpret_cast<v4h*>(x + 4 * l) = rlo;
+  *reinterpret_cast<v4h*>(x + 64 + 4 * l) = rhi;
+  if (!is_kv) return;
+
+  // retrieval-head validity window (applyBiasRopeUpdateKVCache.h:300-304, sink_token_len = 0)
+  int lower = actual_len - cyclic_len;
+  if (lower < 0) lower = 0;
+  if (pos < lower) return;
+
+  const int page = pos >> lay.tpb_log2, slot = pos & (lay.tpb - 1);
+  const int64_t* tab = kv_pointers + (size_t)b * 2 * max_blocks;
+  const half_t* v = row + (size_t)(num_heads + num_kv_heads + hk) * DH;
+  const v4h vlo = *reinterpret_cast<const v4h*>(v + 4 * l);
+  const v4h vhi = *reinterpret_cast<const v4h*>(v + 64 + 4 * l);
+
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const v4h a = which == 0 ? rlo : vlo;
+    const v4h bq = which == 0 ? rhi : vhi;
+    float mx = (float)a[0], mn = (float)a[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mx = __builtin_fmaxf(mx, __builtin_fmaxf((float)a[j], (float)bq[j]));
+      mn = __builtin_fminf(mn, __builtin_fminf((float)a[j], (float)bq[j]));
+    }
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) {
+      mx = __builtin_fmaxf(mx, __shfl_xor(mx, m, 64));
+      mn = __builtin_fminf(mn, __shfl_xor(mn, m, 64));
+    }
+    const float range = mx - mn;
+    const half_t scale_h = (half_t)(range / 15.0f);
+    const float nm = -15.0f * mn;
+    const half_t zero_h = (half_t)(nm / range);
+    const float inv = 1.0f / (float)scale_h;
+    const float z = (float)zero_h;
+    uint8_t* base = reinterpret_cast<uint8_t*>(tab[which * max_blocks + page]);
+    uint8_t* dst = base + ((size_t)hk * lay.tpb + slot) * ROW_BYTES;
+    uint32_t q[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      q[j] = kv4_code((float)a[j], inv, z);
+      q[4 + j] = kv4_code((float)bq[j], inv, z);
+    }
+    *reinterpret_cast<uint16_t*>(dst + 2 * l) = (uint16_t)(q[0] | (q[1] << 4) | (q[2] << 8) | (q[3] << 12));
+    *reinterpret_cast<uint16_t*>(dst + 32 + 2 * l) = (uint16_t)(q[4] | (q[5] << 4) | (q[6] << 8) | (q[7] << 12));
+    if (l == 0) {
+      half_t* sc = reinterpret_cast<half_t*>(base + lay.bytes_per_seq) + hk * lay.tpb + slot;
+      sc[0] = scale_h;
+      sc[lay.num_kv_heads * lay.tpb] = zero_h;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Decode attention
+// ------------------------------------------------------------------------------------------
+// unpack 16 packed bytes (32 codes) and dequantise with fp16 fma(u, scale, c), c = h(-scale*zero).
+// Output order per 32-bit word of 8 codes e0..e7: half2 pairs (e0,e4) (e1,e5) (e2,e6) (e3,e7),
+// i.e. out[w*4 + j] = {e_j, e_{j+4}} of word w (the q operand is loaded in the same order).
+__device__ __forceinline__ void kv4_dequant16(const uint4 raw, v2h scale2, v2h c2, v2h out[16]) {
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+  const v2h k1024 = {(half_t)1024.0f, (half_t)1024.0f};
+  const v2h k16th = {(half_t)0.0625f, (half_t)0.0625f};
+  const v2h k64 = {(half_t)64.0f, (half_t)64.0f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t x = w[i], y = w[i] >> 8;
+    uint32_t h0 = (x & 0x000f000fu) | 0x64006400u;  // {1024+e0, 1024+e4}
+    uint32_t h1 = (x & 0x00f000f0u) | 0x64006400u;  // {1024+16 e1, 1024+16 e5}
+    uint32_t h2 = (y & 0x000f000fu) | 0x64006400u;  // e2, e6
+    uint32_t h3 = (y & 0x00f000f0u) | 0x64006400u;  // e3, e7
+    v2h u0 = __builtin_bit_cast(v2h, h0) - k1024;
+    v2h u1 = __builtin_elementwise_fma(__builtin_bit_cast(v2h, h1), k16th, -k64);
+    v2h u2 = __builtin_bit_cast(v2h, h2) - k1024;
+    v2h u3 = __builtin_elementwise_fma(__builtin_bit_cast(v2h, h3), k16th, -k64);
+    out[i * 4 + 0] = __builtin_elementwise_fma(u0, scale2, c2);
+    out[i * 4 + 1] = __builtin_elementwise_fma(u1, scale2, c2);
+    out[i * 4 + 2] = __builtin_elementwise_fma(u2, scale2, c2);
+    out[i * 4 + 3] = __builtin_elementwise_fma(u3, scale2, c2);
+  }
+}
+
+__device__ __forceinline__ float dot2_acc(v2h a, v2h b, float acc) {
+  return __builtin_amdgcn_fdot2(a, b, acc, false);
+}
+
+struct DecodeArgs {
+  half_t* out;             // [B,Hq,128]
+  const half_t* q;         // row stride q_stride
+  const half_t* k;
+  const half_t* v;
+  int64_t q_stride, kv_stride;
+  const int64_t* kv_pointers;  // [B,2,max_blocks]
+  const int* lengths;
+  int batch, max_blocks, num_heads, num_kv_heads;
+  KvLayout lay;
+  int nsplit;              // KV splits (grid.x)
+  int split_tokens;        // max tokens per split (multiple of 16)
+  const float* rope;
+  int rope_max_pos;
+  float* part_ml;          // [B,Hq,S,2]
+  float* part_o;           // [B,Hq,S,128]
+};
+
+constexpr int DEC_THREADS = 256;
+constexpr int DEC_WAVES = DEC_THREADS / 64;
+
+// G = q heads served per workgroup (<= 4); grid = (S, Hkv * nsub, B), nsub = (Hq/Hkv)/G.
+template <int G>
+__global__ __launch_bounds__(DEC_THREADS) void kv4_decode_partial_kernel(DecodeArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // LDS carve: q_lds [G][128] fp16 | kcur [128] fp16 | vcur [128] fp16 | red [64] f32 |
+  //            scores [G][split_tokens + 16] f32 | obuf [64][128] f32 (reduction scratch)
+  half_t* q_lds = reinterpret_cast<half_t*>(smem);
+  half_t* kcur = q_lds + G * DH;
+  half_t* vcur = kcur + DH;
+  float* red = reinterpret_cast<float*>(vcur + DH);
+  float* scores = red + 64;
+  const int sstride = p.split_tokens + 16;
+  float* obuf = scores + G * sstride;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x;
+  const int qg = (p.num_heads / p.num_kv_heads) / G;   // sub-blocks of q heads per kv head
+  const int hk = blockIdx.y / qg;
+  const int sub = blockIdx.y % qg;
+  const int hq0 = hk * (p.num_heads / p.num_kv_heads) + sub * G;
+  const int b = blockIdx.z;
+  const int tlen = p.lengths[b] - 1;  // history length = RoPE position = append slot
+  const KvLayout lay = p.lay;
+  const int64_t* ktab = p.kv_pointers + (size_t)b * 2 * p.max_blocks;
+  const int64_t* vtab = ktab + p.max_blocks;
+  const float inv_sqrt_dh = 0.08838834764831845f;  // 1/sqrt(128)
+
+  // split token range [t0, t1)
+  int per = (tlen + p.nsplit - 1) / p.nsplit;
+  per = (per + 15) & ~15;
+  if (per > p.split_tokens) per = p.split_tokens;  // host guarantees nsplit*split_tokens >= max ctx
+  const int t0 = min(tlen, split * per);
+  const int t1 = (split == p.nsplit - 1) ? tlen : min(tlen, t0 + per);
+  const int nt = t1 - t0;
+  // the split that also owns the current (un-quantised) token: the last one
+  const bool owns_cur = split == p.nsplit - 1;
+
+  // ---- RoPE q (and k of the current token) into LDS ------------------------------------------
+  {
+    const int rp = tlen < p.rope_max_pos ? tlen : p.rope_max_pos - 1;
+    const float* cs = p.rope + (size_t)rp * DH;  // [64][2]
+    for (int idx = tid; idx < (G + 1) * 64; idx += DEC_THREADS) {
+      const int h = idx >> 6, i = idx & 63;
+      if (h == G && !owns_cur) continue;
+      const half_t* src = h < G ? p.q + (size_t)b * p.q_stride + (size_t)(hq0 + h) * DH
+                                : p.k + (size_t)b * p.kv_stride + (size_t)hk * DH;
+      half_t* dst = h < G ? q_lds + h * DH : kcur;
+      const float c = cs[2 * i], s = cs[2 * i + 1];
+      const float a = (float)src[i], bb = (float)src[i + 64];
+      const float t0f = c * a, t1f = s * bb, t2f = c * bb, t3f = s * a;
+      dst[i] = (half_t)(t0f - t1f);
+      dst[i + 64] = (half_t)(t2f + t3f);
+    }
+    if (owns_cur && tid < DH) vcur[tid] = p.v[(size_t)b * p.kv_stride + (size_t)hk * DH + tid];
+  }
+  __syncthreads();
+
+  // ---- pass 1: scores = q.K / sqrt(Dh) ---------------------------------------------------------
+  const int part = lane & 3;    // 32-dim part of the row
+  const int tslot = lane >> 2;  // token within a 16-token group
+  float mloc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) mloc[g] = -1e30f;
+  {
+    // q part in the dequant order: word w (8 dims), pair j -> dims (8w + j, 8w + j + 4)
+    v2h qreg[G][16];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const half_t* qp = q_lds + g * DH + part * 32 + w * 8 + j;
+          qreg[g][w * 4 + j] = (v2h){qp[0], qp[4]};
+        }
+    for (int base = wave * 16; base < nt; base += DEC_WAVES * 16) {
+      const int ti = base + tslot;  // index inside the split
+      const int tok = t0 + ti;
+      const bool valid = ti < nt;
+      uint4 raw = make_uint4(0, 0, 0, 0);
+      half_t sc = (half_t)0.0f, ze = (half_t)0.0f;
+      if (valid) {
+        const uint8_t* pg = reinterpret_cast<const uint8_t*>(ktab[tok >> lay.tpb_log2]);
+        const int slot = tok & (lay.tpb - 1);
+        raw = *reinterpret_cast<const uint4*>(pg + ((size_t)hk * lay.tpb + slot) * ROW_BYTES + part * 16);
+        const half_t* tail = reinterpret_cast<const half_t*>(pg + lay.bytes_per_seq) + hk * lay.tpb + slot;
+        sc = tail[0];
+        ze = tail[lay.num_kv_heads * lay.tpb];
+      }
+      const half_t ch = (half_t)(-(float)sc * (float)ze);
+      v2h kd[16];
+      kv4_dequant16(raw, (v2h){sc, sc}, (v2h){ch, ch}, kd);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = dot2_acc(kd[i], qreg[g][i], acc);
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        const float sv = valid ? acc * inv_sqrt_dh : -1e30f;
+        mloc[g] = __builtin_fmaxf(mloc[g], sv);
+        if (part == 0) scores[g * sstride + ti] = sv;   // ti < split_tokens + 16 always
+      }
+    }
+  }
+  // current token: q . k_cur with fp32 accumulation of the fp16 operands
+  float scur[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) scur[g] = 0.0f;
+  if (owns_cur) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float a = (float)q_lds[g * DH + lane] * (float)kcur[lane] +
+                (float)q_lds[g * DH + 64 + lane] * (float)kcur[64 + lane];
+      a = wave_sum64(a);
+      scur[g] = a * inv_sqrt_dh;
+      mloc[g] = __builtin_fmaxf(mloc[g], scur[g]);
+    }
+  }
+  // block max per head
+  float mblk[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float wm = wave_max64(mloc[g]);
+    __syncthreads();
+    if (lane == 0) red[wave] = wm;
+    __syncthreads();
+    float m = red[0];
+#pragma unroll
+    for (int w = 1; w < DEC_WAVES; ++w) m = __builtin_fmaxf(m, red[w]);
+    mblk[g] = m;
+  }
+  // p = exp(s - m) in place, block sum
+  float lblk[G];
+  const int ntp = (nt + 15) & ~15;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float ls = 0.0f;
+    for (int i = tid; i < ntp; i += DEC_THREADS) {
+      const float e = i < nt ? __expf(scores[g * sstride + i] - mblk[g]) : 0.0f;
+      scores[g * sstride + i] = e;
+      ls += e;
+    }
+    const float ws = wave_sum64(ls);
+    __syncthreads();
+    if (lane == 0) red[wave] = ws;
+    __syncthreads();
+    float l = red[0];
+#pragma unroll
+    for (int w = 1; w < DEC_WAVES; ++w) l += red[w];
+    lblk[g] = l;
+  }
+  float pcur[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    pcur[g] = owns_cur ? __expf(scur[g] - mblk[g]) : 0.0f;
+    lblk[g] += pcur[g];
+  }
+
+  // ---- pass 2: O = sum_t p_t * V_t -----------------------------------------------------------------
+  float o[G][32];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) o[g][i] = 0.0f;
+  for (int base = wave * 16; base < nt; base += DEC_WAVES * 16) {
+    const int ti = base + tslot;
+    const int tok = t0 + ti;
+    const bool valid = ti < nt;
+    uint4 raw = make_uint4(0, 0, 0, 0);
+    half_t sc = (half_t)0.0f, ze = (half_t)0.0f;
+    if (valid) {
+      const uint8_t* pg = reinterpret_cast<const uint8_t*>(vtab[tok >> lay.tpb_log2]);
+      const int slot = tok & (lay.tpb - 1);
+      raw = *reinterpret_cast<const uint4*>(pg + ((size_t)hk * lay.tpb + slot) * ROW_BYTES + part * 16);
+      const half_t* tail = reinterpret_cast<const half_t*>(pg + lay.bytes_per_seq) + hk * lay.tpb + slot;
+      sc = tail[0];
+      ze = tail[lay.num_kv_heads * lay.tpb];
+    }
+    const half_t ch = (half_t)(-(float)sc * (float)ze);
+    v2h vd[16];
+    kv4_dequant16(raw, (v2h){sc, sc}, (v2h){ch, ch}, vd);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float pv = scores[g * sstride + ti];  // 0 for masked tokens
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        // vd[w*4+j] = dims (8w+j, 8w+j+4)
+        o[g][2 * i] += pv * (float)vd[i][0];
+        o[g][2 * i + 1] += pv * (float)vd[i][1];
+      }
+    }
+  }
+
+  // ---- reduce O over the 64 (wave, token-slot) partials via LDS, one head at a time --------------
+  // obuf[(wave*16 + tslot)][128] with this lane's dims: word w, pair j -> dims part*32 + 8w + j (+4)
+  for (int g = 0; g < G; ++g) {
+    __syncthreads();
+    float* dst = obuf + (size_t)(wave * 16 + tslot) * DH + part * 32;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dst[w * 8 + j] = o[g][2 * (w * 4 + j)];
+        dst[w * 8 + j + 4] = o[g][2 * (w * 4 + j) + 1];
+      }
+    __syncthreads();
+    // 256 threads: dim d = tid & 127, half = tid >> 7 sums 32 partial rows each
+    const int d = tid & 127, hf = tid >> 7;
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) acc += obuf[(size_t)(hf * 32 + r) * DH + d];
+    __syncthreads();
+    if (hf == 1) obuf[d] = acc;
+    __syncthreads();
+    if (hf == 0) {
+      acc += obuf[d];
+      if (owns_cur) acc += pcur[g] * (float)vcur[d];
+      const size_t pi = ((size_t)b * p.num_heads + hq0 + g) * p.nsplit + split;
+      p.part_o[pi * DH + d] = acc;
+      if (d == 0) {
+        p.part_ml[pi * 2 + 0] = mblk[g];
+        p.part_ml[pi * 2 + 1] = lblk[g];
+      }
+    }
+  }
+
+  // ---- append the current token (quantised) to the cache ------------------------------------------
+  // (reference: only the first q head of a GQA group writes; here: sub-block 0 of the owning split)
+  if (owns_cur && sub == 0 && wave < 2) {
+    const half_t* src = wave == 0 ? kcur : vcur;
+    const int64_t* tab = wave == 0 ? ktab : vtab;
+    const float x0 = (float)src[lane], x1 = (float)src[64 + lane];
+    const float mx = wave_max64(__builtin_fmaxf(x0, x1));
+    const float mn = -wave_max64(-__builtin_fminf(x0, x1));
+    const float range = mx - mn;
+    const half_t scale_h = (half_t)(range / 15.0f);
+    const float nm = -15.0f * mn;
+    const half_t zero_h = (half_t)(nm / range);
+    const float inv = 1.0f / (float)scale_h, z = (float)zero_h;
+    uint8_t* pg = reinterpret_cast<uint8_t*>(tab[tlen >> lay.tpb_log2]);
+    const int slot = tlen & (lay.tpb - 1);
+    uint8_t* dst = pg + ((size_t)hk * lay.tpb + slot) * ROW_BYTES;
+    // lane i holds elements i and 64+i; byte j packs elements (2j, 2j+1)
+    const uint32_t c0 = kv4_code(x0, inv, z), c1 = kv4_code(x1, inv, z);
+    const uint32_t n0 = __shfl_down(c0, 1, 64), n1 = __shfl_down(c1, 1, 64);
+    if ((lane & 1) == 0) {
+      dst[lane >> 1] = (uint8_t)(c0 | (n0 << 4));
+      dst[32 + (lane >> 1)] = (uint8_t)(c1 | (n1 << 4));
+    }
+    if (lane == 0) {
+      half_t* scp = reinterpret_cast<half_t*>(pg + lay.bytes_per_seq) + hk * lay.tpb + slot;
+      scp[0] = scale_h;
+      scp[lay.num_kv_heads * lay.tpb] = zero_h;
+    }
+  }
+}
+
+// merge the per-split partials: out = sum_s e^{m_s-M} O_s / (sum_s e^{m_s-M} l_s + 1e-6)
+__global__ __launch_bounds__(128) void kv4_decode_merge_kernel(half_t* __restrict__ out,
+                                                                const float* __restrict__ part_ml,
+                                                                const float* __restrict__ part_o, int nsplit) {
+  const size_t bh = blockIdx.x;
+  const int d = threadIdx.x;
+  float M = -1e30f;
+  for (int s = 0; s < nsplit; ++s) M = __builtin_fmaxf(M, part_ml[(bh * nsplit + s) * 2]);
+  float l = 0.0f, o = 0.0f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float w = __expf(part_ml[(bh * nsplit + s) * 2] - M);
+    l += w * part_ml[(bh * nsplit + s) * 2 + 1];
+    o += w * part_o[(bh * nsplit + s) * DH + d];
+  }
+  out[bh * DH + d] = (half_t)(o * (1.0f / (l + 1e-6f)));
+}
+
+struct DecodePlan {
+  int nsplit, split_tokens, g;
+  size_t lds_bytes;
+};
+
+static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int max_context) {
+  DecodePlan pl;
+  const int group = num_heads / num_kv_heads;
+  pl.g = group >= 4 ? 4 : group;  // group in {1,2,4,8,...}
+  const int wgs_per_split = batch * num_kv_heads * (group / pl.g);
+  int s = (768 + wgs_per_split - 1) / wgs_per_split;  // ~3 workgroups per CU
+  const int max_s = (max_context + 63) / 64;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  int st = ((max_context + s - 1) / s + 15) & ~15;
+  while (st > 1536) {  // LDS bound on the score buffer (<= 64 KiB dynamic LDS)
+    ++s;
+    st = ((max_context + s - 1) / s + 15) & ~15;
+  }
+  pl.nsplit = s;
+  pl.split_tokens = st;
+  pl.lds_bytes = (size_t)(pl.g + 2) * DH * 2 + 64 * 4 + (size_t)pl.g * (st + 16) * 4 + 64 * DH * 4;
+  return pl;
+}
+
+}  // namespace omni
+
+using namespace omni;
+
+extern "C" int omni_compute_padding_offsets(void* out_i32, const void* cu_seqlens_i32, int batch,
+                                            int max_len, int total_tokens, void* stream) {
+  if (!out_i32 || !cu_seqlens_i32 || batch < 0 || max_len < 0 || total_tokens < 0) return OMNI_EINVAL;
+  if (batch == 0) return OMNI_OK;
+  hipLaunchKernelGGL(padding_offsets_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream,
+                     (int*)out_i32, (const int*)cu_seqlens_i32, max_len);
+  return omni_launch_status();
+}
+
+extern "C" int omni_kv4_prefill_write(void* qkv_f16, const void* seq_lens_i32,
+                                      const void* padding_offsets_i32, const void* kv_pointers_i64,
+                                      int tokens, int batch, int max_blocks, int num_heads,
+                                      int num_kv_heads, int head_dim, int max_seq_len,
+                                      int tokens_per_block, const void* rope_cos_sin_f32,
+                                      int rope_max_pos, int max_position_embeddings, void* stream) {
+  if (!qkv_f16 || !seq_lens_i32 || !padding_offsets_i32 || !kv_pointers_i64 || !rope_cos_sin_f32)
+    return OMNI_EINVAL;
+  if (head_dim != DH || tokens < 0 || batch < 1 || num_heads < 1 || num_kv_heads < 1 ||
+      num_heads % num_kv_heads != 0 || tokens_per_block < 16 ||
+      (tokens_per_block & (tokens_per_block - 1)) != 0 || rope_max_pos < 1 || max_seq_len < 1)
+    return OMNI_EINVAL;
+  if (tokens == 0) return OMNI_OK;
+  const long long slots = (long long)tokens * (num_heads + num_kv_heads);
+  const unsigned blocks = (unsigned)((slots + 15) / 16);
+  hipLaunchKernelGGL(kv4_prefill_write_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     (half_t*)qkv_f16, (const int*)seq_lens_i32, (const int*)padding_offsets_i32,
+                     (const int64_t*)kv_pointers_i64, tokens, max_blocks, num_heads, num_kv_heads,
+                     max_seq_len, make_layout(tokens_per_block, num_kv_heads),
+                     (const float*)rope_cos_sin_f32, rope_max_pos, max_position_embeddings);
+  return omni_launch_status();
+}
+
+extern "C" size_t omni_kv4_decode_workspace_bytes(int batch, int num_heads, int head_dim, int max_context) {
+  (void)head_dim;
+  if (batch < 1 || num_heads < 1) return 0;
+  // nsplit <= 64 by construction
+  return (size_t)batch * num_heads * 64 * (DH + 2) * sizeof(float);
+}
+
+extern "C" int omni_kv4_decode_attention(void* out_f16, const void* q_f16, const void* k_f16,
+                                         const void* v_f16, int64_t q_stride, int64_t kv_stride,
+                                         const void* kv_pointers_i64, const void* lengths_i32,
+                                         int batch, int max_blocks, int num_heads, int num_kv_heads,
+                                         int head_dim, int tokens_per_block, int max_context,
+                                         const void* rope_cos_sin_f32, int rope_max_pos,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (!out_f16 || !q_f16 || !k_f16 || !v_f16 || !kv_pointers_i64 || !lengths_i32 || !rope_cos_sin_f32 ||
+      !workspace)
+    return OMNI_EINVAL;
+  if (head_dim != DH || batch < 1 || num_heads < 1 || num_kv_heads < 1 || num_heads % num_kv_heads != 0 ||
+      tokens_per_block < 16 || (tokens_per_block & (tokens_per_block - 1)) != 0 || max_context < 1 ||
+      rope_max_pos < 1)
+    return OMNI_EINVAL;
+  const int group = num_heads / num_kv_heads;
+  if (group != 1 && group != 2 && group % 4 != 0) return OMNI_EINVAL;
+  const DecodePlan pl = plan_decode(batch, num_heads, num_kv_heads, max_context);
+  const size_t need = (size_t)batch * num_heads * pl.nsplit * (DH + 2) * sizeof(float);
+  if (workspace_bytes < need) return OMNI_ENOMEM;
+  DecodeArgs a;
+  a.out = (half_t*)out_f16; a.q = (const half_t*)q_f16; a.k = (const half_t*)k_f16; a.v = (const half_t*)v_f16;
+  a.q_stride = q_stride; a.kv_stride = kv_stride;
+  a.kv_pointers = (const int64_t*)kv_pointers_i64; a.lengths = (const int*)lengths_i32;
+  a.batch = batch; a.max_blocks = max_blocks; a.num_heads = num_heads; a.num_kv_heads = num_kv_heads;
+  a.lay = make_layout(tokens_per_block, num_kv_heads);
+  a.nsplit = pl.nsplit; a.split_tokens = pl.split_tokens;
+  a.rope = (const float*)rope_cos_sin_f32; a.rope_max_pos = rope_max_pos;
+  a.part_ml = (float*)workspace;
+  a.part_o = a.part_ml + (size_t)batch * num_heads * pl.nsplit * 2;
+  dim3 grid(pl.nsplit, num_kv_heads * (group / pl.g), batch);
+  hipStream_t st = (hipStream_t)stream;
+  switch (pl.g) {
+    case 1: hipLaunchKernelGGL((kv4_decode_partial_kernel<1>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); break;
+    case 2: hipLaunchKernelGGL((kv4_decode_partial_kernel<2>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); break;
+    default: hipLaunchKernelGGL((kv4_decode_partial_kernel<4>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); break;
+  }
+  hipLaunchKernelGGL(kv4_decode_merge_kernel, dim3(batch * num_heads), dim3(128), 0, st, (half_t*)out_f16,
+                     a.part_ml, a.part_o, pl.nsplit);
+  return omni_launch_status();
+}

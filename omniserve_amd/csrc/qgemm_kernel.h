@@ -1,0 +1,355 @@
+// W4A8 (per-channel / per-group) and W8A8 GEMM for MI355X (gfx950), hand-written HIP.
+//
+// Replaces omniserve_backend.qgemm_w4a8_per_chn / qgemm_w4a8_per_group / qgemm_w8a8
+// (reference: kernels/csrc/qgemm/*/gemm_cuda.cu).  Not a translation of the CUDA kernels:
+//
+//  * The packed weight tile (32 n x 32 k codes = 512 B, lane = n3*4+k6, byte = k5*8+n2*4+k7,
+//    nibble n1; w4a8_linear.py:296-327) was shaped for mma.m16n8k32 fragments.  Here a wave
+//    streams two tile rows (64 output channels) straight from HBM into VGPRs with one
+//    16-B load per lane, and the unpacked dwords ARE the A operand of v_mfma_i32_16x16x64_i8:
+//    lane L takes chunk (n3 = L&7, k6 = L>>4) of tile row 2*ng + ((L>>3)&1); the four
+//    (n1,n2) row sets of a chunk become four MFMAs.  The dot product is invariant under a
+//    permutation of k shared by both operands, so the int8 activations are staged into LDS
+//    in the matching k order (no cross-lane shuffles, no LDS round trip for weights).
+//  * Activations (shared by the workgroup's waves) go HBM/L2 -> VGPR -> LDS once per 256-k
+//    chunk, double buffered, one barrier per chunk; weights are prefetched one chunk ahead.
+//  * Decode shapes (M <= 128) split K over workgroups so that all 256 CUs stream weights;
+//    partial int32 tiles go to a scratch slab and a tiny epilogue kernel reduces them
+//    (integer addition: exact and order independent).
+//  * Epilogues are compiled with -ffp-contract=off in the reference's operand order so the
+//    fp16 results are bit-identical to oracle/w4a8.py.
+#pragma once
+#include "common.h"
+
+namespace omni {
+
+constexpr int KSTEP = 64;    // k consumed by one round of MFMAs
+constexpr int KCHUNK = 256;  // k staged in LDS per barrier
+constexpr int STEPS = KCHUNK / KSTEP;
+
+enum { MODE_CHN = 0, MODE_GRP = 1, MODE_W8 = 2 };
+
+struct GemmArgs {
+  const int8_t* A;        // [M,K]
+  const uint8_t* W;       // packed [N,K/2] (W4) or [N,K] (W8)
+  const uint8_t* s2s;     // [K/128, N] per-group scales (unsigned bytes)
+  const uint8_t* s2z;     // [K/128, N] per-group zeros
+  const half_t* wscales;  // [N]
+  const half_t* ascales;  // [M]
+  const half_t* wsz;      // [N]
+  const half_t* asum;     // [M]
+  half_t* out;            // [M, out_stride]
+  int32_t* slab;          // [SK][M][N] when split
+  int M, N, K;
+  int64_t out_stride;
+  int kslice;             // k per split (multiple of 64)
+};
+
+// per-byte add mod 256 (CUDA __vadd4)
+__device__ __forceinline__ uint32_t vadd4(uint32_t x, uint32_t y) {
+  return ((x & 0x7f7f7f7fu) + (y & 0x7f7f7f7fu)) ^ ((x ^ y) & 0x80808080u);
+}
+
+template <int MODE>
+__device__ __forceinline__ half_t epilogue(int acc, float sw, float sa, float sz, float asum) {
+  if constexpr (MODE == MODE_CHN) {
+    float t = (float)acc * sw;
+    t = t * sa;
+    float c = sz * asum;
+    return (half_t)(t - c);
+  } else {
+    float s = sw * sa;
+    return (half_t)((float)acc * s);
+  }
+}
+
+// One workgroup = WAVES waves; wave w owns output channels [64*(WAVES*bx + w), +64);
+// all waves share the LDS-staged activation tile of MB*16 rows.
+template <int MB, int MODE, int WAVES, bool TO_SLAB, bool NT>
+__global__ __launch_bounds__(64 * WAVES) void w4a8_gemm_kernel(GemmArgs p) {
+  constexpr int MT = MB * 16;
+  constexpr int NTHREADS = 64 * WAVES;
+  constexpr int A_LOADS = (MT * KCHUNK / 16 + NTHREADS - 1) / NTHREADS;  // 16-B pieces per thread
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2][MT * KCHUNK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int ng = blockIdx.x * WAVES + wave;  // 64-channel group
+  const bool wave_active = (ng * 64) < p.N;
+  const int m0 = blockIdx.z * MT;
+  const int k_begin = blockIdx.y * p.kslice;
+  const int k_end = min(p.K, k_begin + p.kslice);
+  const int nsteps = (k_end - k_begin) / KSTEP;
+  const int nchunks = (nsteps + STEPS - 1) / STEPS;
+
+  // ---- weight addressing -------------------------------------------------------------
+  // W4: lane -> (x = tile row, c = n3, e = k6); W8: lane -> (i = row in 16-block, g = k piece)
+  const int lx = (lane >> 3) & 1, lc = lane & 7, le = lane >> 4;
+  const uint8_t* wbase;
+  if constexpr (MODE == MODE_W8) {
+    wbase = p.W + (size_t)(ng * 64 + (lane & 15)) * p.K + (lane >> 4) * 16;
+  } else {
+    wbase = p.W + ((size_t)(2 * ng + lx) * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
+  }
+  auto load_w = [&](int k, int j) -> uint4 {
+    // W4: j = tile parity inside the 64-k step.  W8: j = 16-row block (0..3).
+    const uint8_t* ptr;
+    if constexpr (MODE == MODE_W8) ptr = wbase + (size_t)j * 16 * p.K + k;
+    else ptr = wbase + (size_t)(k / 32 + j) * 512;
+    v4i v;
+    if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(ptr));
+    else v = *reinterpret_cast<const v4i*>(ptr);
+    return make_uint4((uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
+  };
+  constexpr int WL = (MODE == MODE_W8) ? 4 : 2;  // weight loads per lane per k-step
+  uint4 wq[STEPS][WL];
+
+  // ---- activation staging --------------------------------------------------------------
+  uint4 areg[A_LOADS];
+  auto load_a = [&](int chunk) {
+    const int kc = k_begin + chunk * KCHUNK;
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) {
+      const int id = tid + j * NTHREADS;
+      const int m = id / (KCHUNK / 16), kk = id % (KCHUNK / 16);
+      const int k = kc + kk * 16;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (id < MT * KCHUNK / 16 && (m0 + m) < p.M && k < k_end)
+        v = *reinterpret_cast<const uint4*>(p.A + (size_t)(m0 + m) * p.K + k);
+      areg[j] = v;
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) {
+      const int id = tid + j * NTHREADS;
+      if (id >= MT * KCHUNK / 16) continue;
+      const int m = id / (KCHUNK / 16), kk = id % (KCHUNK / 16);
+      if constexpr (MODE == MODE_W8) {
+        // row-major per k-step: [(ks*MT + m)*64 + g*16]
+        const int ks = kk >> 2, g = kk & 3;
+        *reinterpret_cast<uint4*>(&lds[buf][(ks * MT + m) * 64 + g * 16]) = areg[j];
+      } else {
+        // kk = 16-byte piece: kp = k-pair (64 k), tp = tile parity, d = k5;
+        // piece bytes [e*4+f] scatter to [(kp*MT+m)*64 + e*16 + tp*8 + d*4 + f]
+        const int kp = kk >> 2, tp = (kk >> 1) & 1, d = kk & 1;
+        uint8_t* dst = &lds[buf][(kp * MT + m) * 64 + tp * 8 + d * 4];
+        *reinterpret_cast<uint32_t*>(dst + 0) = areg[j].x;
+        *reinterpret_cast<uint32_t*>(dst + 16) = areg[j].y;
+        *reinterpret_cast<uint32_t*>(dst + 32) = areg[j].z;
+        *reinterpret_cast<uint32_t*>(dst + 48) = areg[j].w;
+      }
+    }
+  };
+
+  v4i acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) acc[mb][ab] = (v4i){0, 0, 0, 0};
+
+  // ---- prologue --------------------------------------------------------------------------
+  if (wave_active) {
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+      if (s < nsteps) {
+#pragma unroll
+        for (int j = 0; j < WL; ++j) wq[s][j] = load_w(k_begin + s * KSTEP, j);
+      }
+  }
+  load_a(0);
+  store_a(0);
+
+  // per-group second-level params for the current chunk (2 groups of 128 per chunk)
+  uint32_t gs[2] = {0, 0}, gz[2] = {0, 0};
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int kc = k_begin + c * KCHUNK;
+    const int steps_here = min(STEPS, nsteps - c * STEPS);
+    const bool has_next = (c + 1) < nchunks;
+    if (has_next) load_a(c + 1);
+    if constexpr (MODE == MODE_GRP) {
+      if (wave_active) {
+        const size_t col = (size_t)(2 * ng + lx) * 32 + lc * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int g = (kc + h * 128) / 128;
+          if (kc + h * 128 < k_end) {
+            gs[h] = *reinterpret_cast<const uint32_t*>(p.s2s + (size_t)g * p.N + col);
+            gz[h] = *reinterpret_cast<const uint32_t*>(p.s2z + (size_t)g * p.N + col);
+          }
+        }
+      }
+    }
+    __syncthreads();  // chunk c of A is visible in lds[c&1]
+    const uint8_t* abuf = lds[c & 1];
+
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      if (s < steps_here && wave_active) {
+        v4i wa[4];
+        if constexpr (MODE == MODE_W8) {
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+            wa[rb] = (v4i){(int)wq[s][rb].x, (int)wq[s][rb].y, (int)wq[s][rb].z, (int)wq[s][rb].w};
+        } else {
+          // dwords of a chunk: x=(k5=0,n2=0) y=(k5=0,n2=1) z=(k5=1,n2=0) w=(k5=1,n2=1)
+          const uint4 t0 = wq[s][0], t1 = wq[s][1];
+          const uint32_t d[2][4] = {{t0.x, t0.z, t1.x, t1.z}, {t0.y, t0.w, t1.y, t1.w}};
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              uint32_t u[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) u[q] = (d[b][q] >> (4 * a)) & 0x0F0F0F0Fu;
+              if constexpr (MODE == MODE_GRP) {
+                const int h = s >> 1;  // group inside the chunk
+                const uint32_t sc = (gs[h] >> (8 * (a * 2 + b))) & 0xFFu;
+                const uint32_t zr = ((gz[h] >> (8 * (a * 2 + b))) & 0xFFu) * 0x01010101u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) u[q] = vadd4(u[q] * sc, zr);
+              }
+              wa[a * 2 + b] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
+            }
+        }
+        // refill this step's weight registers for the next chunk
+        if (has_next && (c + 1) * STEPS + s < nsteps) {
+#pragma unroll
+          for (int j = 0; j < WL; ++j) wq[s][j] = load_w(kc + KCHUNK + s * KSTEP, j);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const v4i bf = *reinterpret_cast<const v4i*>(
+              abuf + ((s * MT + mb * 16 + (lane & 15)) * 4 + (lane >> 4)) * 16);
+#pragma unroll
+          for (int ab = 0; ab < 4; ++ab)
+            acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf, acc[mb][ab], 0, 0, 0);
+        }
+      }
+    }
+    if (has_next) store_a((c + 1) & 1);
+  }
+
+  if (!wave_active) return;
+
+  // ---- write back ------------------------------------------------------------------------
+  // D layout (16x16): col = lane&15 -> m, row = (lane>>4)*4 + r -> channel slot i.
+  // W4: i = x*8 + c, channel = ng*64 + x*32 + ab*8 + c  (4 consecutive channels per lane)
+  // W8: channel = ng*64 + rb*16 + i
+  const int mcol = lane & 15;
+  const int i0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = m0 + mb * 16 + mcol;
+    if (m >= p.M) continue;
+    float sa = 0.f, as = 0.f;
+    if constexpr (!TO_SLAB) {
+      sa = (float)p.ascales[m];
+      if constexpr (MODE == MODE_CHN) as = (float)p.asum[m];
+    }
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+      int n;
+      if constexpr (MODE == MODE_W8) n = ng * 64 + ab * 16 + i0;
+      else n = ng * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
+      const v4i a4 = acc[mb][ab];
+      if constexpr (TO_SLAB) {
+        int32_t* dst = p.slab + ((size_t)blockIdx.y * p.M + m) * p.N + n;
+        *reinterpret_cast<v4i*>(dst) = a4;
+      } else {
+        half_t o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sw = (float)p.wscales[n + r];
+          float sz = 0.f;
+          if constexpr (MODE == MODE_CHN) sz = (float)p.wsz[n + r];
+          o[r] = epilogue<MODE>(a4[r], sw, sa, sz, as);
+        }
+        *reinterpret_cast<uint2*>(p.out + (size_t)m * p.out_stride + n) =
+            *reinterpret_cast<const uint2*>(o);
+      }
+    }
+  }
+}
+
+// Reduce SK int32 slabs and apply the epilogue.  One thread = 4 consecutive channels of one row.
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p, int sk) {
+  const int n4 = p.N / 4;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)p.M * n4) return;
+  const int m = idx / n4, n = (idx % n4) * 4;
+  v4i s = (v4i){0, 0, 0, 0};
+  for (int k = 0; k < sk; ++k)
+    s += *reinterpret_cast<const v4i*>(p.slab + ((size_t)k * p.M + m) * p.N + n);
+  const float sa = (float)p.ascales[m];
+  float as = 0.f;
+  if constexpr (MODE == MODE_CHN) as = (float)p.asum[m];
+  half_t o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float sw = (float)p.wscales[n + r];
+    float sz = 0.f;
+    if constexpr (MODE == MODE_CHN) sz = (float)p.wsz[n + r];
+    o[r] = epilogue<MODE>(s[r], sw, sa, sz, as);
+  }
+  *reinterpret_cast<uint2*>(p.out + (size_t)m * p.out_stride + n) = *reinterpret_cast<const uint2*>(o);
+}
+
+// ---- host-side planning ----------------------------------------------------------------------
+struct GemmPlan {
+  int mb;      // 16-row blocks per workgroup tile
+  int waves;   // waves (64-channel groups) per workgroup
+  int sk;      // K splits
+  int kslice;  // k per split
+};
+
+// Tuning hook (tests / bench sweeps): waves<=0 and sk<=0 restore the heuristic.
+extern "C" void omni_gemm_set_plan_override(int waves, int sk);
+extern "C" void omni_gemm_get_plan(int M, int N, int K, int kalign, int* mb, int* waves, int* sk);
+GemmPlan plan_gemm(int M, int N, int K, int kalign);
+
+template <int MODE, int MB, int WAVES>
+static void launch_variant(const GemmArgs& a, const GemmPlan& pl, bool nt, hipStream_t st) {
+  dim3 grid((a.N / 64 + WAVES - 1) / WAVES, pl.sk, (a.M + MB * 16 - 1) / (MB * 16));
+  dim3 block(64 * WAVES);
+  if (pl.sk > 1) {
+    hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, true, true>), grid, block, 0, st, a);
+    const size_t total = (size_t)a.M * (a.N / 4);
+    hipLaunchKernelGGL((splitk_epilogue_kernel<MODE>), dim3((total + 255) / 256), dim3(256), 0, st, a, pl.sk);
+  } else {
+    if (nt) hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, false>), grid, block, 0, st, a);
+  }
+}
+
+template <int MODE>
+static int launch_gemm(GemmArgs a, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (a.M < 1 || a.N % 64 != 0 || a.K % 64 != 0 || a.K < 64) return OMNI_EINVAL;
+  if (MODE == MODE_GRP && a.K % 128 != 0) return OMNI_EINVAL;
+  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64);
+  if (pl.sk > 1) {
+    const size_t need = (size_t)pl.sk * a.M * a.N * sizeof(int32_t);
+    if (ws == nullptr || ws_bytes < need) return OMNI_ENOMEM;
+    a.slab = static_cast<int32_t*>(ws);
+  }
+  a.kslice = pl.kslice;
+  const bool nt = a.M <= 128;  // weights are read once: stream them past the caches
+  if (pl.waves == 1 && MODE != MODE_W8 && pl.mb <= 2) {
+    if (pl.mb == 1) launch_variant<MODE, 1, 1>(a, pl, nt, st);
+    else launch_variant<MODE, 2, 1>(a, pl, nt, st);
+  } else {
+    switch (pl.mb) {
+      case 1: launch_variant<MODE, 1, 4>(a, pl, nt, st); break;
+      case 2: launch_variant<MODE, 2, 4>(a, pl, nt, st); break;
+      case 4: launch_variant<MODE, 4, 4>(a, pl, nt, st); break;
+      default: launch_variant<MODE, 8, 4>(a, pl, nt, st); break;
+    }
+  }
+  return omni_launch_status();
+}
+
+}  // namespace omni
+

@@ -1,0 +1,15 @@
+// omni_w8a8_gemm: instantiates the W8A8 kernels (see qgemm_kernel.h).
+#include "qgemm_kernel.h"
+using namespace omni;
+
+extern "C" int omni_w8a8_gemm(const void* in_feats, const void* weight, const void* wscales,
+                              const void* ascales, void* out_feats, int M, int N, int K,
+                              int64_t out_row_stride, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  if (!in_feats || !weight || !wscales || !ascales || !out_feats) return OMNI_EINVAL;
+  GemmArgs a{};
+  a.A = (const int8_t*)in_feats; a.W = (const uint8_t*)weight;
+  a.wscales = (const half_t*)wscales; a.ascales = (const half_t*)ascales;
+  a.out = (half_t*)out_feats; a.M = M; a.N = N; a.K = K; a.out_stride = out_row_stride;
+  return launch_gemm<MODE_W8>(a, workspace, workspace_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,211 @@
+"""Minimal decode-step driver for the QServe W4A8KV4 Llama path on one MI355X.
+
+Not an engine: it only wires the kernels in the order of the reference's decoder layer
+(omniserve/modeling/models/llama_w4a8_unpad.py:406-438) on synthetic weights so
+that bench.py / smoke() can time the hot path named by BASELINE.json:
+
+    rms_norm_general_fuse_sum -> qkv GEMM -> single_query_attention (RoPE + KV4 append fused)
+    -> invoke_quant_fuse_sum -> o_proj GEMM -> residual add -> rms_norm_general_fuse_sum
+    -> gate_up GEMM -> silu_and_mul -> invoke_quant_fuse_sum -> down GEMM -> residual add
+    ... x num_layers, then rms_norm -> fp16 lm_head -> argmax  (llama_w4a8_unpad.py:485-488,556-563)
+
+All calls go through the mirrored `omniserve_backend.*` modules, i.e. through the C ABI.
+The whole step is captured in one HIP graph (the reference launches ~322 kernels per step
+eagerly; at MI355X speeds the step is launch-bound otherwise).
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import torch
+
+from .backend import (activation_ops, fused_attention_pure_dense, fused_kernels, layernorm_ops,
+                      qgemm_w4a8_per_chn, qgemm_w4a8_per_group)
+from .rope import rope_table
+from . import _lib
+
+
+@dataclasses.dataclass
+class LlamaConfig:
+    hidden: int = 4096
+    inter: int = 14336
+    heads: int = 32
+    kv_heads: int = 8
+    head_dim: int = 128
+    layers: int = 32
+    vocab: int = 128256
+    rope_theta: float = 500000.0
+    eps: float = 1e-5
+    group_size: int = -1          # -1 = per-channel, 128 = g128
+
+    @staticmethod
+    def llama3_8b(group_size=-1):
+        return LlamaConfig(group_size=group_size)
+
+    @staticmethod
+    def tiny():
+        return LlamaConfig(hidden=256, inter=512, heads=4, kv_heads=2, layers=2, vocab=512)
+
+
+class W4A8Linear:
+    """Synthetic packed weights in the reference layout (w4a8_linear.py:43-100).  Any byte pattern
+    is a valid packing of uniform random 4-bit codes, so the weights are drawn on the device."""
+
+    def __init__(self, n, k, group_size, gen, device):
+        self.n, self.k, self.group = n, k, group_size
+        self.qweight = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, device=device, generator=gen).view(torch.int8)
+        self.s1_scales = (torch.rand((n,), device=device, generator=gen) * 0.018 + 0.002).half()
+        if group_size == -1:
+            zeros = torch.randint(0, 16, (n,), device=device, generator=gen).half()
+            self.s1_szeros = (zeros * self.s1_scales).half()
+        else:
+            ng = k // group_size
+            s2 = torch.randint(1, 9, (ng, n), device=device, generator=gen)
+            z = torch.randint(0, 16, (ng, n), device=device, generator=gen)
+            self.s2_scales = s2.to(torch.int8)
+            self.s2_zeros = (-(z * s2)).to(torch.int8)
+
+    def forward(self, x_i8, scales, sums, out):
+        if self.group == -1:
+            qgemm_w4a8_per_chn.gemm_forward_cuda(x_i8, self.qweight, self.s1_scales, scales, self.s1_szeros, sums, out)
+        else:
+            qgemm_w4a8_per_group.gemm_forward_cuda(x_i8, self.qweight, self.s2_zeros, self.s2_scales,
+                                                   self.s1_scales, scales, out)
+
+    def weight_bytes(self):
+        b = self.qweight.numel()
+        if self.group != -1:
+            b += self.s2_scales.numel() + self.s2_zeros.numel()
+        return b
+
+
+class DecodeRunner:
+    """bs sequences with `context` cached tokens each; step() decodes one token per sequence."""
+
+    def __init__(self, cfg: LlamaConfig, batch: int, context: int, max_new: int, device, seed=0,
+                 use_graph=True):
+        self.cfg, self.B, self.device = cfg, batch, device
+        c = cfg
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        self.gen = gen
+        qkv_n = (c.heads + 2 * c.kv_heads) * c.head_dim
+        self.layers = []
+        for _ in range(c.layers):
+            self.layers.append(dict(
+                ln1=(1.0 + 0.05 * torch.randn(c.hidden, device=device, generator=gen)).half(),
+                ln2=(1.0 + 0.05 * torch.randn(c.hidden, device=device, generator=gen)).half(),
+                qkv=W4A8Linear(qkv_n, c.hidden, c.group_size, gen, device),
+                o=W4A8Linear(c.hidden, c.hidden, c.group_size, gen, device),
+                gate_up=W4A8Linear(2 * c.inter, c.hidden, c.group_size, gen, device),
+                down=W4A8Linear(c.hidden, c.inter, c.group_size, gen, device)))
+        self.final_norm = torch.ones(c.hidden, device=device).half()
+        self.embed = (0.02 * torch.randn(c.vocab, c.hidden, device=device, generator=gen)).half()
+        self.lm_head = (0.02 * torch.randn(c.vocab, c.hidden, device=device, generator=gen)).half()
+
+        # ---- paged KV4 cache: one K pool and one V pool per layer (cache_engine.py:117-136) ----
+        self.tpb = 64
+        self.max_context = context + max_new + 1
+        pages_per_seq = (self.max_context + self.tpb - 1) // self.tpb
+        self.page_bytes = c.kv_heads * self.tpb * (c.head_dim // 2) + 2 * c.kv_heads * self.tpb * 2
+        n_pages = batch * pages_per_seq
+        self.block_tables = []
+        self.pools = []
+        data_bytes = c.kv_heads * self.tpb * (c.head_dim // 2)
+        for _ in range(c.layers):
+            pools = []
+            tab = torch.empty((batch, 2, pages_per_seq), dtype=torch.int64, device=device)
+            for kv in range(2):
+                pool = torch.empty((n_pages, self.page_bytes), dtype=torch.uint8, device=device)
+                pool[:, :data_bytes] = torch.randint(0, 256, (n_pages, data_bytes), dtype=torch.uint8,
+                                                     device=device, generator=gen)
+                tail = pool[:, data_bytes:].view(torch.float16).view(n_pages, 2, c.kv_heads * self.tpb)
+                tail[:, 0] = 0.25 * (0.5 + torch.rand((n_pages, c.kv_heads * self.tpb), device=device, generator=gen))
+                tail[:, 1] = 7.5
+                perm = torch.randperm(n_pages, device=device, generator=gen).view(batch, pages_per_seq)
+                tab[:, kv] = pool.data_ptr() + perm * self.page_bytes
+                pools.append(pool)
+            self.pools.append(pools)
+            self.block_tables.append(tab)
+
+        # ---- persistent activation buffers (the reference re-allocates them every step) ----------
+        B = batch
+        f16, i8 = torch.float16, torch.int8
+        self.x = torch.empty((B, c.hidden), dtype=f16, device=device)
+        self._q_hidden = torch.empty((B, c.hidden), dtype=i8, device=device)
+        self._q_inter = torch.empty((B, c.inter), dtype=i8, device=device)
+        self.act_scale = torch.empty((B,), dtype=f16, device=device)
+        self.act_sum = torch.empty((B,), dtype=f16, device=device)
+        self.qkv_buf = torch.empty((B, qkv_n), dtype=f16, device=device)
+        self.proj_buf = torch.empty((B, c.hidden), dtype=f16, device=device)
+        self.gate_up_buf = torch.empty((B, 2 * c.inter), dtype=f16, device=device)
+        self.mlp_act = torch.empty((B, c.inter), dtype=f16, device=device)
+        self.normed = torch.empty((B, c.hidden), dtype=f16, device=device)
+        self.lengths = torch.full((B,), context, dtype=torch.int32, device=device)
+        self.tokens = torch.randint(0, c.vocab, (B,), device=device, generator=gen)
+        rope_table(self.max_context + 1, c.head_dim, c.rope_theta, 1.0, device)  # pre-build (capture safe)
+        self.graph = None
+        self.use_graph = use_graph
+        self.steps_done = 0
+
+    def step(self):
+        """Decode one token for every sequence (one HIP-graph replay once captured)."""
+        if not self.use_graph:
+            self._eager_step()
+            self.steps_done += 1
+            return
+        if self.graph is None:
+            # warm up eagerly on a side stream (sizes the workspaces / RoPE table), roll the
+            # sequence state back, then capture the identical step
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                saved = (self.lengths.clone(), self.tokens.clone())
+                self._eager_step()
+                self.lengths.copy_(saved[0])
+                self.tokens.copy_(saved[1])
+            torch.cuda.current_stream().wait_stream(s)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._eager_step()
+        self.graph.replay()
+        self.steps_done += 1
+
+    def _eager_step(self):
+        # one decoder layer at decode shape = llama_w4a8_unpad.py:406-438
+        c = self.cfg
+        self.lengths.add_(1)
+        torch.index_select(self.embed, 0, self.tokens, out=self.x)
+        B = self.B
+        hq, hk, d = c.heads, c.kv_heads, c.head_dim
+        for li, L in enumerate(self.layers):
+            qa_h, qa_i = self._q_hidden, self._q_inter
+            layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln1"], self.act_sum, self.act_scale, c.eps, True)
+            L["qkv"].forward(qa_h, self.act_scale, self.act_sum, self.qkv_buf)
+            q = self.qkv_buf[:, : hq * d].view(B, hq, d)
+            k = self.qkv_buf[:, hq * d:(hq + hk) * d].view(B, hk, d)
+            v = self.qkv_buf[:, (hq + hk) * d:].view(B, hk, d)
+            attn = fused_attention_pure_dense.single_query_attention(
+                q, k, v, self.block_tables[li], self.lengths, None, 65536, self.tpb, hk * d // 2,
+                self.max_context, d, c.rope_theta, True, True, True)
+            fused_kernels.invoke_quant_fuse_sum(qa_h, attn.view(B, hq * d), self.act_sum, self.act_scale)
+            L["o"].forward(qa_h, self.act_scale, self.act_sum, self.proj_buf)
+            self.x.add_(self.proj_buf)
+            layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln2"], self.act_sum, self.act_scale, c.eps, True)
+            L["gate_up"].forward(qa_h, self.act_scale, self.act_sum, self.gate_up_buf)
+            activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
+            fused_kernels.invoke_quant_fuse_sum(qa_i, self.mlp_act, self.act_sum, self.act_scale)
+            L["down"].forward(qa_i, self.act_scale, self.act_sum, self.proj_buf)
+            self.x.add_(self.proj_buf)
+        layernorm_ops.rms_norm(self.normed, self.x, self.final_norm, c.eps, False)
+        logits = torch.matmul(self.normed, self.lm_head.t())
+        self.tokens.copy_(torch.argmax(logits, dim=-1))
+
+    # ---- accounting -----------------------------------------------------------
+    def gemm_weight_bytes_per_step(self):
+        return sum(L[n].weight_bytes() for L in self.layers for n in ("qkv", "o", "gate_up", "down"))
+
+    def kv_bytes_per_step(self, context):
+        c = self.cfg
+        per_tok = 2 * (c.kv_heads * c.head_dim // 2 + c.kv_heads * 4)
+        return per_tok * context * self.B * c.layers

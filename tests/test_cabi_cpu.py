@@ -1,0 +1,67 @@
+"""CPU-side checks of the drop-in boundary: the library builds/loads and exports exactly the
+symbols include/omniserve_hip.h declares; the Python mirror has the reference's module and
+function names and arities.  No compute calls (no GPU here)."""
+import inspect
+import os
+import re
+
+from omniserve_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "omniserve_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(omni_[a-z0-9_]+)\s*\(", src))
+
+
+def test_library_exports_every_declared_symbol():
+    h = _lib.lib()
+    syms = _header_symbols()
+    assert len(syms) >= 17
+    for s in syms:
+        assert hasattr(h, s), "library does not export %s" % s
+    assert syms == set(_lib.PROTOTYPES), "ctypes prototypes out of sync with the header"
+    assert h.omni_abi_version() == 1
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    h = _lib.lib()
+    # null pointers / bad shapes must return -EINVAL before any launch
+    assert h.omni_w4a8_per_chn_gemm(None, None, None, None, None, None, None, 16, 64, 64, 64, None, 0, None) == -22
+    assert h.omni_quant(None, None, None, 4, 128, None) == -22
+    assert h.omni_gemm_workspace_bytes(16, 4096, 4096) > 0
+    assert h.omni_gemm_workspace_bytes(4096, 4096, 4096) == 0
+
+
+# reference module -> {function: number of positional parameters}  (kernels/csrc/**.h)
+REFERENCE_API = {
+    "qgemm_w4a8_per_chn": {"gemm_forward_cuda": 7},
+    "qgemm_w4a8_per_group": {"gemm_forward_cuda": 7},
+    "qgemm_w8a8": {"w8a8_gemm_forward_cuda": 5},
+    "fused_kernels": {"invoke_quant": 3, "invoke_quant_fuse_sum": 4},
+    "layernorm_ops": {"rms_norm": 5, "rms_norm_general": 6, "rms_norm_general_fuse_sum": 7},
+    "activation_ops": {"silu_and_mul": 2},
+    "fused_attention_pure_dense": {"single_query_attention": 15, "apply_bias_rope_update_kv_cache": 15,
+                                   "compute_padding_offsets": 3},
+    "fused_attention_fine_grained_dense": {"apply_bias_rope_update_kv_cache": 27, "compute_padding_offsets": 3},
+}
+
+
+def test_python_mirror_has_reference_names_and_arities():
+    import importlib
+    for mod, fns in REFERENCE_API.items():
+        m = importlib.import_module("omniserve_backend." + mod)
+        for fn, n in fns.items():
+            f = getattr(m, fn)
+            assert len(inspect.signature(f).parameters) == n, (mod, fn)
+
+
+def test_ops_fail_loudly_without_device_tensors():
+    import pytest
+    import torch
+    import omniserve_backend.fused_kernels as fk
+    x = torch.zeros(2, 128, dtype=torch.float16)
+    with pytest.raises(RuntimeError):
+        fk.invoke_quant(torch.zeros(2, 128, dtype=torch.int8), x, torch.zeros(2, dtype=torch.float16))

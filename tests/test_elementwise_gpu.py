@@ -1,0 +1,82 @@
+"""Parity of quant / norm / activation kernels against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import elementwise as oe
+from tests.util import assert_f16_equal, dev, f16_ulp_diff, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _x(tokens, hidden, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((tokens, hidden)) * scale).astype(np.float16)
+
+
+@pytest.mark.parametrize("tokens,hidden", [(1, 128), (16, 4096), (37, 14336), (5, 1024), (3, 28672), (0, 4096)])
+@pytest.mark.parametrize("fuse", [False, True])
+def test_quant(tokens, hidden, fuse):
+    import omniserve_backend.fused_kernels as fk
+    x = _x(tokens, hidden, tokens + hidden, 3.0)
+    out = torch.empty((tokens, hidden), dtype=torch.int8, device=dev())
+    scale = torch.empty((tokens,), dtype=torch.float16, device=dev())
+    ssum = torch.empty((tokens,), dtype=torch.float16, device=dev())
+    if fuse:
+        fk.invoke_quant_fuse_sum(out, to_dev(x), ssum, scale)
+    else:
+        fk.invoke_quant(out, to_dev(x), scale)
+    torch.cuda.synchronize()
+    if tokens == 0:
+        return
+    q, s, sm = oe.quant_per_token(x, fuse)
+    assert np.array_equal(out.cpu().numpy(), q)
+    assert_f16_equal(scale, s, "scale")
+    if fuse:
+        assert_f16_equal(ssum, sm, "sum")
+
+
+@pytest.mark.parametrize("tokens,hidden", [(1, 128), (16, 4096), (33, 8192), (7, 5120), (4, 96)])
+@pytest.mark.parametrize("fuse", [False, True])
+def test_rms_norm_general(tokens, hidden, fuse):
+    import omniserve_backend.layernorm_ops as ln
+    x = _x(tokens, hidden, 3 * tokens + hidden, 2.0) + np.float16(0.25)   # non-zero mean matters
+    g = (1.0 + 0.1 * np.random.default_rng(1).standard_normal(hidden)).astype(np.float16)
+    out = torch.empty((tokens, hidden), dtype=torch.int8, device=dev())
+    scale = torch.empty((tokens,), dtype=torch.float16, device=dev())
+    ssum = torch.empty((tokens,), dtype=torch.float16, device=dev())
+    if fuse:
+        ln.rms_norm_general_fuse_sum(out, to_dev(x), to_dev(g), ssum, scale, 1e-5, True)
+    else:
+        ln.rms_norm_general(out, to_dev(x), to_dev(g), scale, 1e-5, True)
+    torch.cuda.synchronize()
+    q, s, sm = oe.rms_norm_general(x, g, 1e-5, fuse)
+    assert np.array_equal(out.cpu().numpy(), q)
+    assert_f16_equal(scale, s, "scale")
+    if fuse:
+        assert_f16_equal(ssum, sm, "sum")
+
+
+@pytest.mark.parametrize("tokens,hidden", [(1, 128), (16, 4096), (9, 8192)])
+def test_rms_norm(tokens, hidden):
+    import omniserve_backend.layernorm_ops as ln
+    x = _x(tokens, hidden, tokens, 2.0)
+    w = (1.0 + 0.1 * np.random.default_rng(2).standard_normal(hidden)).astype(np.float16)
+    out = torch.empty((tokens, hidden), dtype=torch.float16, device=dev())
+    ln.rms_norm(out, to_dev(x), to_dev(w), 1e-5, False)
+    torch.cuda.synchronize()
+    assert_f16_equal(out, oe.rms_norm(x, w, 1e-5), "rms_norm")
+
+
+@pytest.mark.parametrize("tokens,d", [(1, 64), (16, 14336), (5, 100), (33, 4096)])
+def test_silu_and_mul(tokens, d):
+    import omniserve_backend.activation_ops as act
+    x = _x(tokens, 2 * d, tokens + d, 2.0)
+    out = torch.empty((tokens, d), dtype=torch.float16, device=dev())
+    act.silu_and_mul(out, to_dev(x))
+    torch.cuda.synchronize()
+    want = oe.silu_and_mul(x)
+    # expf on the device vs numpy differ by <= 1 ulp in f32; after the two fp16 roundings the
+    # result may differ by one fp16 ulp in rare cases
+    assert f16_ulp_diff(out, want) <= 1
+    assert (np.asarray(out.cpu().numpy()).view(np.uint16) != want.view(np.uint16)).mean() < 1e-3
