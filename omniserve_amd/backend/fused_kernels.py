@@ -18,6 +18,8 @@ def invoke_quant(out, input, scale):
     if not torch.is_tensor(scale):
         raise NotImplementedError("invoke_quant: per-tensor (scalar scale) overload is not implemented")
     tokens, hidden = _shape(out, input)
+    if tokens == 0:
+        return
     rc = _lib.lib().omni_quant(out.data_ptr(), input.data_ptr(), scale.data_ptr(), tokens, hidden,
                                _lib.current_stream())
     _lib.check(rc, "fused_kernels.invoke_quant")
@@ -28,6 +30,8 @@ def invoke_quant_fuse_sum(out, input, input_sum, scale):
     if not torch.is_tensor(scale) or not torch.is_tensor(input_sum):
         raise NotImplementedError("invoke_quant_fuse_sum: scalar overload is not implemented")
     tokens, hidden = _shape(out, input)
+    if tokens == 0:
+        return
     rc = _lib.lib().omni_quant_fuse_sum(out.data_ptr(), input.data_ptr(), input_sum.data_ptr(),
                                         scale.data_ptr(), tokens, hidden, _lib.current_stream())
     _lib.check(rc, "fused_kernels.invoke_quant_fuse_sum")

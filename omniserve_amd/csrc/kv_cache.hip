@@ -243,7 +243,7 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_partial_kernel(DecodeA
   per = (per + 15) & ~15;
   if (per > p.split_tokens) per = p.split_tokens;  // host guarantees nsplit*split_tokens >= max ctx
   const int t0 = min(tlen, split * per);
-  const int t1 = (split == p.nsplit - 1) ? tlen : min(tlen, t0 + per);
+  const int t1 = (split == p.nsplit - 1) ? min(tlen, t0 + p.split_tokens) : min(tlen, t0 + per);
   const int nt = t1 - t0;
   // the split that also owns the current (un-quantised) token: the last one
   const bool owns_cur = split == p.nsplit - 1;

@@ -44,7 +44,7 @@ class LlamaConfig:
 
     @staticmethod
     def tiny():
-        return LlamaConfig(hidden=256, inter=512, heads=4, kv_heads=2, layers=2, vocab=512)
+        return LlamaConfig(hidden=512, inter=1024, heads=4, kv_heads=2, layers=2, vocab=512)
 
 
 class W4A8Linear:
@@ -96,7 +96,7 @@ class DecodeRunner:
                 ln1=(1.0 + 0.05 * torch.randn(c.hidden, device=device, generator=gen)).half(),
                 ln2=(1.0 + 0.05 * torch.randn(c.hidden, device=device, generator=gen)).half(),
                 qkv=W4A8Linear(qkv_n, c.hidden, c.group_size, gen, device),
-                o=W4A8Linear(c.hidden, c.hidden, c.group_size, gen, device),
+                o=W4A8Linear(c.hidden, c.heads * c.head_dim, c.group_size, gen, device),
                 gate_up=W4A8Linear(2 * c.inter, c.hidden, c.group_size, gen, device),
                 down=W4A8Linear(c.hidden, c.inter, c.group_size, gen, device)))
         self.final_norm = torch.ones(c.hidden, device=device).half()
@@ -134,6 +134,7 @@ class DecodeRunner:
         self.x = torch.empty((B, c.hidden), dtype=f16, device=device)
         self._q_hidden = torch.empty((B, c.hidden), dtype=i8, device=device)
         self._q_inter = torch.empty((B, c.inter), dtype=i8, device=device)
+        self._q_attn = torch.empty((B, c.heads * c.head_dim), dtype=i8, device=device)
         self.act_scale = torch.empty((B,), dtype=f16, device=device)
         self.act_sum = torch.empty((B,), dtype=f16, device=device)
         self.qkv_buf = torch.empty((B, qkv_n), dtype=f16, device=device)
@@ -188,8 +189,8 @@ class DecodeRunner:
             attn = fused_attention_pure_dense.single_query_attention(
                 q, k, v, self.block_tables[li], self.lengths, None, 65536, self.tpb, hk * d // 2,
                 self.max_context, d, c.rope_theta, True, True, True)
-            fused_kernels.invoke_quant_fuse_sum(qa_h, attn.view(B, hq * d), self.act_sum, self.act_scale)
-            L["o"].forward(qa_h, self.act_scale, self.act_sum, self.proj_buf)
+            fused_kernels.invoke_quant_fuse_sum(self._q_attn, attn.view(B, hq * d), self.act_sum, self.act_scale)
+            L["o"].forward(self._q_attn, self.act_scale, self.act_sum, self.proj_buf)
             self.x.add_(self.proj_buf)
             layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln2"], self.act_sum, self.act_scale, c.eps, True)
             L["gate_up"].forward(qa_h, self.act_scale, self.act_sum, self.gate_up_buf)

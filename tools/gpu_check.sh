@@ -1,0 +1,15 @@
+#!/bin/bash
+# One-shot GPU validation run (invoked through gpurun): layout probe, parity tests, smoke, bench,
+# GEMV plan sweep, rocprofv3 kernel stats.  Everything lands under gpurun_out/.
+set -u
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+O=gpurun_out
+echo "== probe" ; (hipcc --offload-arch=gfx950 -w tools/mfma_probe.hip -o /tmp/probe && timeout 60 /tmp/probe) 2>&1 | tee $O/probe.log
+echo "== pytest" ; timeout 1500 python -m pytest tests -m gpu -q --maxfail=30 -p no:cacheprovider 2>&1 | tail -80 | tee $O/pytest.log
+echo "== smoke" ; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -20 | tee $O/smoke.log
+echo "== bench" ; timeout 600 python bench.py --steps 64 --warmup 8 2>&1 | tail -20 | tee $O/bench.log
+echo "== sweep" ; timeout 600 python tools/gemv_sweep.py 16 2>&1 | tail -80 | tee $O/gemv_sweep.log
+echo "== rocprof" ; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/prof -o bench -- python $OLDPWD/bench.py --steps 32 --warmup 4 --no-extras) 2>&1 | tail -15 | tee $O/rocprof.log
+ls -R $O/prof 2>/dev/null | head -30
