@@ -136,6 +136,9 @@ int omni_kv4_prefill_write(void* qkv_f16, const void* seq_lens_i32, const void* 
                            int tokens_per_block, const void* rope_cos_sin_f32, int rope_max_pos,
                            int max_position_embeddings, void* stream);
 
+/* Tuning hook: force the number of KV splits of omni_kv4_decode_attention (0 = heuristic). */
+void omni_kv4_decode_set_split_override(int nsplit);
+
 /* Scratch bytes for omni_kv4_decode_attention (split-KV partials). */
 size_t omni_kv4_decode_workspace_bytes(int batch, int num_heads, int head_dim, int max_context);
 

@@ -35,6 +35,7 @@ PROTOTYPES = {
     "omni_silu_and_mul": (_i, [_vp, _vp, _i, _i, _vp]),
     "omni_compute_padding_offsets": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "omni_kv4_prefill_write": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _i, _i, _vp]),
+    "omni_kv4_decode_set_split_override": (None, [_i]),
     "omni_kv4_decode_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "omni_kv4_decode_attention": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp] + [_i] * 7 + [_vp, _i, _vp, _sz, _vp]),
 }

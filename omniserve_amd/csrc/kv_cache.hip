@@ -210,27 +210,54 @@ struct DecodeArgs {
 
 constexpr int DEC_THREADS = 256;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
+constexpr int DEC_UK = 8;  // 16-token groups whose K loads a wave issues back to back (pass 1)
+constexpr int DEC_U = 4;   // same for V (pass 2 carries the P.V accumulators, fewer spare VGPRs)
+
+// position of head-dim element d in the "dequant order" used for q in LDS: within every 8-dim
+// word the pairs (j, j+4) are adjacent, matching the half2 pairs kv4_dequant16 produces.
+__device__ __forceinline__ int perm_pos(int d) {
+  const int r = d & 7;
+  return (d & ~7) | ((r & 3) << 1) | (r >> 2);
+}
+
+// reduce-scatter step over the lane bit selected by `mask`: v[0..N) -> v[0..N/2)
+template <int N>
+__device__ __forceinline__ void rs_step(float* v, int mask, int lane) {
+  const bool up = (lane & mask) != 0;
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) {
+    const float lo = v[i], hi = v[i + N / 2];
+    const float keep = up ? hi : lo;
+    const float send = up ? lo : hi;
+    v[i] = keep + __shfl_xor(send, mask, 64);
+  }
+}
 
 // G = q heads served per workgroup (<= 4); grid = (S, Hkv * nsub, B), nsub = (Hq/Hkv)/G.
-template <int G>
-__global__ __launch_bounds__(DEC_THREADS) void kv4_decode_partial_kernel(DecodeArgs p) {
+// DIRECT: S == 1, the normalised fp16 output is written straight to `out` (no merge kernel).
+template <int G, bool DIRECT>
+__global__ __launch_bounds__(DEC_THREADS) void kv4_decode_kernel(DecodeArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // LDS carve: q_lds [G][128] fp16 | kcur [128] fp16 | vcur [128] fp16 | red [64] f32 |
-  //            scores [G][split_tokens + 16] f32 | obuf [64][128] f32 (reduction scratch)
-  half_t* q_lds = reinterpret_cast<half_t*>(smem);
-  half_t* kcur = q_lds + G * DH;
-  half_t* vcur = kcur + DH;
-  float* red = reinterpret_cast<float*>(vcur + DH);
-  float* scores = red + 64;
+  constexpr int V = G * 32;       // P.V partial values per lane
+  constexpr int VPL = V / 16;     // values per lane after the in-wave reduce-scatter
+  // LDS carve (all offsets multiples of 16 B):
+  half_t* q_lds = reinterpret_cast<half_t*>(smem);            // [G][128] dequant order
+  half_t* kcur = q_lds + G * DH;                              // [128] natural order (post RoPE)
+  half_t* kcur_p = kcur + DH;                                 // [128] dequant order
+  half_t* vcur = kcur_p + DH;                                 // [128]
+  float* red = reinterpret_cast<float*>(vcur + DH);           // [64]
+  int64_t* pages = reinterpret_cast<int64_t*>(red + 64);      // [2][40] K / V page pointers of the split
+  float* xbuf = reinterpret_cast<float*>(pages + 80);         // [4][64][VPL]
+  float* scores = xbuf + DEC_WAVES * 64 * VPL;                // [G][sstride]
   const int sstride = p.split_tokens + 16;
-  float* obuf = scores + G * sstride;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int split = blockIdx.x;
-  const int qg = (p.num_heads / p.num_kv_heads) / G;   // sub-blocks of q heads per kv head
+  const int group = p.num_heads / p.num_kv_heads;
+  const int qg = group / G;
   const int hk = blockIdx.y / qg;
   const int sub = blockIdx.y % qg;
-  const int hq0 = hk * (p.num_heads / p.num_kv_heads) + sub * G;
+  const int hq0 = hk * group + sub * G;
   const int b = blockIdx.z;
   const int tlen = p.lengths[b] - 1;  // history length = RoPE position = append slot
   const KvLayout lay = p.lay;
@@ -238,17 +265,23 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_partial_kernel(DecodeA
   const int64_t* vtab = ktab + p.max_blocks;
   const float inv_sqrt_dh = 0.08838834764831845f;  // 1/sqrt(128)
 
-  // split token range [t0, t1)
+  // split token range [t0, t1): multiples of 16, so a 16-token group never straddles a page
   int per = (tlen + p.nsplit - 1) / p.nsplit;
   per = (per + 15) & ~15;
-  if (per > p.split_tokens) per = p.split_tokens;  // host guarantees nsplit*split_tokens >= max ctx
+  if (per > p.split_tokens) per = p.split_tokens;
   const int t0 = min(tlen, split * per);
   const int t1 = (split == p.nsplit - 1) ? min(tlen, t0 + p.split_tokens) : min(tlen, t0 + per);
   const int nt = t1 - t0;
-  // the split that also owns the current (un-quantised) token: the last one
-  const bool owns_cur = split == p.nsplit - 1;
+  const bool owns_cur = split == p.nsplit - 1;  // this split also takes the current token
+  const int page0 = t0 >> lay.tpb_log2;
 
-  // ---- RoPE q (and k of the current token) into LDS ------------------------------------------
+  // ---- stage: page pointers, RoPE(q) (and k of the current token) ------------------------------
+  if (tid < 80) {
+    const int pi = tid < 40 ? tid : tid - 40;
+    const int64_t* tab = tid < 40 ? ktab : vtab;
+    const int pg = page0 + pi;
+    pages[tid] = (pg < p.max_blocks && (pg << lay.tpb_log2) <= tlen) ? tab[pg] : 0;
+  }
   {
     const int rp = tlen < p.rope_max_pos ? tlen : p.rope_max_pos - 1;
     const float* cs = p.rope + (size_t)rp * DH;  // [64][2]
@@ -257,95 +290,110 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_partial_kernel(DecodeA
       if (h == G && !owns_cur) continue;
       const half_t* src = h < G ? p.q + (size_t)b * p.q_stride + (size_t)(hq0 + h) * DH
                                 : p.k + (size_t)b * p.kv_stride + (size_t)hk * DH;
-      half_t* dst = h < G ? q_lds + h * DH : kcur;
       const float c = cs[2 * i], s = cs[2 * i + 1];
       const float a = (float)src[i], bb = (float)src[i + 64];
       const float t0f = c * a, t1f = s * bb, t2f = c * bb, t3f = s * a;
-      dst[i] = (half_t)(t0f - t1f);
-      dst[i + 64] = (half_t)(t2f + t3f);
+      const half_t r0 = (half_t)(t0f - t1f), r1 = (half_t)(t2f + t3f);
+      if (h < G) {
+        q_lds[h * DH + perm_pos(i)] = r0;
+        q_lds[h * DH + perm_pos(i + 64)] = r1;
+      } else {
+        kcur[i] = r0; kcur[i + 64] = r1;
+        kcur_p[perm_pos(i)] = r0; kcur_p[perm_pos(i + 64)] = r1;
+      }
     }
     if (owns_cur && tid < DH) vcur[tid] = p.v[(size_t)b * p.kv_stride + (size_t)hk * DH + tid];
   }
   __syncthreads();
 
-  // ---- pass 1: scores = q.K / sqrt(Dh) ---------------------------------------------------------
-  const int part = lane & 3;    // 32-dim part of the row
+  const int part = lane & 3;    // 32-dim part of the row (16 packed bytes)
   const int tslot = lane >> 2;  // token within a 16-token group
+  const int ngroups = (nt + 15) >> 4;
+  const size_t head_off = (size_t)hk * lay.tpb * ROW_BYTES + part * 16;
+  const int tail_off = lay.bytes_per_seq + hk * lay.tpb * 2;      // scale tail of this head
+  const int zero_off = lay.num_kv_heads * lay.tpb * 2;             // scale -> zero distance
+
+  // ---- pass 1: scores = q.K / sqrt(Dh) -------------------------------------------------------------
   float mloc[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) mloc[g] = -1e30f;
   {
-    // q part in the dequant order: word w (8 dims), pair j -> dims (8w + j, 8w + j + 4)
     v2h qreg[G][16];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int w = 0; w < 4; ++w)
+      for (int w = 0; w < 4; ++w) {
+        const v8h t = *reinterpret_cast<const v8h*>(q_lds + g * DH + part * 32 + w * 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const half_t* qp = q_lds + g * DH + part * 32 + w * 8 + j;
-          qreg[g][w * 4 + j] = (v2h){qp[0], qp[4]};
-        }
-    for (int base = wave * 16; base < nt; base += DEC_WAVES * 16) {
-      const int ti = base + tslot;  // index inside the split
-      const int tok = t0 + ti;
-      const bool valid = ti < nt;
-      uint4 raw = make_uint4(0, 0, 0, 0);
-      half_t sc = (half_t)0.0f, ze = (half_t)0.0f;
-      if (valid) {
-        const uint8_t* pg = reinterpret_cast<const uint8_t*>(ktab[tok >> lay.tpb_log2]);
-        const int slot = tok & (lay.tpb - 1);
-        raw = *reinterpret_cast<const uint4*>(pg + ((size_t)hk * lay.tpb + slot) * ROW_BYTES + part * 16);
-        const half_t* tail = reinterpret_cast<const half_t*>(pg + lay.bytes_per_seq) + hk * lay.tpb + slot;
-        sc = tail[0];
-        ze = tail[lay.num_kv_heads * lay.tpb];
+        for (int j = 0; j < 4; ++j) qreg[g][w * 4 + j] = (v2h){t[2 * j], t[2 * j + 1]};
       }
-      const half_t ch = (half_t)(-(float)sc * (float)ze);
-      v2h kd[16];
-      kv4_dequant16(raw, (v2h){sc, sc}, (v2h){ch, ch}, kd);
+    for (int g0 = wave; g0 < ngroups; g0 += DEC_WAVES * DEC_UK) {
+      uint4 raw[DEC_UK];
+      half_t sc[DEC_UK], ze[DEC_UK];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float acc = 0.0f;
+      for (int u = 0; u < DEC_UK; ++u) {  // branch-free: out-of-range lanes re-read token t0
+        const int ti = (g0 + u * DEC_WAVES) * 16 + tslot;
+        const int tok = ti < nt ? t0 + ti : t0;
+        const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[(tok >> lay.tpb_log2) - page0]);
+        const int slot = tok & (lay.tpb - 1);
+        raw[u] = *reinterpret_cast<const uint4*>(pg + head_off + (size_t)slot * ROW_BYTES);
+        const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
+        sc[u] = tail[0];
+        ze[u] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
+      }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc = dot2_acc(kd[i], qreg[g][i], acc);
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        const float sv = valid ? acc * inv_sqrt_dh : -1e30f;
-        mloc[g] = __builtin_fmaxf(mloc[g], sv);
-        if (part == 0) scores[g * sstride + ti] = sv;   // ti < split_tokens + 16 always
+      for (int u = 0; u < DEC_UK; ++u) {
+        const int ti = (g0 + u * DEC_WAVES) * 16 + tslot;
+        const bool valid = ti < nt;
+        const half_t ch = (half_t)(-(float)sc[u] * (float)ze[u]);
+        v2h kd[16];
+        kv4_dequant16(raw[u], (v2h){sc[u], sc[u]}, (v2h){ch, ch}, kd);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc = dot2_acc(kd[i], qreg[g][i], acc);
+          acc += __shfl_xor(acc, 1, 64);
+          acc += __shfl_xor(acc, 2, 64);
+          const float sv = valid ? acc * inv_sqrt_dh : -1e30f;
+          mloc[g] = __builtin_fmaxf(mloc[g], sv);
+          if (part == 0 && ti < ngroups * 16) scores[g * sstride + ti] = sv;
+        }
       }
     }
   }
-  // current token: q . k_cur with fp32 accumulation of the fp16 operands
+  // current token: q . k_cur (both in dequant order), fp32 accumulation of the fp16 operands
   float scur[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) scur[g] = 0.0f;
   if (owns_cur) {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      float a = (float)q_lds[g * DH + lane] * (float)kcur[lane] +
-                (float)q_lds[g * DH + 64 + lane] * (float)kcur[64 + lane];
+      float a = (float)q_lds[g * DH + lane] * (float)kcur_p[lane] +
+                (float)q_lds[g * DH + 64 + lane] * (float)kcur_p[64 + lane];
       a = wave_sum64(a);
       scur[g] = a * inv_sqrt_dh;
       mloc[g] = __builtin_fmaxf(mloc[g], scur[g]);
     }
   }
-  // block max per head
+  // block max per head (also orders the score writes before the reads below)
   float mblk[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const float wm = wave_max64(mloc[g]);
-    __syncthreads();
-    if (lane == 0) red[wave] = wm;
-    __syncthreads();
-    float m = red[0];
+    if (lane == 0) red[g * DEC_WAVES + wave] = wm;
+  }
+  __syncthreads();
 #pragma unroll
-    for (int w = 1; w < DEC_WAVES; ++w) m = __builtin_fmaxf(m, red[w]);
+  for (int g = 0; g < G; ++g) {
+    float m = red[g * DEC_WAVES];
+#pragma unroll
+    for (int w = 1; w < DEC_WAVES; ++w) m = __builtin_fmaxf(m, red[g * DEC_WAVES + w]);
     mblk[g] = m;
   }
-  // p = exp(s - m) in place, block sum
-  float lblk[G];
-  const int ntp = (nt + 15) & ~15;
+  // p = exp(s - m) in place + block sum
+  float lloc[G];
+  const int ntp = ngroups * 16;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     float ls = 0.0f;
@@ -354,81 +402,82 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_partial_kernel(DecodeA
       scores[g * sstride + i] = e;
       ls += e;
     }
-    const float ws = wave_sum64(ls);
-    __syncthreads();
-    if (lane == 0) red[wave] = ws;
-    __syncthreads();
-    float l = red[0];
-#pragma unroll
-    for (int w = 1; w < DEC_WAVES; ++w) l += red[w];
-    lblk[g] = l;
+    lloc[g] = wave_sum64(ls);
   }
-  float pcur[G];
+  __syncthreads();  // all reads of red[] (max) done, all p written
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+    if (lane == 0) red[g * DEC_WAVES + wave] = lloc[g];
+  __syncthreads();
+  float lblk[G], pcur[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
+    float l = red[g * DEC_WAVES];
+#pragma unroll
+    for (int w = 1; w < DEC_WAVES; ++w) l += red[g * DEC_WAVES + w];
     pcur[g] = owns_cur ? __expf(scur[g] - mblk[g]) : 0.0f;
-    lblk[g] += pcur[g];
+    lblk[g] = l + pcur[g];
   }
 
   // ---- pass 2: O = sum_t p_t * V_t -----------------------------------------------------------------
-  float o[G][32];
+  float o[V];   // index g*32 + 2*i + h  <->  head g, half2 pair i = w*4+j, element h
 #pragma unroll
-  for (int g = 0; g < G; ++g)
+  for (int i = 0; i < V; ++i) o[i] = 0.0f;
+  for (int g0 = wave; g0 < ngroups; g0 += DEC_WAVES * DEC_U) {
+    uint4 raw[DEC_U];
+    half_t sc[DEC_U], ze[DEC_U];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) o[g][i] = 0.0f;
-  for (int base = wave * 16; base < nt; base += DEC_WAVES * 16) {
-    const int ti = base + tslot;
-    const int tok = t0 + ti;
-    const bool valid = ti < nt;
-    uint4 raw = make_uint4(0, 0, 0, 0);
-    half_t sc = (half_t)0.0f, ze = (half_t)0.0f;
-    if (valid) {
-      const uint8_t* pg = reinterpret_cast<const uint8_t*>(vtab[tok >> lay.tpb_log2]);
+    for (int u = 0; u < DEC_U; ++u) {
+      const int ti = (g0 + u * DEC_WAVES) * 16 + tslot;
+      const int tok = ti < nt ? t0 + ti : t0;
+      const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[40 + (tok >> lay.tpb_log2) - page0]);
       const int slot = tok & (lay.tpb - 1);
-      raw = *reinterpret_cast<const uint4*>(pg + ((size_t)hk * lay.tpb + slot) * ROW_BYTES + part * 16);
-      const half_t* tail = reinterpret_cast<const half_t*>(pg + lay.bytes_per_seq) + hk * lay.tpb + slot;
-      sc = tail[0];
-      ze = tail[lay.num_kv_heads * lay.tpb];
+      raw[u] = *reinterpret_cast<const uint4*>(pg + head_off + (size_t)slot * ROW_BYTES);
+      const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
+      sc[u] = tail[0];
+      ze[u] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
     }
-    const half_t ch = (half_t)(-(float)sc * (float)ze);
-    v2h vd[16];
-    kv4_dequant16(raw, (v2h){sc, sc}, (v2h){ch, ch}, vd);
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float pv = scores[g * sstride + ti];  // 0 for masked tokens
+    for (int u = 0; u < DEC_U; ++u) {
+      const int ti = (g0 + u * DEC_WAVES) * 16 + tslot;
+      const bool valid = ti < nt;
+      const half_t ch = (half_t)(-(float)sc[u] * (float)ze[u]);
+      v2h vd[16];
+      kv4_dequant16(raw[u], (v2h){sc[u], sc[u]}, (v2h){ch, ch}, vd);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        // vd[w*4+j] = dims (8w+j, 8w+j+4)
-        o[g][2 * i] += pv * (float)vd[i][0];
-        o[g][2 * i + 1] += pv * (float)vd[i][1];
+      for (int g = 0; g < G; ++g) {
+        const float pv = valid ? scores[g * sstride + ti] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          o[g * 32 + 2 * i] += pv * (float)vd[i][0];
+          o[g * 32 + 2 * i + 1] += pv * (float)vd[i][1];
+        }
       }
     }
   }
 
-  // ---- reduce O over the 64 (wave, token-slot) partials via LDS, one head at a time --------------
-  // obuf[(wave*16 + tslot)][128] with this lane's dims: word w, pair j -> dims part*32 + 8w + j (+4)
-  for (int g = 0; g < G; ++g) {
-    __syncthreads();
-    float* dst = obuf + (size_t)(wave * 16 + tslot) * DH + part * 32;
+  // ---- reduce O: in-wave reduce-scatter over the 16 token slots, then across the 4 waves via LDS ----
+  rs_step<V>(o, 32, lane);
+  rs_step<V / 2>(o, 16, lane);
+  rs_step<V / 4>(o, 8, lane);
+  rs_step<V / 8>(o, 4, lane);
+  // lane (tslot, part) now owns flattened indices tslot*VPL + r, r < VPL
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        dst[w * 8 + j] = o[g][2 * (w * 4 + j)];
-        dst[w * 8 + j + 4] = o[g][2 * (w * 4 + j) + 1];
-      }
-    __syncthreads();
-    // 256 threads: dim d = tid & 127, half = tid >> 7 sums 32 partial rows each
-    const int d = tid & 127, hf = tid >> 7;
+  for (int r = 0; r < VPL; ++r) xbuf[(wave * 64 + lane) * VPL + r] = o[r];
+  __syncthreads();
+  for (int oi = tid; oi < G * DH; oi += DEC_THREADS) {
+    const int g = oi >> 7, d = oi & 127;
+    const int prt = d >> 5, dl = d & 31;
+    const int e = 2 * ((dl >> 3) * 4 + (dl & 3)) + ((dl >> 2) & 1);
+    const int fidx = g * 32 + e;
+    const int ln = (fidx / VPL) * 4 + prt, r = fidx % VPL;
     float acc = 0.0f;
-#pragma unroll 8
-    for (int r = 0; r < 32; ++r) acc += obuf[(size_t)(hf * 32 + r) * DH + d];
-    __syncthreads();
-    if (hf == 1) obuf[d] = acc;
-    __syncthreads();
-    if (hf == 0) {
-      acc += obuf[d];
-      if (owns_cur) acc += pcur[g] * (float)vcur[d];
+#pragma unroll
+    for (int w = 0; w < DEC_WAVES; ++w) acc += xbuf[(w * 64 + ln) * VPL + r];
+    if (owns_cur) acc += pcur[g] * (float)vcur[d];
+    if constexpr (DIRECT) {
+      p.out[((size_t)b * p.num_heads + hq0 + g) * DH + d] = (half_t)(acc * (1.0f / (lblk[g] + 1e-6f)));
+    } else {
       const size_t pi = ((size_t)b * p.num_heads + hq0 + g) * p.nsplit + split;
       p.part_o[pi * DH + d] = acc;
       if (d == 0) {
@@ -491,24 +540,31 @@ struct DecodePlan {
   size_t lds_bytes;
 };
 
+static int g_override_nsplit = 0;
+
 static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int max_context) {
   DecodePlan pl;
   const int group = num_heads / num_kv_heads;
   pl.g = group >= 4 ? 4 : group;  // group in {1,2,4,8,...}
   const int wgs_per_split = batch * num_kv_heads * (group / pl.g);
-  int s = (768 + wgs_per_split - 1) / wgs_per_split;  // ~3 workgroups per CU
+  // the kernel runs one 256-thread workgroup per CU (it spends the register file on the P.V
+  // accumulators): split the KV range until there is ~1 workgroup per CU; a single split skips
+  // the merge kernel
+  int s = wgs_per_split >= 256 ? 1 : (256 + wgs_per_split - 1) / wgs_per_split;
+  if (g_override_nsplit > 0) s = g_override_nsplit;
   const int max_s = (max_context + 63) / 64;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
   int st = ((max_context + s - 1) / s + 15) & ~15;
-  while (st > 1536) {  // LDS bound on the score buffer (<= 64 KiB dynamic LDS)
+  while (st > 2048 && s < 64) {  // LDS bound on the score buffer
     ++s;
     st = ((max_context + s - 1) / s + 15) & ~15;
   }
   pl.nsplit = s;
   pl.split_tokens = st;
-  pl.lds_bytes = (size_t)(pl.g + 2) * DH * 2 + 64 * 4 + (size_t)pl.g * (st + 16) * 4 + 64 * DH * 4;
+  pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * 64 * (pl.g * 2) * 4 +
+                 (size_t)pl.g * (st + 16) * 4;
   return pl;
 }
 
@@ -548,6 +604,8 @@ extern "C" int omni_kv4_prefill_write(void* qkv_f16, const void* seq_lens_i32,
   return omni_launch_status();
 }
 
+extern "C" void omni_kv4_decode_set_split_override(int nsplit) { omni::g_override_nsplit = nsplit; }
+
 extern "C" size_t omni_kv4_decode_workspace_bytes(int batch, int num_heads, int head_dim, int max_context) {
   (void)head_dim;
   if (batch < 1 || num_heads < 1) return 0;
@@ -586,12 +644,29 @@ extern "C" int omni_kv4_decode_attention(void* out_f16, const void* q_f16, const
   a.part_o = a.part_ml + (size_t)batch * num_heads * pl.nsplit * 2;
   dim3 grid(pl.nsplit, num_kv_heads * (group / pl.g), batch);
   hipStream_t st = (hipStream_t)stream;
-  switch (pl.g) {
-    case 1: hipLaunchKernelGGL((kv4_decode_partial_kernel<1>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); break;
-    case 2: hipLaunchKernelGGL((kv4_decode_partial_kernel<2>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); break;
-    default: hipLaunchKernelGGL((kv4_decode_partial_kernel<4>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); break;
+  if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;  // context beyond 64 splits x 2048 tokens
+#define OMNI_LAUNCH_DEC(G_, D_)                                                                       \
+  do {                                                                                                \
+    if (pl.lds_bytes > 64 * 1024)                                                                     \
+      (void)hipFuncSetAttribute((const void*)kv4_decode_kernel<G_, D_>,                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);      \
+    hipLaunchKernelGGL((kv4_decode_kernel<G_, D_>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a);    \
+  } while (0)
+  if (pl.nsplit == 1) {
+    switch (pl.g) {
+      case 1: OMNI_LAUNCH_DEC(1, true); break;
+      case 2: OMNI_LAUNCH_DEC(2, true); break;
+      default: OMNI_LAUNCH_DEC(4, true); break;
+    }
+  } else {
+    switch (pl.g) {
+      case 1: OMNI_LAUNCH_DEC(1, false); break;
+      case 2: OMNI_LAUNCH_DEC(2, false); break;
+      default: OMNI_LAUNCH_DEC(4, false); break;
+    }
+    hipLaunchKernelGGL(kv4_decode_merge_kernel, dim3(batch * num_heads), dim3(128), 0, st, (half_t*)out_f16,
+                       a.part_ml, a.part_o, pl.nsplit);
   }
-  hipLaunchKernelGGL(kv4_decode_merge_kernel, dim3(batch * num_heads), dim3(128), 0, st, (half_t*)out_f16,
-                     a.part_ml, a.part_o, pl.nsplit);
+#undef OMNI_LAUNCH_DEC
   return omni_launch_status();
 }

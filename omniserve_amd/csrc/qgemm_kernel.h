@@ -274,16 +274,241 @@ __global__ __launch_bounds__(64 * WAVES) void w4a8_gemm_kernel(GemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Decode-shape kernel (M <= 128): pure weight streaming.
+//   * the whole activation K-slice of the workgroup is staged into (dynamic) LDS ONCE, in the
+//     weights' k order -> a single barrier, none inside the stream loop;
+//   * each wave keeps a ring of RING k-steps (RING * 2 KiB) of packed weights in flight: the
+//     registers of step s are refilled for step s+RING right after they are unpacked, so the
+//     HBM latency is covered by RING-1 steps of MFMA work plus the other resident waves.
+// ------------------------------------------------------------------------------------------
+template <int MB, int MODE>
+struct GemvCfg {
+  static constexpr int WL = (MODE == MODE_W8) ? 4 : 2;
+  static constexpr int RING = (MODE == MODE_W8) ? (MB <= 2 ? 4 : 2) : (MB <= 2 ? 8 : 4);
+};
+
+template <int MB, int MODE, int WAVES, bool TO_SLAB>
+__global__ __launch_bounds__(64 * WAVES) void w4a8_gemv_kernel(GemmArgs p) {
+  constexpr int MT = MB * 16;
+  constexpr int NTHREADS = 64 * WAVES;
+  constexpr int WL = GemvCfg<MB, MODE>::WL;
+  constexpr int RING = GemvCfg<MB, MODE>::RING;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // [nsteps][MT][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int ng = blockIdx.x * WAVES + wave;
+  const bool wave_active = (ng * 64) < p.N;
+  const int k_begin = blockIdx.y * p.kslice;
+  const int k_end = min(p.K, k_begin + p.kslice);
+  const int nsteps = (k_end - k_begin) / KSTEP;
+
+  const int lx = (lane >> 3) & 1, lc = lane & 7, le = lane >> 4;
+  const uint8_t* wbase;
+  if constexpr (MODE == MODE_W8) wbase = p.W + (size_t)(ng * 64 + (lane & 15)) * p.K + (lane >> 4) * 16;
+  else wbase = p.W + ((size_t)(2 * ng + lx) * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
+  auto load_w = [&](int k, int j) -> uint4 {
+    const uint8_t* ptr;
+    if constexpr (MODE == MODE_W8) ptr = wbase + (size_t)j * 16 * p.K + k;
+    else ptr = wbase + (size_t)(k / 32 + j) * 512;
+    const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(ptr));
+    return make_uint4((uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
+  };
+  const size_t gcol = (size_t)(2 * ng + lx) * 32 + lc * 4;  // per-group param column of this lane
+  auto load_gp = [&](const uint8_t* base, int k) -> uint32_t {
+    return *reinterpret_cast<const uint32_t*>(base + (size_t)(k / 128) * p.N + gcol);
+  };
+
+  // ---- 1. put the first RING steps of weights in flight --------------------------------------
+  // The stream is organised in `rounds` of RING steps with NO control flow inside a round, so
+  // the compiler can emit counted s_waitcnt vmcnt(N) (any branch around a load degrades every
+  // wait to vmcnt(0) and serialises the ring).  nsteps % RING leftovers run in a simple tail loop.
+  const int rounds = nsteps / RING;
+  uint4 wq[RING][WL];
+  uint32_t gs[RING], gz[RING];  // per-group second-level params of the step's 128-k group
+  if (wave_active && rounds > 0) {
+#pragma unroll
+    for (int s = 0; s < RING; ++s) {
+#pragma unroll
+      for (int j = 0; j < WL; ++j) wq[s][j] = load_w(k_begin + s * KSTEP, j);
+      if constexpr (MODE == MODE_GRP) {
+        gs[s] = load_gp(p.s2s, k_begin + s * KSTEP);
+        gz[s] = load_gp(p.s2z, k_begin + s * KSTEP);
+      }
+    }
+  }
+
+  // ---- 2. stage the activation slice (M x kslice int8) into LDS in the weights' k order -------
+  {
+    const int ppr = nsteps * 4;            // 16-byte pieces per row
+    const int pieces = MT * ppr;
+    constexpr int BATCH = 8;
+    for (int id0 = tid; id0 < pieces; id0 += NTHREADS * BATCH) {
+      uint4 a[BATCH];
+#pragma unroll
+      for (int b = 0; b < BATCH; ++b) {
+        const int id = id0 + b * NTHREADS;
+        const int m = id / ppr, kk = id - m * ppr;
+        a[b] = make_uint4(0, 0, 0, 0);
+        if (id < pieces && m < p.M)
+          a[b] = *reinterpret_cast<const uint4*>(p.A + (size_t)m * p.K + k_begin + kk * 16);
+      }
+#pragma unroll
+      for (int b = 0; b < BATCH; ++b) {
+        const int id = id0 + b * NTHREADS;
+        if (id >= pieces) continue;
+        const int m = id / ppr, kk = id - m * ppr;
+        if constexpr (MODE == MODE_W8) {
+          *reinterpret_cast<uint4*>(&lds[((kk >> 2) * MT + m) * 64 + (kk & 3) * 16]) = a[b];
+        } else {
+          const int kp = kk >> 2, tp = (kk >> 1) & 1, d = kk & 1;
+          uint8_t* dst = &lds[(kp * MT + m) * 64 + tp * 8 + d * 4];
+          *reinterpret_cast<uint32_t*>(dst + 0) = a[b].x;
+          *reinterpret_cast<uint32_t*>(dst + 16) = a[b].y;
+          *reinterpret_cast<uint32_t*>(dst + 32) = a[b].z;
+          *reinterpret_cast<uint32_t*>(dst + 48) = a[b].w;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (!wave_active) return;
+
+  v4i acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) acc[mb][ab] = (v4i){0, 0, 0, 0};
+
+  // ---- 3. stream -------------------------------------------------------------------------------
+  auto unpack = [&](const uint4 (&w)[WL], uint32_t sc4, uint32_t zr4, v4i (&wa)[4]) {
+    if constexpr (MODE == MODE_W8) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) wa[rb] = (v4i){(int)w[rb].x, (int)w[rb].y, (int)w[rb].z, (int)w[rb].w};
+    } else {
+      const uint4 t0 = w[0], t1 = w[1];
+      const uint32_t d[2][4] = {{t0.x, t0.z, t1.x, t1.z}, {t0.y, t0.w, t1.y, t1.w}};
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          uint32_t u[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) u[q] = (d[b][q] >> (4 * a)) & 0x0F0F0F0Fu;
+          if constexpr (MODE == MODE_GRP) {
+            const uint32_t sc = (sc4 >> (8 * (a * 2 + b))) & 0xFFu;
+            const uint32_t zr = ((zr4 >> (8 * (a * 2 + b))) & 0xFFu) * 0x01010101u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u[q] = vadd4(u[q] * sc, zr);
+          }
+          wa[a * 2 + b] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
+        }
+    }
+  };
+  auto mma_step = [&](const v4i (&wa)[4], int st) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const v4i bf = *reinterpret_cast<const v4i*>(
+          lds + ((st * MT + mb * 16 + (lane & 15)) * 4 + (lane >> 4)) * 16);
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab)
+        acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf, acc[mb][ab], 0, 0, 0);
+    }
+  };
+  for (int r = 0; r + 1 < rounds; ++r) {  // steady state: consume step s, refill it for round r+1
+#pragma unroll
+    for (int s = 0; s < RING; ++s) {
+      v4i wa[4];
+      unpack(wq[s], gs[s], gz[s], wa);
+      const int kn = k_begin + ((r + 1) * RING + s) * KSTEP;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) wq[s][j] = load_w(kn, j);
+      if constexpr (MODE == MODE_GRP) {
+        gs[s] = load_gp(p.s2s, kn);
+        gz[s] = load_gp(p.s2z, kn);
+      }
+      mma_step(wa, r * RING + s);
+    }
+  }
+  if (rounds > 0) {  // last round: drain
+#pragma unroll
+    for (int s = 0; s < RING; ++s) {
+      v4i wa[4];
+      unpack(wq[s], gs[s], gz[s], wa);
+      mma_step(wa, (rounds - 1) * RING + s);
+    }
+  }
+  for (int st = rounds * RING; st < nsteps; ++st) {  // leftovers (nsteps % RING), unpipelined
+    uint4 w[WL];
+    const int kn = k_begin + st * KSTEP;
+#pragma unroll
+    for (int j = 0; j < WL; ++j) w[j] = load_w(kn, j);
+    uint32_t sc4 = 0, zr4 = 0;
+    if constexpr (MODE == MODE_GRP) { sc4 = load_gp(p.s2s, kn); zr4 = load_gp(p.s2z, kn); }
+    v4i wa[4];
+    unpack(w, sc4, zr4, wa);
+    mma_step(wa, st);
+  }
+
+  // ---- 4. write back (same mapping as w4a8_gemm_kernel) ------------------------------------------
+  const int mcol = lane & 15;
+  const int i0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = mb * 16 + mcol;
+    if (m >= p.M) continue;
+    float sa = 0.f, as = 0.f;
+    if constexpr (!TO_SLAB) {
+      sa = (float)p.ascales[m];
+      if constexpr (MODE == MODE_CHN) as = (float)p.asum[m];
+    }
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+      int n;
+      if constexpr (MODE == MODE_W8) n = ng * 64 + ab * 16 + i0;
+      else n = ng * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
+      const v4i a4 = acc[mb][ab];
+      if constexpr (TO_SLAB) {
+        int32_t* dst = p.slab + ((size_t)blockIdx.y * p.M + m) * p.N + n;
+        *reinterpret_cast<v4i*>(dst) = a4;
+      } else {
+        half_t o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sw = (float)p.wscales[n + r];
+          float sz = 0.f;
+          if constexpr (MODE == MODE_CHN) sz = (float)p.wsz[n + r];
+          o[r] = epilogue<MODE>(a4[r], sw, sa, sz, as);
+        }
+        *reinterpret_cast<uint2*>(p.out + (size_t)m * p.out_stride + n) =
+            *reinterpret_cast<const uint2*>(o);
+      }
+    }
+  }
+}
+
 // Reduce SK int32 slabs and apply the epilogue.  One thread = 4 consecutive channels of one row.
 template <int MODE>
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p, int sk) {
+__global__ __launch_bounds__(64) void splitk_epilogue_kernel(GemmArgs p, int sk) {
   const int n4 = p.N / 4;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)p.M * n4) return;
   const int m = idx / n4, n = (idx % n4) * 4;
-  v4i s = (v4i){0, 0, 0, 0};
-  for (int k = 0; k < sk; ++k)
-    s += *reinterpret_cast<const v4i*>(p.slab + ((size_t)k * p.M + m) * p.N + n);
+  const int32_t* src = p.slab + (size_t)m * p.N + n;
+  const size_t sstride = (size_t)p.M * p.N;
+  v4i s0 = (v4i){0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+  int k = 0;
+  for (; k + 4 <= sk; k += 4) {  // four independent 16-B loads in flight
+    const v4i a0 = *reinterpret_cast<const v4i*>(src + (size_t)(k + 0) * sstride);
+    const v4i a1 = *reinterpret_cast<const v4i*>(src + (size_t)(k + 1) * sstride);
+    const v4i a2 = *reinterpret_cast<const v4i*>(src + (size_t)(k + 2) * sstride);
+    const v4i a3 = *reinterpret_cast<const v4i*>(src + (size_t)(k + 3) * sstride);
+    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+  }
+  for (; k < sk; ++k) s0 += *reinterpret_cast<const v4i*>(src + (size_t)k * sstride);
+  const v4i s = (s0 + s1) + (s2 + s3);
   const float sa = (float)p.ascales[m];
   float as = 0.f;
   if constexpr (MODE == MODE_CHN) as = (float)p.asum[m];
@@ -312,16 +537,31 @@ extern "C" void omni_gemm_get_plan(int M, int N, int K, int kalign, int* mb, int
 GemmPlan plan_gemm(int M, int N, int K, int kalign);
 
 template <int MODE, int MB, int WAVES>
-static void launch_variant(const GemmArgs& a, const GemmPlan& pl, bool nt, hipStream_t st) {
-  dim3 grid((a.N / 64 + WAVES - 1) / WAVES, pl.sk, (a.M + MB * 16 - 1) / (MB * 16));
-  dim3 block(64 * WAVES);
+static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
+  // prefill regime: chunked LDS staging, weights through L2
+  dim3 grid((a.N / 64 + WAVES - 1) / WAVES, 1, (a.M + MB * 16 - 1) / (MB * 16));
+  hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, false>), grid, dim3(64 * WAVES), 0, st, a);
+}
+
+template <int MODE, int MB, int WAVES>
+static void launch_gemv(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
+  dim3 grid((a.N / 64 + WAVES - 1) / WAVES, pl.sk, 1);
+  const size_t lds = (size_t)MB * 16 * pl.kslice;
   if (pl.sk > 1) {
-    hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, true, true>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, WAVES, true>), grid, dim3(64 * WAVES), lds, st, a);
     const size_t total = (size_t)a.M * (a.N / 4);
-    hipLaunchKernelGGL((splitk_epilogue_kernel<MODE>), dim3((total + 255) / 256), dim3(256), 0, st, a, pl.sk);
+    hipLaunchKernelGGL((splitk_epilogue_kernel<MODE>), dim3((total + 63) / 64), dim3(64), 0, st, a, pl.sk);
   } else {
-    if (nt) hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, false>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, WAVES, false>), grid, dim3(64 * WAVES), lds, st, a);
+  }
+}
+
+template <int MODE, int MB>
+static void launch_gemv_waves(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
+  switch (pl.waves) {
+    case 1: launch_gemv<MODE, MB, 1>(a, pl, st); break;
+    case 2: launch_gemv<MODE, MB, 2>(a, pl, st); break;
+    default: launch_gemv<MODE, MB, 4>(a, pl, st); break;
   }
 }
 
@@ -336,16 +576,14 @@ static int launch_gemm(GemmArgs a, void* ws, size_t ws_bytes, hipStream_t st) {
     a.slab = static_cast<int32_t*>(ws);
   }
   a.kslice = pl.kslice;
-  const bool nt = a.M <= 128;  // weights are read once: stream them past the caches
-  if (pl.waves == 1 && MODE != MODE_W8 && pl.mb <= 2) {
-    if (pl.mb == 1) launch_variant<MODE, 1, 1>(a, pl, nt, st);
-    else launch_variant<MODE, 2, 1>(a, pl, nt, st);
+  if (a.M > 128) {
+    launch_variant<MODE, 8, 4>(a, pl, st);
   } else {
     switch (pl.mb) {
-      case 1: launch_variant<MODE, 1, 4>(a, pl, nt, st); break;
-      case 2: launch_variant<MODE, 2, 4>(a, pl, nt, st); break;
-      case 4: launch_variant<MODE, 4, 4>(a, pl, nt, st); break;
-      default: launch_variant<MODE, 8, 4>(a, pl, nt, st); break;
+      case 1: launch_gemv_waves<MODE, 1>(a, pl, st); break;
+      case 2: launch_gemv_waves<MODE, 2>(a, pl, st); break;
+      case 4: launch_gemv_waves<MODE, 4>(a, pl, st); break;
+      default: launch_gemv_waves<MODE, 8>(a, pl, st); break;
     }
   }
   return omni_launch_status();

@@ -12,16 +12,23 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign) {
     pl.mb = 8; pl.waves = 4; pl.sk = 1; pl.kslice = K;
     return pl;
   }
-  // bandwidth-bound regime (decode): every CU must stream weights.
+  // bandwidth-bound regime (decode): every CU must stream weights.  One wave owns 64 channels
+  // and a K-slice; the slice of activations (MT x kslice bytes) must fit the 64 KiB dynamic LDS.
   pl.mb = M <= 16 ? 1 : (M <= 32 ? 2 : (M <= 64 ? 4 : 8));
-  pl.waves = 4;
+  const int mt = pl.mb * 16;
   const int ngroups = N / 64;
+  pl.waves = ngroups % 4 == 0 ? 4 : (ngroups % 2 == 0 ? 2 : 1);
+  auto ok = [&](int s) {
+    return s >= 1 && (K % s) == 0 && ((K / s) % kalign) == 0 && (K / s) >= 128 && mt * (K / s) <= 65536;
+  };
   int sk = 1;
-  const int target_waves = 1024;  // ~4 waves per CU, each with a 256-k chunk (8 KiB) in flight
-  auto ok = [&](int s) { return (K % s) == 0 && ((K / s) % kalign) == 0 && (K / s) >= KCHUNK; };
-  while (ngroups * sk < target_waves && ok(sk * 2)) sk *= 2;
+  while (!ok(sk) && sk < 64) sk *= 2;               // LDS bound first
+  const int target_waves = 768;                       // ~3 waves per CU, each with 16 KiB in flight
+  while (ngroups * sk < target_waves && ok(sk * 2) && (K / (sk * 2)) >= 512) sk *= 2;
   if (g_override_sk > 0 && ok(g_override_sk)) sk = g_override_sk;
-  if (g_override_waves == 1 && pl.mb <= 2) pl.waves = 1;
+  if (g_override_waves > 0 && g_override_waves <= 4 && ngroups % g_override_waves == 0 &&
+      g_override_waves != 3)
+    pl.waves = g_override_waves;
   pl.sk = sk;
   pl.kslice = K / sk;
   return pl;

@@ -76,7 +76,7 @@ def test_silu_and_mul(tokens, d):
     act.silu_and_mul(out, to_dev(x))
     torch.cuda.synchronize()
     want = oe.silu_and_mul(x)
-    # expf on the device vs numpy differ by <= 1 ulp in f32; after the two fp16 roundings the
-    # result may differ by one fp16 ulp in rare cases
-    assert f16_ulp_diff(out, want) <= 1
+    # expf on the device vs numpy's differ by an ulp in f32; each of the two fp16 roundings
+    # (silu -> fp16, product -> fp16) can then flip by one ulp: <= 2 fp16 ulp, and rarely
+    assert f16_ulp_diff(out, want) <= 2
     assert (np.asarray(out.cpu().numpy()).view(np.uint16) != want.view(np.uint16)).mean() < 1e-3
