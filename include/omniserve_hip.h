@@ -108,6 +108,21 @@ int omni_rms_norm_general_fuse_sum(void* out_i8, const void* in_f16, const void*
  *   (kernels/csrc/activation_kernels.cu:10-30,84-97): in fp16 [tokens, 2d] -> out [tokens, d]. */
 int omni_silu_and_mul(void* out_f16, const void* in_f16, int tokens, int d, void* stream);
 
+/* ---- Fused extensions (opt-in, NOT part of the reference API) --------------
+ * Bit-identical to the two reference calls they replace; they exist because at MI355X speeds a
+ * decode step is bound by the number of dependent kernels, not by bytes. */
+
+/* residual += delta (fp16 add, as the torch `x + proj` between the reference's calls,
+ * llama_w4a8_unpad.py:425,437), then omni_rms_norm_general_fuse_sum on the updated residual. */
+int omni_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const void* delta_f16,
+                                       const void* weight_f16, void* sum_f16, void* scale_f16,
+                                       float eps, int tokens, int hidden, void* stream);
+
+/* omni_silu_and_mul followed by omni_quant_fuse_sum without materialising the fp16 product
+ * (activation.py:54-64 calls them back to back).  in fp16 [tokens, 2d] -> out int8 [tokens, d]. */
+int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f16, void* scale_f16,
+                                 int tokens, int d, void* stream);
+
 /* ----------------------------------------------------------------------------------------------
  * KV4 paged cache (page = int4 data [H_kv][tpb][Dh/2] | fp16 scale [H_kv][tpb] | fp16 zero [H_kv][tpb],
  *   omniserve/worker/cache_engine.py:73-88, kernels/csrc/fused_attention/common/kvCacheUtils.h:53-164)

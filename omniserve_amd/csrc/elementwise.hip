@@ -20,27 +20,39 @@ constexpr int VPT = 16;  // elements per thread held in registers: hidden <= 163
 // ------------------------------------------------------------------------------------------
 // invoke_quant / invoke_quant_fuse_sum   (fused_kernels.cu:57-142)
 // ------------------------------------------------------------------------------------------
-template <bool FUSE_SUM>
-__global__ __launch_bounds__(NT_MAX) void quant_kernel(int8_t* __restrict__ out,
-                                                        const half_t* __restrict__ in,
-                                                        half_t* __restrict__ sum_out,
-                                                        half_t* __restrict__ scale_out, int hidden) {
-  __shared__ float red[32];
+__device__ __forceinline__ half_t silu_mul_h(half_t a, half_t b) {
+  const float xf = (float)a;
+  const half_t s = (half_t)(xf / (1.0f + expf(-xf)));
+  return (half_t)((float)s * (float)b);
+}
+
+struct PlainLoader {   // x[i] of a contiguous fp16 row
+  const half_t* row;
+  __device__ __forceinline__ float operator()(int i) const { return (float)row[i]; }
+};
+struct SiluMulLoader { // h(h(silu(gate[i])) * up[i]) of a [2d] row: the value silu_and_mul would store
+  const half_t* row;
+  int d;
+  __device__ __forceinline__ float operator()(int i) const { return (float)silu_mul_h(row[i], row[d + i]); }
+};
+
+template <bool FUSE_SUM, typename Loader>
+__device__ __forceinline__ void quant_row(int8_t* __restrict__ out_row, Loader ld, half_t* __restrict__ sum_out,
+                                          half_t* __restrict__ scale_out, int hidden, float* red) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  const size_t row = (size_t)blockIdx.x * hidden;
   float x[VPT];
   float amax = 0.0f, s = 0.0f;
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
     const int i = tid + j * nt;
     const bool ok = i < hidden;  // branch-free: keeps x[] in registers
-    const float v = (float)in[row + (ok ? i : 0)];
+    const float v = ld(ok ? i : 0);
     x[j] = ok ? v : 0.0f;
     if constexpr (FUSE_SUM) s = ok ? s + x[j] : s;
     amax = __builtin_fmaxf(amax, __builtin_fabsf(x[j]));
   }
-  for (int i = tid + VPT * nt; i < hidden; i += nt) {  // hidden > VPT*1024: re-read tail later
-    const float v = (float)in[row + i];
+  for (int i = tid + VPT * nt; i < hidden; i += nt) {  // hidden > VPT*1024: re-evaluated below
+    const float v = ld(i);
     if constexpr (FUSE_SUM) s = s + v;
     amax = __builtin_fmaxf(amax, __builtin_fabsf(v));
   }
@@ -54,19 +66,43 @@ __global__ __launch_bounds__(NT_MAX) void quant_kernel(int8_t* __restrict__ out,
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
     const int i = tid + j * nt;
-    if (i < hidden) out[row + i] = rni_sat_s8(x[j] * q);
+    if (i < hidden) out_row[i] = rni_sat_s8(x[j] * q);
   }
-  for (int i = tid + VPT * nt; i < hidden; i += nt) out[row + i] = rni_sat_s8((float)in[row + i] * q);
+  for (int i = tid + VPT * nt; i < hidden; i += nt) out_row[i] = rni_sat_s8(ld(i) * q);
+}
+
+template <bool FUSE_SUM>
+__global__ __launch_bounds__(NT_MAX) void quant_kernel(int8_t* __restrict__ out,
+                                                        const half_t* __restrict__ in,
+                                                        half_t* __restrict__ sum_out,
+                                                        half_t* __restrict__ scale_out, int hidden) {
+  __shared__ float red[32];
+  const size_t row = (size_t)blockIdx.x * hidden;
+  quant_row<FUSE_SUM>(out + row, PlainLoader{in + row}, sum_out, scale_out, hidden, red);
+}
+
+// Fused extension: silu_and_mul + invoke_quant_fuse_sum without the fp16
+// [tokens, d] round trip; bit-identical to running the two kernels back to back.
+__global__ __launch_bounds__(NT_MAX) void silu_mul_quant_kernel(int8_t* __restrict__ out,
+                                                                 const half_t* __restrict__ in,
+                                                                 half_t* __restrict__ sum_out,
+                                                                 half_t* __restrict__ scale_out, int d) {
+  __shared__ float red[32];
+  quant_row<true>(out + (size_t)blockIdx.x * d, SiluMulLoader{in + (size_t)blockIdx.x * 2 * d, d}, sum_out,
+                  scale_out, d, red);
 }
 
 // ------------------------------------------------------------------------------------------
 // rms_norm_general[_fuse_sum], per-token quant   (layernorm_kernels.cu:58-331)
 //   y = (x - mean) * rsqrt(mean(x^2) + eps) * gamma   [mean subtracted in the output only]
 // ------------------------------------------------------------------------------------------
-template <bool FUSE_SUM>
+// ADD: fused extension -- `in` is the residual stream, updated in place with
+// x = h(x + delta) (the torch fp16 add the reference does between the two calls) before the norm.
+template <bool FUSE_SUM, bool ADD>
 __global__ __launch_bounds__(NT_MAX) void general_norm_quant_kernel(
-    int8_t* __restrict__ out, const half_t* __restrict__ in, const half_t* __restrict__ gamma,
-    half_t* __restrict__ sum_out, half_t* __restrict__ scale_out, float eps, int hidden) {
+    int8_t* __restrict__ out, half_t* __restrict__ in, const half_t* __restrict__ delta,
+    const half_t* __restrict__ gamma, half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
+    float eps, int hidden) {
   __shared__ float red[32];
   const int tid = threadIdx.x, nt = blockDim.x;
   const size_t row = (size_t)blockIdx.x * hidden;
@@ -76,7 +112,12 @@ __global__ __launch_bounds__(NT_MAX) void general_norm_quant_kernel(
   for (int j = 0; j < VPT; ++j) {
     const int i = tid + j * nt;
     const bool ok = i < hidden;
-    const float v = (float)in[row + (ok ? i : 0)];
+    float v = (float)in[row + (ok ? i : 0)];
+    if constexpr (ADD) {
+      const half_t xs = (half_t)(v + (float)delta[row + (ok ? i : 0)]);
+      if (ok) in[row + i] = xs;
+      v = (float)xs;
+    }
     x[j] = ok ? v : 0.0f;
     lsum = ok ? lsum + x[j] : lsum;
     lsq = ok ? lsq + x[j] * x[j] : lsq;
@@ -235,8 +276,8 @@ extern "C" int omni_rms_norm_general(void* out_i8, const void* in_f16, const voi
   if (!out_i8 || !in_f16 || !weight_f16 || !scale_f16 || tokens < 0 || hidden < 1) return OMNI_EINVAL;
   if (hidden > VPT * NT_MAX) return OMNI_EINVAL;
   if (tokens == 0) return OMNI_OK;
-  hipLaunchKernelGGL((general_norm_quant_kernel<false>), dim3(tokens), dim3(norm_block(hidden, true)),
-                     0, (hipStream_t)stream, (int8_t*)out_i8, (const half_t*)in_f16,
+  hipLaunchKernelGGL((general_norm_quant_kernel<false, false>), dim3(tokens), dim3(norm_block(hidden, true)),
+                     0, (hipStream_t)stream, (int8_t*)out_i8, (half_t*)in_f16, (const half_t*)nullptr,
                      (const half_t*)weight_f16, (half_t*)nullptr, (half_t*)scale_f16, eps, hidden);
   return omni_launch_status();
 }
@@ -249,8 +290,8 @@ extern "C" int omni_rms_norm_general_fuse_sum(void* out_i8, const void* in_f16,
     return OMNI_EINVAL;
   if (hidden > VPT * NT_MAX) return OMNI_EINVAL;
   if (tokens == 0) return OMNI_OK;
-  hipLaunchKernelGGL((general_norm_quant_kernel<true>), dim3(tokens), dim3(norm_block(hidden, true)),
-                     0, (hipStream_t)stream, (int8_t*)out_i8, (const half_t*)in_f16,
+  hipLaunchKernelGGL((general_norm_quant_kernel<true, false>), dim3(tokens), dim3(norm_block(hidden, true)),
+                     0, (hipStream_t)stream, (int8_t*)out_i8, (half_t*)in_f16, (const half_t*)nullptr,
                      (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden);
   return omni_launch_status();
 }
@@ -270,5 +311,63 @@ extern "C" int omni_silu_and_mul(void* out_f16, const void* in_f16, int tokens, 
     hipLaunchKernelGGL(silu_and_mul_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        (hipStream_t)stream, (half_t*)out_f16, (const half_t*)in_f16, tokens, d);
   }
+  return omni_launch_status();
+}
+
+// ---- debug probe: the norm statistics exactly as general_norm_quant_kernel computes them ---------------
+__global__ __launch_bounds__(NT_MAX) void norm_stats_debug_kernel(const half_t* __restrict__ in, float* __restrict__ out,
+                                                                   float eps, int hidden) {
+  __shared__ float red[32];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const size_t row = (size_t)blockIdx.x * hidden;
+  float lsum = 0.0f, lsq = 0.0f;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int i = tid + j * nt;
+    const bool ok = i < hidden;
+    const float v = ok ? (float)in[row + (ok ? i : 0)] : 0.0f;
+    lsum = ok ? lsum + v : lsum;
+    lsq = ok ? lsq + v * v : lsq;
+  }
+  const float tot = ref_block_sum(lsum, red);
+  const float mean = tot / (float)hidden;
+  const float var = ref_block_sum(lsq, red);
+  const float vh = var / (float)hidden;
+  const float ve = vh + eps;
+  const float sq = __builtin_sqrtf(ve);
+  const float rstd = 1.0f / sq;
+  if (tid == 0) {
+    float* o = out + (size_t)blockIdx.x * 8;
+    o[0] = tot; o[1] = var; o[2] = mean; o[3] = vh; o[4] = ve; o[5] = sq; o[6] = rstd; o[7] = lsum;
+  }
+}
+
+extern "C" int omni_debug_norm_stats(const void* in_f16, void* out_f32, float eps, int tokens, int hidden, void* stream) {
+  hipLaunchKernelGGL(norm_stats_debug_kernel, dim3(tokens), dim3(norm_block(hidden, true)), 0, (hipStream_t)stream,
+                     (const half_t*)in_f16, (float*)out_f32, eps, hidden);
+  return omni_launch_status();
+}
+
+// ---- fused extensions (opt-in; not part of the reference API) ------------------------
+extern "C" int omni_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const void* delta_f16,
+                                                  const void* weight_f16, void* sum_f16, void* scale_f16,
+                                                  float eps, int tokens, int hidden, void* stream) {
+  if (!out_i8 || !residual_f16 || !delta_f16 || !weight_f16 || !sum_f16 || !scale_f16 || tokens < 0 || hidden < 1)
+    return OMNI_EINVAL;
+  if (hidden > VPT * NT_MAX) return OMNI_EINVAL;
+  if (tokens == 0) return OMNI_OK;
+  hipLaunchKernelGGL((general_norm_quant_kernel<true, true>), dim3(tokens), dim3(norm_block(hidden, true)),
+                     0, (hipStream_t)stream, (int8_t*)out_i8, (half_t*)residual_f16, (const half_t*)delta_f16,
+                     (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden);
+  return omni_launch_status();
+}
+
+extern "C" int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f16, void* scale_f16,
+                                            int tokens, int d, void* stream) {
+  if (!out_i8 || !in_f16 || !sum_f16 || !scale_f16 || tokens < 0 || d < 1) return OMNI_EINVAL;
+  if (d % 32 != 0) return OMNI_EINVAL;
+  if (tokens == 0) return OMNI_OK;
+  hipLaunchKernelGGL(silu_mul_quant_kernel, dim3(tokens), dim3(norm_block(d, false)), 0, (hipStream_t)stream,
+                     (int8_t*)out_i8, (const half_t*)in_f16, (half_t*)sum_f16, (half_t*)scale_f16, d);
   return omni_launch_status();
 }

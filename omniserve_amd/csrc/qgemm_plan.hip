@@ -19,12 +19,13 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign) {
   const int ngroups = N / 64;
   pl.waves = ngroups % 4 == 0 ? 4 : (ngroups % 2 == 0 ? 2 : 1);
   auto ok = [&](int s) {
-    return s >= 1 && (K % s) == 0 && ((K / s) % kalign) == 0 && (K / s) >= 128 && mt * (K / s) <= 65536;
+    return s >= 1 && (K % s) == 0 && ((K / s) % kalign) == 0 && mt * (K / s) <= 65536;
   };
   int sk = 1;
-  while (!ok(sk) && sk < 64) sk *= 2;               // LDS bound first
+  while (!ok(sk) && sk < 1024) ++sk;                // LDS bound first (smallest valid split)
   const int target_waves = 768;                       // ~3 waves per CU, each with 16 KiB in flight
   while (ngroups * sk < target_waves && ok(sk * 2) && (K / (sk * 2)) >= 512) sk *= 2;
+  if (!ok(sk)) sk = 1;                                // cannot happen for K % kalign == 0; stay safe
   if (g_override_sk > 0 && ok(g_override_sk)) sk = g_override_sk;
   if (g_override_waves > 0 && g_override_waves <= 4 && ngroups % g_override_waves == 0 &&
       g_override_waves != 3)
