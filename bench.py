@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--context", type=int, default=1024)
     ap.add_argument("--group-size", type=int, default=-1)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="reference call sequence (no fused extension kernels)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / gemm_4096 legs")
     args = ap.parse_args()
 
@@ -158,7 +159,7 @@ def main():
     from omniserve_amd.runtime import DecodeRunner, LlamaConfig
     cfg = LlamaConfig.llama3_8b(args.group_size)
     runner = DecodeRunner(cfg, args.batch, args.context, args.steps + args.warmup + 4, device,
-                          seed=1234 + rank, use_graph=not args.no_graph)
+                          seed=1234 + rank, use_graph=not args.no_graph, fused=not args.no_fused)
     for _ in range(args.warmup):
         runner.step()
     torch.cuda.synchronize()
@@ -195,7 +196,7 @@ def main():
                        args.context, "BASELINE.json configs[1]" if args.group_size == -1 else "configs[2]-like"),
                    "batch_per_gpu": args.batch, "context": args.context, "layers": cfg.layers,
                    "parallelism": "replicas x%d (no collective)" % world if world > 1 else "single GPU",
-                   "hip_graph": not args.no_graph,
+                   "hip_graph": not args.no_graph, "fused_ext_kernels": not args.no_fused,
                    "gemm_weight_bytes_per_step": runner.gemm_weight_bytes_per_step(),
                    "kv_bytes_per_step": runner.kv_bytes_per_step(args.context)},
     }

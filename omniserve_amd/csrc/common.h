@@ -22,6 +22,15 @@ static inline int omni_launch_status() {
   return e == hipSuccess ? OMNI_OK : OMNI_ELAUNCH;
 }
 
+// Keeps an f32 intermediate as a materialised, once-rounded f32 value.  Without it the backend
+// folds `(half)(a * (float)b_half)` into v_fma_mixlo_f16 (one rounding straight to fp16), whereas
+// the reference (and oracle/) round to f32 first and to fp16 second; the two differ in ~2^-13 of
+// the elements.
+__device__ __forceinline__ float rounded_f32(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 // cvt.rni.sat.s8.f32 (reference kernels/csrc/utils.cuh:79-84): round half to
 // even, saturate to [-128,127], NaN -> 0.
 __device__ __forceinline__ int8_t rni_sat_s8(float x) {

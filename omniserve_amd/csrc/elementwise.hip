@@ -135,7 +135,7 @@ __global__ __launch_bounds__(NT_MAX) void general_norm_quant_kernel(
     const int i = tid + j * nt;
     const bool ok = i < hidden;
     float y = (x[j] - mean) * rstd;
-    y = y * (float)gamma[ok ? i : 0];
+    y = rounded_f32(y * (float)gamma[ok ? i : 0]);
     x[j] = y;
     const float yh = ok ? (float)(half_t)y : 0.0f;
     amax_h = __builtin_fmaxf(amax_h, __builtin_fabsf(yh));
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NT_MAX) void rms_norm_kernel(half_t* __restrict__ o
   for (int j = 0; j < VPT; ++j) {
     const int i = tid + j * nt;
     if (i < hidden) {
-      const half_t t = (half_t)(x[j] * rstd);
+      const half_t t = (half_t)rounded_f32(x[j] * rstd);
       out[row + i] = (half_t)((float)t * (float)weight[i]);
     }
   }

@@ -276,25 +276,35 @@ __global__ __launch_bounds__(64 * WAVES) void w4a8_gemm_kernel(GemmArgs p) {
 
 // ------------------------------------------------------------------------------------------
 // Decode-shape kernel (M <= 128): pure weight streaming.
-//   * the whole activation K-slice of the workgroup is staged into (dynamic) LDS ONCE, in the
-//     weights' k order -> a single barrier, none inside the stream loop;
-//   * each wave keeps a ring of RING k-steps (RING * 2 KiB) of packed weights in flight: the
-//     registers of step s are refilled for step s+RING right after they are unpacked, so the
-//     HBM latency is covered by RING-1 steps of MFMA work plus the other resident waves.
+//   * each wave keeps a ring of RING k-steps (RING x 2 KiB) of packed weights in flight: the
+//     registers of step s are refilled for step s+RING right after they are unpacked, so the HBM
+//     latency is covered by RING-1 steps of MFMA work;
+//   * the int8 activations are staged one ROUND (RING steps) ahead: global/L2 -> VGPR at the top
+//     of round r, -> LDS (in the weights' k order, double buffered) at its end.  On-GPU ablation
+//     (tools/gemv_probe.hip, profiles/) showed that staging the whole K-slice up front costs up to
+//     2x on this kernel, while the stream + unpack + LDS reads + MFMA alone run at the plain-copy rate;
+//   * M <= 16 uses single-wave workgroups (finest scheduling granule, no barrier at all); larger M
+//     shares the staged activations between 2 or 4 waves (one barrier per round).
+//   * no control flow inside a round, so every wait is a counted s_waitcnt vmcnt(N).
 // ------------------------------------------------------------------------------------------
 template <int MB, int MODE>
 struct GemvCfg {
   static constexpr int WL = (MODE == MODE_W8) ? 4 : 2;
-  static constexpr int RING = (MODE == MODE_W8) ? (MB <= 2 ? 4 : 2) : (MB <= 2 ? 8 : 4);
+  static constexpr int RING = (MODE == MODE_W8) ? 4 : (MB <= 2 ? 8 : 4);
+  static constexpr int WAVES = MB == 1 ? 1 : (MB == 2 ? 2 : 4);
 };
 
-template <int MB, int MODE, int WAVES, bool TO_SLAB>
-__global__ __launch_bounds__(64 * WAVES) void w4a8_gemv_kernel(GemmArgs p) {
+template <int MB, int MODE, bool TO_SLAB>
+__global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES)) void w4a8_gemv_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
+  constexpr int WAVES = GemvCfg<MB, MODE>::WAVES;
   constexpr int NTHREADS = 64 * WAVES;
   constexpr int WL = GemvCfg<MB, MODE>::WL;
   constexpr int RING = GemvCfg<MB, MODE>::RING;
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // [nsteps][MT][64]
+  constexpr int RK = RING * KSTEP;                       // k per round
+  constexpr int APT = (MT * RK / 16) / NTHREADS;          // 16-B activation pieces per thread per round
+  static_assert((MT * RK / 16) % NTHREADS == 0, "activation round must tile the workgroup");
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2][MT * RK];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -304,11 +314,14 @@ __global__ __launch_bounds__(64 * WAVES) void w4a8_gemv_kernel(GemmArgs p) {
   const int k_begin = blockIdx.y * p.kslice;
   const int k_end = min(p.K, k_begin + p.kslice);
   const int nsteps = (k_end - k_begin) / KSTEP;
+  const int rounds = nsteps / RING;
 
   const int lx = (lane >> 3) & 1, lc = lane & 7, le = lane >> 4;
+  // inactive waves (N/64 not a multiple of WAVES) stream the last valid group again and drop it
+  const int ngc = wave_active ? ng : (p.N / 64 - 1);
   const uint8_t* wbase;
-  if constexpr (MODE == MODE_W8) wbase = p.W + (size_t)(ng * 64 + (lane & 15)) * p.K + (lane >> 4) * 16;
-  else wbase = p.W + ((size_t)(2 * ng + lx) * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
+  if constexpr (MODE == MODE_W8) wbase = p.W + (size_t)(ngc * 64 + (lane & 15)) * p.K + (lane >> 4) * 16;
+  else wbase = p.W + ((size_t)(2 * ngc + lx) * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
   auto load_w = [&](int k, int j) -> uint4 {
     const uint8_t* ptr;
     if constexpr (MODE == MODE_W8) ptr = wbase + (size_t)j * 16 * p.K + k;
@@ -316,65 +329,39 @@ __global__ __launch_bounds__(64 * WAVES) void w4a8_gemv_kernel(GemmArgs p) {
     const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(ptr));
     return make_uint4((uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
   };
-  const size_t gcol = (size_t)(2 * ng + lx) * 32 + lc * 4;  // per-group param column of this lane
+  const size_t gcol = (size_t)(2 * ngc + lx) * 32 + lc * 4;  // per-group param column of this lane
   auto load_gp = [&](const uint8_t* base, int k) -> uint32_t {
     return *reinterpret_cast<const uint32_t*>(base + (size_t)(k / 128) * p.N + gcol);
   };
 
-  // ---- 1. put the first RING steps of weights in flight --------------------------------------
-  // The stream is organised in `rounds` of RING steps with NO control flow inside a round, so
-  // the compiler can emit counted s_waitcnt vmcnt(N) (any branch around a load degrades every
-  // wait to vmcnt(0) and serialises the ring).  nsteps % RING leftovers run in a simple tail loop.
-  const int rounds = nsteps / RING;
-  uint4 wq[RING][WL];
-  uint32_t gs[RING], gz[RING];  // per-group second-level params of the step's 128-k group
-  if (wave_active && rounds > 0) {
+  // activation staging: piece id -> (row m, 16-byte piece kk of the round)
+  uint4 areg[APT];
+  auto load_a = [&](int kr) {  // kr = first k of the round
 #pragma unroll
-    for (int s = 0; s < RING; ++s) {
+    for (int j = 0; j < APT; ++j) {
+      const int id = tid + j * NTHREADS;
+      const int m = id / (RK / 16), kk = id % (RK / 16);
+      const int mc = m < p.M ? m : p.M - 1;  // rows >= M re-read the last row (results never stored)
+      areg[j] = *reinterpret_cast<const uint4*>(p.A + (size_t)mc * p.K + kr + kk * 16);
+    }
+  };
+  auto store_a = [&](int buf) {
 #pragma unroll
-      for (int j = 0; j < WL; ++j) wq[s][j] = load_w(k_begin + s * KSTEP, j);
-      if constexpr (MODE == MODE_GRP) {
-        gs[s] = load_gp(p.s2s, k_begin + s * KSTEP);
-        gz[s] = load_gp(p.s2z, k_begin + s * KSTEP);
+    for (int j = 0; j < APT; ++j) {
+      const int id = tid + j * NTHREADS;
+      const int m = id / (RK / 16), kk = id % (RK / 16);
+      if constexpr (MODE == MODE_W8) {
+        *reinterpret_cast<uint4*>(&lds[buf][((kk >> 2) * MT + m) * 64 + (kk & 3) * 16]) = areg[j];
+      } else {
+        const int kp = kk >> 2, tp = (kk >> 1) & 1, d = kk & 1;
+        uint8_t* dst = &lds[buf][(kp * MT + m) * 64 + tp * 8 + d * 4];
+        *reinterpret_cast<uint32_t*>(dst + 0) = areg[j].x;
+        *reinterpret_cast<uint32_t*>(dst + 16) = areg[j].y;
+        *reinterpret_cast<uint32_t*>(dst + 32) = areg[j].z;
+        *reinterpret_cast<uint32_t*>(dst + 48) = areg[j].w;
       }
     }
-  }
-
-  // ---- 2. stage the activation slice (M x kslice int8) into LDS in the weights' k order -------
-  {
-    const int ppr = nsteps * 4;            // 16-byte pieces per row
-    const int pieces = MT * ppr;
-    constexpr int BATCH = 8;
-    for (int id0 = tid; id0 < pieces; id0 += NTHREADS * BATCH) {
-      uint4 a[BATCH];
-#pragma unroll
-      for (int b = 0; b < BATCH; ++b) {
-        const int id = id0 + b * NTHREADS;
-        const int m = id / ppr, kk = id - m * ppr;
-        a[b] = make_uint4(0, 0, 0, 0);
-        if (id < pieces && m < p.M)
-          a[b] = *reinterpret_cast<const uint4*>(p.A + (size_t)m * p.K + k_begin + kk * 16);
-      }
-#pragma unroll
-      for (int b = 0; b < BATCH; ++b) {
-        const int id = id0 + b * NTHREADS;
-        if (id >= pieces) continue;
-        const int m = id / ppr, kk = id - m * ppr;
-        if constexpr (MODE == MODE_W8) {
-          *reinterpret_cast<uint4*>(&lds[((kk >> 2) * MT + m) * 64 + (kk & 3) * 16]) = a[b];
-        } else {
-          const int kp = kk >> 2, tp = (kk >> 1) & 1, d = kk & 1;
-          uint8_t* dst = &lds[(kp * MT + m) * 64 + tp * 8 + d * 4];
-          *reinterpret_cast<uint32_t*>(dst + 0) = a[b].x;
-          *reinterpret_cast<uint32_t*>(dst + 16) = a[b].y;
-          *reinterpret_cast<uint32_t*>(dst + 32) = a[b].z;
-          *reinterpret_cast<uint32_t*>(dst + 48) = a[b].w;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (!wave_active) return;
+  };
 
   v4i acc[MB][4];
 #pragma unroll
@@ -382,7 +369,6 @@ __global__ __launch_bounds__(64 * WAVES) void w4a8_gemv_kernel(GemmArgs p) {
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) acc[mb][ab] = (v4i){0, 0, 0, 0};
 
-  // ---- 3. stream -------------------------------------------------------------------------------
   auto unpack = [&](const uint4 (&w)[WL], uint32_t sc4, uint32_t zr4, v4i (&wa)[4]) {
     if constexpr (MODE == MODE_W8) {
 #pragma unroll
@@ -407,52 +393,94 @@ __global__ __launch_bounds__(64 * WAVES) void w4a8_gemv_kernel(GemmArgs p) {
         }
     }
   };
-  auto mma_step = [&](const v4i (&wa)[4], int st) {
+  auto mma_step = [&](const v4i (&wa)[4], const uint8_t* abuf, int s) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const v4i bf = *reinterpret_cast<const v4i*>(
-          lds + ((st * MT + mb * 16 + (lane & 15)) * 4 + (lane >> 4)) * 16);
+      const v4i bf = *reinterpret_cast<const v4i*>(abuf + ((s * MT + mb * 16 + (lane & 15)) * 4 + (lane >> 4)) * 16);
 #pragma unroll
       for (int ab = 0; ab < 4; ++ab)
         acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf, acc[mb][ab], 0, 0, 0);
     }
   };
-  for (int r = 0; r + 1 < rounds; ++r) {  // steady state: consume step s, refill it for round r+1
+
+  uint4 wq[RING][WL];
+  uint32_t gs[RING], gz[RING];
+  if (rounds > 0) {
+    // ---- prologue: ring for round 0 in flight, activations of round 0 into LDS ----------------
 #pragma unroll
     for (int s = 0; s < RING; ++s) {
-      v4i wa[4];
-      unpack(wq[s], gs[s], gz[s], wa);
-      const int kn = k_begin + ((r + 1) * RING + s) * KSTEP;
 #pragma unroll
-      for (int j = 0; j < WL; ++j) wq[s][j] = load_w(kn, j);
+      for (int j = 0; j < WL; ++j) wq[s][j] = load_w(k_begin + s * KSTEP, j);
       if constexpr (MODE == MODE_GRP) {
-        gs[s] = load_gp(p.s2s, kn);
-        gz[s] = load_gp(p.s2z, kn);
+        gs[s] = load_gp(p.s2s, k_begin + s * KSTEP);
+        gz[s] = load_gp(p.s2z, k_begin + s * KSTEP);
       }
-      mma_step(wa, r * RING + s);
     }
-  }
-  if (rounds > 0) {  // last round: drain
+    load_a(k_begin);
+    store_a(0);
+    if constexpr (WAVES > 1) __syncthreads();
+    // ---- steady state ---------------------------------------------------------------------------
+    for (int r = 0; r + 1 < rounds; ++r) {
+      load_a(k_begin + (r + 1) * RK);
+      const uint8_t* abuf = lds[r & 1];
 #pragma unroll
-    for (int s = 0; s < RING; ++s) {
-      v4i wa[4];
-      unpack(wq[s], gs[s], gz[s], wa);
-      mma_step(wa, (rounds - 1) * RING + s);
+      for (int s = 0; s < RING; ++s) {
+        v4i wa[4];
+        unpack(wq[s], gs[s], gz[s], wa);
+        const int kn = k_begin + (r + 1) * RK + s * KSTEP;
+#pragma unroll
+        for (int j = 0; j < WL; ++j) wq[s][j] = load_w(kn, j);
+        if constexpr (MODE == MODE_GRP) {
+          gs[s] = load_gp(p.s2s, kn);
+          gz[s] = load_gp(p.s2z, kn);
+        }
+        mma_step(wa, abuf, s);
+      }
+      store_a((r + 1) & 1);
+      if constexpr (WAVES > 1) __syncthreads();
+    }
+    {  // last round: drain the ring
+      const uint8_t* abuf = lds[(rounds - 1) & 1];
+#pragma unroll
+      for (int s = 0; s < RING; ++s) {
+        v4i wa[4];
+        unpack(wq[s], gs[s], gz[s], wa);
+        mma_step(wa, abuf, s);
+      }
     }
   }
-  for (int st = rounds * RING; st < nsteps; ++st) {  // leftovers (nsteps % RING), unpipelined
-    uint4 w[WL];
+  // ---- leftovers (nsteps % RING): one step at a time, unpipelined (planner avoids this) ------------
+  for (int st = rounds * RING; st < nsteps; ++st) {
     const int kn = k_begin + st * KSTEP;
+    if constexpr (WAVES > 1) __syncthreads();
+    for (int id = tid; id < MT * 4; id += NTHREADS) {
+      const int m = id >> 2, kk = id & 3;
+      const int mc = m < p.M ? m : p.M - 1;
+      const uint4 a = *reinterpret_cast<const uint4*>(p.A + (size_t)mc * p.K + kn + kk * 16);
+      if constexpr (MODE == MODE_W8) {
+        *reinterpret_cast<uint4*>(&lds[0][m * 64 + kk * 16]) = a;
+      } else {
+        const int tp = (kk >> 1) & 1, d = kk & 1;
+        uint8_t* dst = &lds[0][m * 64 + tp * 8 + d * 4];
+        *reinterpret_cast<uint32_t*>(dst + 0) = a.x;
+        *reinterpret_cast<uint32_t*>(dst + 16) = a.y;
+        *reinterpret_cast<uint32_t*>(dst + 32) = a.z;
+        *reinterpret_cast<uint32_t*>(dst + 48) = a.w;
+      }
+    }
+    if constexpr (WAVES > 1) __syncthreads();
+    uint4 w[WL];
 #pragma unroll
     for (int j = 0; j < WL; ++j) w[j] = load_w(kn, j);
     uint32_t sc4 = 0, zr4 = 0;
     if constexpr (MODE == MODE_GRP) { sc4 = load_gp(p.s2s, kn); zr4 = load_gp(p.s2z, kn); }
     v4i wa[4];
     unpack(w, sc4, zr4, wa);
-    mma_step(wa, st);
+    mma_step(wa, lds[0], 0);
   }
+  if (!wave_active) return;
 
-  // ---- 4. write back (same mapping as w4a8_gemm_kernel) ------------------------------------------
+  // ---- write back (same mapping as w4a8_gemm_kernel) ------------------------------------------------
   const int mcol = lane & 15;
   const int i0 = (lane >> 4) * 4;
 #pragma unroll
@@ -543,25 +571,16 @@ static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st
   hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, false>), grid, dim3(64 * WAVES), 0, st, a);
 }
 
-template <int MODE, int MB, int WAVES>
+template <int MODE, int MB>
 static void launch_gemv(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
+  constexpr int WAVES = GemvCfg<MB, MODE>::WAVES;
   dim3 grid((a.N / 64 + WAVES - 1) / WAVES, pl.sk, 1);
-  const size_t lds = (size_t)MB * 16 * pl.kslice;
   if (pl.sk > 1) {
-    hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, WAVES, true>), grid, dim3(64 * WAVES), lds, st, a);
+    hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, true>), grid, dim3(64 * WAVES), 0, st, a);
     const size_t total = (size_t)a.M * (a.N / 4);
     hipLaunchKernelGGL((splitk_epilogue_kernel<MODE>), dim3((total + 63) / 64), dim3(64), 0, st, a, pl.sk);
   } else {
-    hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, WAVES, false>), grid, dim3(64 * WAVES), lds, st, a);
-  }
-}
-
-template <int MODE, int MB>
-static void launch_gemv_waves(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
-  switch (pl.waves) {
-    case 1: launch_gemv<MODE, MB, 1>(a, pl, st); break;
-    case 2: launch_gemv<MODE, MB, 2>(a, pl, st); break;
-    default: launch_gemv<MODE, MB, 4>(a, pl, st); break;
+    hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, false>), grid, dim3(64 * WAVES), 0, st, a);
   }
 }
 
@@ -580,10 +599,10 @@ static int launch_gemm(GemmArgs a, void* ws, size_t ws_bytes, hipStream_t st) {
     launch_variant<MODE, 8, 4>(a, pl, st);
   } else {
     switch (pl.mb) {
-      case 1: launch_gemv_waves<MODE, 1>(a, pl, st); break;
-      case 2: launch_gemv_waves<MODE, 2>(a, pl, st); break;
-      case 4: launch_gemv_waves<MODE, 4>(a, pl, st); break;
-      default: launch_gemv_waves<MODE, 8>(a, pl, st); break;
+      case 1: launch_gemv<MODE, 1>(a, pl, st); break;
+      case 2: launch_gemv<MODE, 2>(a, pl, st); break;
+      case 4: launch_gemv<MODE, 4>(a, pl, st); break;
+      default: launch_gemv<MODE, 8>(a, pl, st); break;
     }
   }
   return omni_launch_status();

@@ -13,23 +13,23 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign) {
     return pl;
   }
   // bandwidth-bound regime (decode): every CU must stream weights.  One wave owns 64 channels
-  // and a K-slice; the slice of activations (MT x kslice bytes) must fit the 64 KiB dynamic LDS.
+  // and a K-slice; activations are staged per round of RING steps, so the slice length is free.
   pl.mb = M <= 16 ? 1 : (M <= 32 ? 2 : (M <= 64 ? 4 : 8));
-  const int mt = pl.mb * 16;
+  pl.waves = pl.mb == 1 ? 1 : (pl.mb == 2 ? 2 : 4);   // fixed per tile height (GemvCfg)
   const int ngroups = N / 64;
-  pl.waves = ngroups % 4 == 0 ? 4 : (ngroups % 2 == 0 ? 2 : 1);
-  auto ok = [&](int s) {
-    return s >= 1 && (K % s) == 0 && ((K / s) % kalign) == 0 && mt * (K / s) <= 65536;
-  };
+  const int round_k = (pl.mb <= 2 ? 8 : 4) * 64;     // k per ring round (W8A8 uses 4 x 64 <= this)
+  auto ok = [&](int s) { return s >= 1 && (K % s) == 0 && ((K / s) % kalign) == 0; };
+  auto full_rounds = [&](int s) { return ((K / s) % round_k) == 0; };
+  // split K until ~2 waves per CU stream (a wave keeps 16 KiB in flight); prefer slices made of
+  // whole rounds, and no split at all when the channels alone fill the machine (no slab traffic)
   int sk = 1;
-  while (!ok(sk) && sk < 1024) ++sk;                // LDS bound first (smallest valid split)
-  const int target_waves = 768;                       // ~3 waves per CU, each with 16 KiB in flight
-  while (ngroups * sk < target_waves && ok(sk * 2) && (K / (sk * 2)) >= 512) sk *= 2;
-  if (!ok(sk)) sk = 1;                                // cannot happen for K % kalign == 0; stay safe
+  const int target_waves = 448;
+  for (int s = 1; s <= 64 && ngroups * sk < target_waves; ++s) {
+    if (!ok(s) || (K / s) < round_k) continue;
+    if (!full_rounds(s) && full_rounds(sk)) continue;
+    sk = s;
+  }
   if (g_override_sk > 0 && ok(g_override_sk)) sk = g_override_sk;
-  if (g_override_waves > 0 && g_override_waves <= 4 && ngroups % g_override_waves == 0 &&
-      g_override_waves != 3)
-    pl.waves = g_override_waves;
   pl.sk = sk;
   pl.kslice = K / sk;
   return pl;

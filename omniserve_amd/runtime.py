@@ -19,7 +19,7 @@ import dataclasses
 
 import torch
 
-from .backend import (activation_ops, fused_attention_pure_dense, fused_kernels, layernorm_ops,
+from .backend import (activation_ops, fused_attention_pure_dense, fused_ext, fused_kernels, layernorm_ops,
                       qgemm_w4a8_per_chn, qgemm_w4a8_per_group)
 from .rope import rope_table
 from . import _lib
@@ -83,8 +83,11 @@ class DecodeRunner:
     """bs sequences with `context` cached tokens each; step() decodes one token per sequence."""
 
     def __init__(self, cfg: LlamaConfig, batch: int, context: int, max_new: int, device, seed=0,
-                 use_graph=True):
+                 use_graph=True, fused=True):
         self.cfg, self.B, self.device = cfg, batch, device
+        # fused=True uses the opt-in fused entry points (residual add + norm + quant, silu*mul + quant;
+        # bit-identical to the reference call sequence, SURVEY.md 8f.1); False = the reference sequence
+        self.fused = fused
         c = cfg
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
@@ -181,7 +184,11 @@ class DecodeRunner:
         hq, hk, d = c.heads, c.kv_heads, c.head_dim
         for li, L in enumerate(self.layers):
             qa_h, qa_i = self._q_hidden, self._q_inter
-            layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln1"], self.act_sum, self.act_scale, c.eps, True)
+            if self.fused and li > 0:   # residual += down_proj(prev layer), then norm + quant
+                fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln1"], self.act_sum,
+                                                        self.act_scale, c.eps)
+            else:
+                layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln1"], self.act_sum, self.act_scale, c.eps, True)
             L["qkv"].forward(qa_h, self.act_scale, self.act_sum, self.qkv_buf)
             q = self.qkv_buf[:, : hq * d].view(B, hq, d)
             k = self.qkv_buf[:, hq * d:(hq + hk) * d].view(B, hk, d)
@@ -191,13 +198,21 @@ class DecodeRunner:
                 self.max_context, d, c.rope_theta, True, True, True)
             fused_kernels.invoke_quant_fuse_sum(self._q_attn, attn.view(B, hq * d), self.act_sum, self.act_scale)
             L["o"].forward(self._q_attn, self.act_scale, self.act_sum, self.proj_buf)
-            self.x.add_(self.proj_buf)
-            layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln2"], self.act_sum, self.act_scale, c.eps, True)
+            if self.fused:
+                fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln2"], self.act_sum,
+                                                        self.act_scale, c.eps)
+            else:
+                self.x.add_(self.proj_buf)
+                layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln2"], self.act_sum, self.act_scale, c.eps, True)
             L["gate_up"].forward(qa_h, self.act_scale, self.act_sum, self.gate_up_buf)
-            activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
-            fused_kernels.invoke_quant_fuse_sum(qa_i, self.mlp_act, self.act_sum, self.act_scale)
+            if self.fused:
+                fused_ext.silu_mul_quant_fuse_sum(qa_i, self.gate_up_buf, self.act_sum, self.act_scale)
+            else:
+                activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
+                fused_kernels.invoke_quant_fuse_sum(qa_i, self.mlp_act, self.act_sum, self.act_scale)
             L["down"].forward(qa_i, self.act_scale, self.act_sum, self.proj_buf)
-            self.x.add_(self.proj_buf)
+            if not self.fused or li == len(self.layers) - 1:
+                self.x.add_(self.proj_buf)
         layernorm_ops.rms_norm(self.normed, self.x, self.final_norm, c.eps, False)
         logits = torch.matmul(self.normed, self.lm_head.t())
         self.tokens.copy_(torch.argmax(logits, dim=-1))

@@ -80,3 +80,41 @@ def test_silu_and_mul(tokens, d):
     # (silu -> fp16, product -> fp16) can then flip by one ulp: <= 2 fp16 ulp, and rarely
     assert f16_ulp_diff(out, want) <= 2
     assert (np.asarray(out.cpu().numpy()).view(np.uint16) != want.view(np.uint16)).mean() < 1e-3
+
+
+@pytest.mark.parametrize("tokens,hidden", [(16, 4096), (5, 8192), (3, 128)])
+def test_fused_add_norm_matches_the_two_reference_calls(tokens, hidden):
+    import omniserve_backend.layernorm_ops as ln
+    from omniserve_amd.backend import fused_ext
+    x = _x(tokens, hidden, 11 + tokens, 2.0)
+    delta = _x(tokens, hidden, 12 + tokens, 1.0)
+    g = (1.0 + 0.1 * np.random.default_rng(1).standard_normal(hidden)).astype(np.float16)
+    xs = (x.astype(np.float32) + delta.astype(np.float32)).astype(np.float16)     # torch fp16 add
+    q, s, sm = oe.rms_norm_general(xs, g, 1e-5, True)
+    res = to_dev(x)
+    out = torch.empty((tokens, hidden), dtype=torch.int8, device=dev())
+    scale = torch.empty((tokens,), dtype=torch.float16, device=dev())
+    ssum = torch.empty((tokens,), dtype=torch.float16, device=dev())
+    fused_ext.add_rms_norm_general_fuse_sum(out, res, to_dev(delta), to_dev(g), ssum, scale, 1e-5)
+    torch.cuda.synchronize()
+    assert_f16_equal(res, xs, "residual updated in place")
+    assert np.array_equal(out.cpu().numpy(), q)
+    assert_f16_equal(scale, s, "scale")
+    assert_f16_equal(ssum, sm, "sum")
+
+
+@pytest.mark.parametrize("tokens,d", [(16, 14336), (3, 28672), (5, 128)])
+def test_fused_silu_mul_quant_matches_the_two_kernels(tokens, d):
+    """Compared against the HIP silu_and_mul + quant pair (both go through the same device expf)."""
+    import omniserve_backend.activation_ops as act
+    import omniserve_backend.fused_kernels as fk
+    from omniserve_amd.backend import fused_ext
+    x = to_dev(_x(tokens, 2 * d, tokens + d, 2.0))
+    tmp = torch.empty((tokens, d), dtype=torch.float16, device=dev())
+    act.silu_and_mul(tmp, x)
+    q1 = torch.empty((tokens, d), dtype=torch.int8, device=dev()); s1 = torch.empty((tokens,), dtype=torch.float16, device=dev()); m1 = s1.clone()
+    fk.invoke_quant_fuse_sum(q1, tmp, m1, s1)
+    q2 = torch.empty_like(q1); s2 = torch.empty_like(s1); m2 = torch.empty_like(s1)
+    fused_ext.silu_mul_quant_fuse_sum(q2, x, m2, s2)
+    torch.cuda.synchronize()
+    assert torch.equal(q1, q2) and torch.equal(s1.view(torch.int16), s2.view(torch.int16)) and torch.equal(m1.view(torch.int16), m2.view(torch.int16))
