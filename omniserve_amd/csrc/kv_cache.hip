@@ -518,6 +518,326 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_kernel(DecodeArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Decode attention, matrix-core version (default).  Same work decomposition and numerics contract
+// as kv4_decode_kernel above, but Q.K^T and P.V run on v_mfma_f32_16x16x32_f16:
+//   * Q.K^T: A = dequantised K (row = token, k = head dims: one packed dword = 8 codes = one
+//     lane's 8 k-slots), B = q (col = q head, padded to 16), 4 MFMAs per 16 tokens;
+//   * P.V: V is stored token-major, the contraction runs over tokens, so the dequantised fp16 V
+//     tile (32 tokens x 128 dims) goes through LDS once and comes back transposed with
+//     ds_read_b64_tr_b16 (lane L of a 16-lane group passes &M[L>>2][4*(L&3)] and receives column
+//     L of the 4x16 block -- verified on hardware with tools/tr_probe.hip); A = V^T (row = dim),
+//     B = P^T (col = q head, probabilities rounded to fp16 as the reference does), 8 MFMAs per
+//     32 tokens; O accumulators are 32 VGPRs instead of 128.
+// ------------------------------------------------------------------------------------------
+typedef __fp16 v4hp __attribute__((__vector_size__(4 * sizeof(__fp16))));
+constexpr int VROW = 272;        // bytes per token row of the V tile in LDS (256 + 16: conflict-free b128 writes)
+constexpr int VTILE = 32 * VROW;  // one 32-token tile per wave
+constexpr int MF_UK = 8;          // K groups (16 tokens) in flight per wave
+constexpr int MF_UT = 2;          // V tiles (32 tokens) in flight per wave
+
+__device__ __forceinline__ int unperm_pos(int q) { return (q & ~7) | ((q >> 1) & 3) | ((q & 1) << 2); }
+
+template <int G, bool DIRECT>
+__global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int sstride = p.split_tokens + 32;
+  half_t* q_lds = reinterpret_cast<half_t*>(smem);            // [G][128] dequant order
+  half_t* kcur = q_lds + G * DH;                              // [128] natural order (post RoPE)
+  half_t* kcur_p = kcur + DH;                                 // [128] dequant order
+  half_t* vcur = kcur_p + DH;                                 // [128]
+  float* red = reinterpret_cast<float*>(vcur + DH);           // [64]
+  int64_t* pages = reinterpret_cast<int64_t*>(red + 64);      // [2][40]
+  float* xbuf = reinterpret_cast<float*>(pages + 80);         // [4 waves][G][128]
+  uint8_t* vtile = reinterpret_cast<uint8_t*>(xbuf + DEC_WAVES * G * DH);  // [4 waves][32][VROW]
+  float* scores = reinterpret_cast<float*>(vtile + DEC_WAVES * VTILE);     // [G][sstride] f32
+  half_t* ph = reinterpret_cast<half_t*>(scores + G * sstride);             // [G][sstride] fp16 probabilities
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x;
+  const int group = p.num_heads / p.num_kv_heads;
+  const int qg = group / G;
+  const int hk = blockIdx.y / qg;
+  const int sub = blockIdx.y % qg;
+  const int hq0 = hk * group + sub * G;
+  const int b = blockIdx.z;
+  const int tlen = p.lengths[b] - 1;
+  const KvLayout lay = p.lay;
+  const int64_t* ktab = p.kv_pointers + (size_t)b * 2 * p.max_blocks;
+  const int64_t* vtab = ktab + p.max_blocks;
+  const float inv_sqrt_dh = 0.08838834764831845f;
+
+  int per = (tlen + p.nsplit - 1) / p.nsplit;
+  per = (per + 15) & ~15;
+  if (per > p.split_tokens) per = p.split_tokens;
+  const int t0 = min(tlen, split * per);
+  const int t1 = (split == p.nsplit - 1) ? min(tlen, t0 + p.split_tokens) : min(tlen, t0 + per);
+  const int nt = t1 - t0;
+  const bool owns_cur = split == p.nsplit - 1;
+  const int page0 = t0 >> lay.tpb_log2;
+
+  // ---- stage: page pointers, RoPE(q) (and k of the current token) ------------------------------
+  if (tid < 80) {
+    const int pi = tid < 40 ? tid : tid - 40;
+    const int64_t* tab = tid < 40 ? ktab : vtab;
+    const int pg = page0 + pi;
+    pages[tid] = (pg < p.max_blocks && (pg << lay.tpb_log2) <= tlen) ? tab[pg] : 0;
+  }
+  {
+    const int rp = tlen < p.rope_max_pos ? tlen : p.rope_max_pos - 1;
+    const float* cs = p.rope + (size_t)rp * DH;
+    for (int idx = tid; idx < (G + 1) * 64; idx += DEC_THREADS) {
+      const int h = idx >> 6, i = idx & 63;
+      if (h == G && !owns_cur) continue;
+      const half_t* src = h < G ? p.q + (size_t)b * p.q_stride + (size_t)(hq0 + h) * DH
+                                : p.k + (size_t)b * p.kv_stride + (size_t)hk * DH;
+      const float c = cs[2 * i], sn = cs[2 * i + 1];
+      const float a = (float)src[i], bb = (float)src[i + 64];
+      const float t0f = c * a, t1f = sn * bb, t2f = c * bb, t3f = sn * a;
+      const half_t r0 = (half_t)(t0f - t1f), r1 = (half_t)(t2f + t3f);
+      if (h < G) {
+        q_lds[h * DH + perm_pos(i)] = r0;
+        q_lds[h * DH + perm_pos(i + 64)] = r1;
+      } else {
+        kcur[i] = r0; kcur[i + 64] = r1;
+        kcur_p[perm_pos(i)] = r0; kcur_p[perm_pos(i + 64)] = r1;
+      }
+    }
+    if (owns_cur && tid < DH) vcur[tid] = p.v[(size_t)b * p.kv_stride + (size_t)hk * DH + tid];
+  }
+  __syncthreads();
+
+  const int ngroups = (nt + 15) >> 4;
+  const int ntiles = (nt + 31) >> 5;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int jh = l15 < G ? l15 : 0;                               // this lane's q-head column (clamped)
+  const int tail_off = lay.bytes_per_seq + hk * lay.tpb * 2;
+  const int zero_off = lay.num_kv_heads * lay.tpb * 2;
+
+  // ---- pass 1: scores = q.K / sqrt(Dh) on MFMA ------------------------------------------------------
+  float mloc = -1e30f;   // running max of this lane's head column (valid for l15 < G)
+  {
+    v8h qb[4];  // B operand: q[head jh][32*l4 + 8s + (0..7 in dequant order)]
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)
+      qb[sidx] = *reinterpret_cast<const v8h*>(q_lds + jh * DH + 32 * l4 + 8 * sidx);
+    const size_t khead_off = (size_t)hk * lay.tpb * ROW_BYTES + l4 * 16;  // lane: token l15, 16-B piece l4
+    for (int g0 = wave; g0 < ngroups; g0 += DEC_WAVES * MF_UK) {
+      uint4 raw[MF_UK];
+      half_t sc[MF_UK], ze[MF_UK];
+#pragma unroll
+      for (int u = 0; u < MF_UK; ++u) {
+        const int ti = (g0 + u * DEC_WAVES) * 16 + l15;
+        const int tok = ti < nt ? t0 + ti : t0;
+        const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[(tok >> lay.tpb_log2) - page0]);
+        const int slot = tok & (lay.tpb - 1);
+        raw[u] = *reinterpret_cast<const uint4*>(pg + khead_off + (size_t)slot * ROW_BYTES);
+        const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
+        sc[u] = tail[0];
+        ze[u] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
+      }
+#pragma unroll
+      for (int u = 0; u < MF_UK; ++u) {
+        const int gbase = (g0 + u * DEC_WAVES) * 16;
+        if (gbase >= ngroups * 16) continue;  // wave-uniform
+        const half_t ch = (half_t)(-(float)sc[u] * (float)ze[u]);
+        v2h kd[16];
+        kv4_dequant16(raw[u], (v2h){sc[u], sc[u]}, (v2h){ch, ch}, kd);
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+          const v8h a = {kd[4 * sidx][0], kd[4 * sidx][1], kd[4 * sidx + 1][0], kd[4 * sidx + 1][1],
+                         kd[4 * sidx + 2][0], kd[4 * sidx + 2][1], kd[4 * sidx + 3][0], kd[4 * sidx + 3][1]};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qb[sidx], acc, 0, 0, 0);
+        }
+        // acc[r] = q[head l15] . K[token gbase + 4*l4 + r]
+        if (l15 < G) {
+          v4f sv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ti = gbase + 4 * l4 + r;
+            sv[r] = ti < nt ? acc[r] * inv_sqrt_dh : -1e30f;
+            mloc = __builtin_fmaxf(mloc, sv[r]);
+          }
+          *reinterpret_cast<v4f*>(scores + l15 * sstride + gbase + 4 * l4) = sv;
+        }
+      }
+    }
+  }
+  float scur[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) scur[g] = 0.0f;
+  if (owns_cur) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float a = (float)q_lds[g * DH + lane] * (float)kcur_p[lane] +
+                (float)q_lds[g * DH + 64 + lane] * (float)kcur_p[64 + lane];
+      a = wave_sum64(a);
+      scur[g] = a * inv_sqrt_dh;
+    }
+  }
+  // block max per head
+  float mblk[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float m = wave_max64(l15 == g ? mloc : -1e30f);
+    if (owns_cur) m = __builtin_fmaxf(m, scur[g]);
+    if (lane == 0) red[g * DEC_WAVES + wave] = m;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float m = red[g * DEC_WAVES];
+#pragma unroll
+    for (int w = 1; w < DEC_WAVES; ++w) m = __builtin_fmaxf(m, red[g * DEC_WAVES + w]);
+    mblk[g] = m;
+  }
+  // p = fp16(exp(s - m)) into ph (zero padded to whole 32-token tiles), block sum of the rounded p
+  float lloc[G];
+  const int ntp = ntiles * 32;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float ls = 0.0f;
+    for (int i = tid; i < ntp; i += DEC_THREADS) {
+      const half_t e = i < nt ? (half_t)__expf(scores[g * sstride + i] - mblk[g]) : (half_t)0.0f;
+      ph[g * sstride + i] = e;
+      ls += (float)e;
+    }
+    lloc[g] = wave_sum64(ls);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+    if (lane == 0) red[g * DEC_WAVES + wave] = lloc[g];
+  __syncthreads();
+  float lblk[G], pcur[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float l = red[g * DEC_WAVES];
+#pragma unroll
+    for (int w = 1; w < DEC_WAVES; ++w) l += red[g * DEC_WAVES + w];
+    pcur[g] = owns_cur ? __expf(scur[g] - mblk[g]) : 0.0f;
+    lblk[g] = l + pcur[g];
+  }
+
+  // ---- pass 2: O^T = V^T . P^T on MFMA (V through LDS, transposed read) ----------------------------------
+  v4f oacc[8];   // block c: rows = column positions c*16 + 4*l4 + r of the V tile, col = head l15
+#pragma unroll
+  for (int c = 0; c < 8; ++c) oacc[c] = (v4f){0.f, 0.f, 0.f, 0.f};
+  {
+    uint8_t* vt = vtile + wave * VTILE;
+    const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
+    const size_t vhead_off = (size_t)hk * lay.tpb * ROW_BYTES + vpiece * 16;
+    // transposed-read address of this lane inside a 16-dim column block: row (l15>>2) of the 4-token
+    // block owned by lane group l4, halves [4*(l15&3), +4)
+    const int tr_off = (4 * l4 + (l15 >> 2)) * VROW + (l15 & 3) * 8;
+    for (int tl0 = wave; tl0 < ntiles; tl0 += DEC_WAVES * MF_UT) {
+      uint4 raw[MF_UT][2];
+      half_t sc[MF_UT][2], ze[MF_UT][2];
+#pragma unroll
+      for (int u = 0; u < MF_UT; ++u)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ti = (tl0 + u * DEC_WAVES) * 32 + h * 16 + vtok;
+          const int tok = ti < nt ? t0 + ti : t0;
+          const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[40 + (tok >> lay.tpb_log2) - page0]);
+          const int slot = tok & (lay.tpb - 1);
+          raw[u][h] = *reinterpret_cast<const uint4*>(pg + vhead_off + (size_t)slot * ROW_BYTES);
+          const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
+          sc[u][h] = tail[0];
+          ze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
+        }
+#pragma unroll
+      for (int u = 0; u < MF_UT; ++u) {
+        const int tbase = (tl0 + u * DEC_WAVES) * 32;
+        if (tbase >= ntp) continue;  // wave-uniform
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const half_t ch = (half_t)(-(float)sc[u][h] * (float)ze[u][h]);
+          v2h vd[16];
+          kv4_dequant16(raw[u][h], (v2h){sc[u][h], sc[u][h]}, (v2h){ch, ch}, vd);
+          uint8_t* dst = vt + (h * 16 + vtok) * VROW + vpiece * 64;   // 32 values in dequant order
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const v8h t = {vd[4 * w][0], vd[4 * w][1], vd[4 * w + 1][0], vd[4 * w + 1][1],
+                           vd[4 * w + 2][0], vd[4 * w + 2][1], vd[4 * w + 3][0], vd[4 * w + 3][1]};
+            *reinterpret_cast<v8h*>(dst + w * 16) = t;
+          }
+        }
+        // B operand: P[head jh][tokens tbase + 4*l4 + (0..3), tbase + 16 + 4*l4 + (0..3)]
+        typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
+        const v4h_t p0 = *reinterpret_cast<const v4h_t*>(ph + jh * sstride + tbase + 4 * l4);
+        const v4h_t p1 = *reinterpret_cast<const v4h_t*>(ph + jh * sstride + tbase + 16 + 4 * l4);
+        const v8h pb = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const uint8_t* src = vt + tr_off + c * 32;
+          const v4hp lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) v4hp*)(__attribute__((address_space(3))) void*)(src));
+          const v4hp hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) v4hp*)(__attribute__((address_space(3))) void*)(src + 16 * VROW));
+          const v8h a = {(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
+                         (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+          oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb, oacc[c], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- reduce O across the 4 waves via LDS, un-permute the columns, normalise / emit partials --------------
+  if (l15 < G) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      *reinterpret_cast<v4f*>(xbuf + ((size_t)wave * G + l15) * DH + c * 16 + 4 * l4) = oacc[c];
+  }
+  __syncthreads();
+  for (int oi = tid; oi < G * DH; oi += DEC_THREADS) {
+    const int g = oi >> 7, qpos = oi & 127;
+    const int d = unperm_pos(qpos);
+    float acc = 0.0f;
+#pragma unroll
+    for (int w = 0; w < DEC_WAVES; ++w) acc += xbuf[((size_t)w * G + g) * DH + qpos];
+    if (owns_cur) acc += pcur[g] * (float)vcur[d];
+    if constexpr (DIRECT) {
+      p.out[((size_t)b * p.num_heads + hq0 + g) * DH + d] = (half_t)(acc * (1.0f / (lblk[g] + 1e-6f)));
+    } else {
+      const size_t pi = ((size_t)b * p.num_heads + hq0 + g) * p.nsplit + split;
+      p.part_o[pi * DH + d] = acc;
+      if (qpos == 0) {
+        p.part_ml[pi * 2 + 0] = mblk[g];
+        p.part_ml[pi * 2 + 1] = lblk[g];
+      }
+    }
+  }
+
+  // ---- append the current token (quantised) to the cache ------------------------------------------
+  if (owns_cur && sub == 0 && wave < 2) {
+    const half_t* src = wave == 0 ? kcur : vcur;
+    const int64_t* tab = wave == 0 ? ktab : vtab;
+    const float x0 = (float)src[lane], x1 = (float)src[64 + lane];
+    const float mx = wave_max64(__builtin_fmaxf(x0, x1));
+    const float mn = -wave_max64(-__builtin_fminf(x0, x1));
+    const float range = mx - mn;
+    const half_t scale_h = (half_t)(range / 15.0f);
+    const float nm = -15.0f * mn;
+    const half_t zero_h = (half_t)(nm / range);
+    const float inv = 1.0f / (float)scale_h, z = (float)zero_h;
+    uint8_t* pg = reinterpret_cast<uint8_t*>(tab[tlen >> lay.tpb_log2]);
+    const int slot = tlen & (lay.tpb - 1);
+    uint8_t* dst = pg + ((size_t)hk * lay.tpb + slot) * ROW_BYTES;
+    const uint32_t c0 = kv4_code(x0, inv, z), c1 = kv4_code(x1, inv, z);
+    const uint32_t n0 = __shfl_down(c0, 1, 64), n1 = __shfl_down(c1, 1, 64);
+    if ((lane & 1) == 0) {
+      dst[lane >> 1] = (uint8_t)(c0 | (n0 << 4));
+      dst[32 + (lane >> 1)] = (uint8_t)(c1 | (n1 << 4));
+    }
+    if (lane == 0) {
+      half_t* scp = reinterpret_cast<half_t*>(pg + lay.bytes_per_seq) + hk * lay.tpb + slot;
+      scp[0] = scale_h;
+      scp[lay.num_kv_heads * lay.tpb] = zero_h;
+    }
+  }
+}
+
 // merge the per-split partials: out = sum_s e^{m_s-M} O_s / (sum_s e^{m_s-M} l_s + 1e-6)
 __global__ __launch_bounds__(128) void kv4_decode_merge_kernel(half_t* __restrict__ out,
                                                                 const float* __restrict__ part_ml,
@@ -538,9 +858,11 @@ __global__ __launch_bounds__(128) void kv4_decode_merge_kernel(half_t* __restric
 struct DecodePlan {
   int nsplit, split_tokens, g;
   size_t lds_bytes;
+  bool mfma;
 };
 
 static int g_override_nsplit = 0;
+static int g_use_valu_kernel = 0;   // tuning / A-B hook: 1 = the VALU kernel (kv4_decode_kernel)
 
 static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int max_context) {
   DecodePlan pl;
@@ -563,8 +885,13 @@ static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int ma
   }
   pl.nsplit = s;
   pl.split_tokens = st;
-  pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * 64 * (pl.g * 2) * 4 +
-                 (size_t)pl.g * (st + 16) * 4;
+  pl.mfma = !g_use_valu_kernel;
+  if (pl.mfma)
+    pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * pl.g * DH * 4 +
+                   (size_t)DEC_WAVES * VTILE + (size_t)pl.g * (st + 32) * 6;
+  else
+    pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * 64 * (pl.g * 2) * 4 +
+                   (size_t)pl.g * (st + 16) * 4;
   return pl;
 }
 
@@ -604,7 +931,12 @@ extern "C" int omni_kv4_prefill_write(void* qkv_f16, const void* seq_lens_i32,
   return omni_launch_status();
 }
 
-extern "C" void omni_kv4_decode_set_split_override(int nsplit) { omni::g_override_nsplit = nsplit; }
+extern "C" void omni_kv4_decode_set_split_override(int nsplit) {
+  // nsplit >= 0: force the KV split count (0 = heuristic); nsplit = -1 / -2: select the VALU / MFMA kernel
+  if (nsplit == -1) omni::g_use_valu_kernel = 1;
+  else if (nsplit == -2) omni::g_use_valu_kernel = 0;
+  else omni::g_override_nsplit = nsplit;
+}
 
 extern "C" size_t omni_kv4_decode_workspace_bytes(int batch, int num_heads, int head_dim, int max_context) {
   (void)head_dim;
@@ -647,10 +979,17 @@ extern "C" int omni_kv4_decode_attention(void* out_f16, const void* q_f16, const
   if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;  // context beyond 64 splits x 2048 tokens
 #define OMNI_LAUNCH_DEC(G_, D_)                                                                       \
   do {                                                                                                \
-    if (pl.lds_bytes > 64 * 1024)                                                                     \
-      (void)hipFuncSetAttribute((const void*)kv4_decode_kernel<G_, D_>,                               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);      \
-    hipLaunchKernelGGL((kv4_decode_kernel<G_, D_>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a);    \
+    if (pl.mfma) {                                                                                    \
+      if (pl.lds_bytes > 64 * 1024)                                                                   \
+        (void)hipFuncSetAttribute((const void*)kv4_decode_mfma_kernel<G_, D_>,                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);    \
+      hipLaunchKernelGGL((kv4_decode_mfma_kernel<G_, D_>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); \
+    } else {                                                                                          \
+      if (pl.lds_bytes > 64 * 1024)                                                                   \
+        (void)hipFuncSetAttribute((const void*)kv4_decode_kernel<G_, D_>,                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);    \
+      hipLaunchKernelGGL((kv4_decode_kernel<G_, D_>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a);  \
+    }                                                                                                 \
   } while (0)
   if (pl.nsplit == 1) {
     switch (pl.g) {
