@@ -97,7 +97,7 @@ def cpu_baseline(cfg, batch):
     (unpack once, untimed; timed: torch._int_mm + the fp32 epilogue), extrapolated to a step."""
     import numpy as np
     from oracle import w4a8
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)   # oneDNN int8 at M=32 does not scale past a few cores
     torch.set_num_threads(cores)
     shapes = [((cfg.heads + 2 * cfg.kv_heads) * cfg.head_dim, cfg.hidden), (cfg.hidden, cfg.hidden),
               (2 * cfg.inter, cfg.hidden), (cfg.hidden, cfg.inter)]
@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--group-size", type=int, default=-1)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="reference call sequence (no fused extension kernels)")
+    ap.add_argument("--fused-level", type=int, default=2, help="0 reference sequence, 1 fused add+norm / silu+quant, 2 + deferred split-K epilogue")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / gemm_4096 legs")
     args = ap.parse_args()
 
@@ -159,7 +160,7 @@ def main():
     from omniserve_amd.runtime import DecodeRunner, LlamaConfig
     cfg = LlamaConfig.llama3_8b(args.group_size)
     runner = DecodeRunner(cfg, args.batch, args.context, args.steps + args.warmup + 4, device,
-                          seed=1234 + rank, use_graph=not args.no_graph, fused=not args.no_fused)
+                          seed=1234 + rank, use_graph=not args.no_graph, fused=0 if args.no_fused else args.fused_level)
     for _ in range(args.warmup):
         runner.step()
     torch.cuda.synchronize()
@@ -196,7 +197,7 @@ def main():
                        args.context, "BASELINE.json configs[1]" if args.group_size == -1 else "configs[2]-like"),
                    "batch_per_gpu": args.batch, "context": args.context, "layers": cfg.layers,
                    "parallelism": "replicas x%d (no collective)" % world if world > 1 else "single GPU",
-                   "hip_graph": not args.no_graph, "fused_ext_kernels": not args.no_fused,
+                   "hip_graph": not args.no_graph, "fused_ext_level": runner.fused,
                    "gemm_weight_bytes_per_step": runner.gemm_weight_bytes_per_step(),
                    "kv_bytes_per_step": runner.kv_bytes_per_step(args.context)},
     }

@@ -118,6 +118,20 @@ int omni_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const v
                                        const void* weight_f16, void* sum_f16, void* scale_f16,
                                        float eps, int tokens, int hidden, void* stream);
 
+/* Deferred split-K epilogue for decode shapes (M <= 128): omni_w4a8_per_chn_gemm_partial writes only the
+ * int32 partial sums slab[sk][M][N] (*sk_out = number of slabs, host int), and
+ * omni_splitk_add_rms_norm_general_fuse_sum consumes them:
+ *   residual += fp16( epilogue( sum_k slab[k] ) )   -- exactly omni_w4a8_per_chn_gemm's output, then
+ *   omni_rms_norm_general_fuse_sum(residual).  ascales_in / a_ssums_in are the scales and sums of
+ * the GEMM's int8 input (they must not alias the sum / scale outputs). */
+int omni_w4a8_per_chn_gemm_partial(const void* in_feats, const void* qweight, void* slab_i32,
+                                   size_t slab_bytes, int M, int N, int K, int* sk_out, void* stream);
+int omni_splitk_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const void* slab_i32, int sk,
+                                              const void* wscales_f16, const void* ascales_in_f16,
+                                              const void* w_szs_f16, const void* a_ssums_in_f16,
+                                              const void* weight_f16, void* sum_f16, void* scale_f16,
+                                              float eps, int tokens, int hidden, void* stream);
+
 /* omni_silu_and_mul followed by omni_quant_fuse_sum without materialising the fp16 product
  * (activation.py:54-64 calls them back to back).  in fp16 [tokens, 2d] -> out int8 [tokens, d]. */
 int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f16, void* scale_f16,

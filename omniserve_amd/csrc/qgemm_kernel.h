@@ -608,5 +608,25 @@ static int launch_gemm(GemmArgs a, void* ws, size_t ws_bytes, hipStream_t st) {
   return omni_launch_status();
 }
 
+// Deferred-epilogue variant (fused extension): only the int32 split-K slabs are produced; the consumer
+// kernel (omni_splitk_add_rms_norm_general_fuse_sum) reduces them and applies the epilogue.
+template <int MODE>
+static int launch_gemm_partial(GemmArgs a, void* slab, size_t slab_bytes, int* sk_out, hipStream_t st) {
+  if (a.M < 1 || a.M > 128 || a.N % 64 != 0 || a.K % 64 != 0 || a.K < 64 || !slab || !sk_out) return OMNI_EINVAL;
+  if (MODE == MODE_GRP && a.K % 128 != 0) return OMNI_EINVAL;
+  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64);
+  if (slab_bytes < (size_t)pl.sk * a.M * a.N * sizeof(int32_t)) return OMNI_ENOMEM;
+  a.slab = static_cast<int32_t*>(slab);
+  a.kslice = pl.kslice;
+  switch (pl.mb) {
+    case 1: { constexpr int W = GemvCfg<1, MODE>::WAVES; hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, true>), dim3((a.N / 64 + W - 1) / W, pl.sk), dim3(64 * W), 0, st, a); } break;
+    case 2: { constexpr int W = GemvCfg<2, MODE>::WAVES; hipLaunchKernelGGL((w4a8_gemv_kernel<2, MODE, true>), dim3((a.N / 64 + W - 1) / W, pl.sk), dim3(64 * W), 0, st, a); } break;
+    case 4: { constexpr int W = GemvCfg<4, MODE>::WAVES; hipLaunchKernelGGL((w4a8_gemv_kernel<4, MODE, true>), dim3((a.N / 64 + W - 1) / W, pl.sk), dim3(64 * W), 0, st, a); } break;
+    default: { constexpr int W = GemvCfg<8, MODE>::WAVES; hipLaunchKernelGGL((w4a8_gemv_kernel<8, MODE, true>), dim3((a.N / 64 + W - 1) / W, pl.sk), dim3(64 * W), 0, st, a); } break;
+  }
+  *sk_out = pl.sk;
+  return omni_launch_status();
+}
+
 }  // namespace omni
 

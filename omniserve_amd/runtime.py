@@ -85,9 +85,13 @@ class DecodeRunner:
     def __init__(self, cfg: LlamaConfig, batch: int, context: int, max_new: int, device, seed=0,
                  use_graph=True, fused=True):
         self.cfg, self.B, self.device = cfg, batch, device
-        # fused=True uses the opt-in fused entry points (residual add + norm + quant, silu*mul + quant;
-        # bit-identical to the reference call sequence); False = the reference sequence
-        self.fused = fused
+        # fused: 0/False = the reference call sequence; 1 = opt-in fused entry points (residual add +
+        # norm + quant, silu*mul + quant); 2/True = additionally defer the split-K epilogue of o_proj /
+        # down_proj into the following add+norm kernel.  All bit-identical to the reference sequence
+        # (SURVEY.md 8f.1).
+        self.fused = 2 if fused is True else int(fused)
+        if cfg.group_size != -1 and self.fused > 1:
+            self.fused = 1   # the deferred epilogue exists for the per-channel GEMM only
         c = cfg
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
@@ -138,8 +142,11 @@ class DecodeRunner:
         self._q_hidden = torch.empty((B, c.hidden), dtype=i8, device=device)
         self._q_inter = torch.empty((B, c.inter), dtype=i8, device=device)
         self._q_attn = torch.empty((B, c.heads * c.head_dim), dtype=i8, device=device)
-        self.act_scale = torch.empty((B,), dtype=f16, device=device)
+        self.act_scale = torch.empty((B,), dtype=f16, device=device)   # written by norm kernels
         self.act_sum = torch.empty((B,), dtype=f16, device=device)
+        self.act_scale2 = torch.empty((B,), dtype=f16, device=device)  # written by quant kernels
+        self.act_sum2 = torch.empty((B,), dtype=f16, device=device)
+        self.slab = torch.empty((16 << 20,), dtype=torch.uint8, device=device)  # deferred split-K partial sums
         self.qkv_buf = torch.empty((B, qkv_n), dtype=f16, device=device)
         self.proj_buf = torch.empty((B, c.hidden), dtype=f16, device=device)
         self.gate_up_buf = torch.empty((B, 2 * c.inter), dtype=f16, device=device)
@@ -182,37 +189,52 @@ class DecodeRunner:
         torch.index_select(self.embed, 0, self.tokens, out=self.x)
         B = self.B
         hq, hk, d = c.heads, c.kv_heads, c.head_dim
+        sA, mA = self.act_scale2, self.act_sum2   # scales / sums produced by quant-type kernels
+        sB, mB = self.act_scale, self.act_sum     # ... by norm kernels
+        pending = None                             # (sk, linear) of a down_proj whose epilogue is deferred
+        nl = len(self.layers)
         for li, L in enumerate(self.layers):
             qa_h, qa_i = self._q_hidden, self._q_inter
-            if self.fused and li > 0:   # residual += down_proj(prev layer), then norm + quant
-                fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln1"], self.act_sum,
-                                                        self.act_scale, c.eps)
+            if pending is not None:     # residual += down_proj(prev layer) [deferred epilogue], norm + quant
+                sk, lin = pending
+                fused_ext.splitk_add_rms_norm_general_fuse_sum(qa_h, self.x, self.slab, sk, lin.s1_scales, sA,
+                                                               lin.s1_szeros, mA, L["ln1"], mB, sB, c.eps)
+                pending = None
+            elif self.fused and li > 0:
+                fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln1"], mB, sB, c.eps)
             else:
-                layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln1"], self.act_sum, self.act_scale, c.eps, True)
-            L["qkv"].forward(qa_h, self.act_scale, self.act_sum, self.qkv_buf)
+                layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln1"], mB, sB, c.eps, True)
+            L["qkv"].forward(qa_h, sB, mB, self.qkv_buf)
             q = self.qkv_buf[:, : hq * d].view(B, hq, d)
             k = self.qkv_buf[:, hq * d:(hq + hk) * d].view(B, hk, d)
             v = self.qkv_buf[:, (hq + hk) * d:].view(B, hk, d)
             attn = fused_attention_pure_dense.single_query_attention(
                 q, k, v, self.block_tables[li], self.lengths, None, 65536, self.tpb, hk * d // 2,
                 self.max_context, d, c.rope_theta, True, True, True)
-            fused_kernels.invoke_quant_fuse_sum(self._q_attn, attn.view(B, hq * d), self.act_sum, self.act_scale)
-            L["o"].forward(self._q_attn, self.act_scale, self.act_sum, self.proj_buf)
-            if self.fused:
-                fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln2"], self.act_sum,
-                                                        self.act_scale, c.eps)
+            fused_kernels.invoke_quant_fuse_sum(self._q_attn, attn.view(B, hq * d), mA, sA)
+            if self.fused >= 2:
+                sk = fused_ext.gemm_partial_per_chn(self._q_attn, L["o"].qweight, self.slab)
+                fused_ext.splitk_add_rms_norm_general_fuse_sum(qa_h, self.x, self.slab, sk, L["o"].s1_scales, sA,
+                                                               L["o"].s1_szeros, mA, L["ln2"], mB, sB, c.eps)
             else:
-                self.x.add_(self.proj_buf)
-                layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln2"], self.act_sum, self.act_scale, c.eps, True)
-            L["gate_up"].forward(qa_h, self.act_scale, self.act_sum, self.gate_up_buf)
+                L["o"].forward(self._q_attn, sA, mA, self.proj_buf)
+                if self.fused:
+                    fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln2"], mB, sB, c.eps)
+                else:
+                    self.x.add_(self.proj_buf)
+                    layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln2"], mB, sB, c.eps, True)
+            L["gate_up"].forward(qa_h, sB, mB, self.gate_up_buf)
             if self.fused:
-                fused_ext.silu_mul_quant_fuse_sum(qa_i, self.gate_up_buf, self.act_sum, self.act_scale)
+                fused_ext.silu_mul_quant_fuse_sum(qa_i, self.gate_up_buf, mA, sA)
             else:
                 activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
-                fused_kernels.invoke_quant_fuse_sum(qa_i, self.mlp_act, self.act_sum, self.act_scale)
-            L["down"].forward(qa_i, self.act_scale, self.act_sum, self.proj_buf)
-            if not self.fused or li == len(self.layers) - 1:
-                self.x.add_(self.proj_buf)
+                fused_kernels.invoke_quant_fuse_sum(qa_i, self.mlp_act, mA, sA)
+            if self.fused >= 2 and li < nl - 1:
+                pending = (fused_ext.gemm_partial_per_chn(qa_i, L["down"].qweight, self.slab), L["down"])
+            else:
+                L["down"].forward(qa_i, sA, mA, self.proj_buf)
+                if not self.fused or li == nl - 1:
+                    self.x.add_(self.proj_buf)
         layernorm_ops.rms_norm(self.normed, self.x, self.final_norm, c.eps, False)
         logits = torch.matmul(self.normed, self.lm_head.t())
         self.tokens.copy_(torch.argmax(logits, dim=-1))

@@ -118,3 +118,42 @@ def test_fused_silu_mul_quant_matches_the_two_kernels(tokens, d):
     fused_ext.silu_mul_quant_fuse_sum(q2, x, m2, s2)
     torch.cuda.synchronize()
     assert torch.equal(q1, q2) and torch.equal(s1.view(torch.int16), s2.view(torch.int16)) and torch.equal(m1.view(torch.int16), m2.view(torch.int16))
+
+
+def test_deferred_splitk_epilogue_matches_gemm_then_add_norm():
+    """o_proj / down_proj path of the fused runner: partial GEMM + slab-consuming add+norm must equal
+    the reference sequence GEMM -> residual add -> rms_norm_general_fuse_sum bit for bit."""
+    import omniserve_backend.layernorm_ops as ln
+    import omniserve_backend.qgemm_w4a8_per_chn as gemm
+    from omniserve_amd.backend import fused_ext
+    from oracle import w4a8
+    M, N, K = 16, 4096, 4096
+    u, z, s1 = w4a8.synth_per_channel(N, K, 3)
+    qw, s1h, szh = w4a8.pack_per_channel(u, z, s1)
+    a, sa, asum = oe.quant_per_token(_x(M, K, 5, 1.0), True)
+    resid = _x(M, N, 6, 2.0)
+    g = (1.0 + 0.1 * np.random.default_rng(1).standard_normal(N)).astype(np.float16)
+    qw_d, s1_d, sz_d, a_d, sa_d, as_d, g_d = map(to_dev, (qw, s1h, szh, a, sa, asum, g))
+    # reference sequence
+    proj = torch.empty((M, N), dtype=torch.float16, device=dev())
+    gemm.gemm_forward_cuda(a_d, qw_d, s1_d, sa_d, sz_d, as_d, proj)
+    x1 = to_dev(resid); x1.add_(proj)
+    q1 = torch.empty((M, N), dtype=torch.int8, device=dev()); sc1 = torch.empty((M,), dtype=torch.float16, device=dev()); sm1 = sc1.clone()
+    ln.rms_norm_general_fuse_sum(q1, x1, g_d, sm1, sc1, 1e-5, True)
+    # deferred epilogue
+    slab = torch.empty((64 << 20,), dtype=torch.uint8, device=dev())
+    sk = fused_ext.gemm_partial_per_chn(a_d, qw_d, slab)
+    x2 = to_dev(resid)
+    q2 = torch.empty_like(q1); sc2 = torch.empty_like(sc1); sm2 = torch.empty_like(sc1)
+    fused_ext.splitk_add_rms_norm_general_fuse_sum(q2, x2, slab, sk, s1_d, sa_d, sz_d, as_d, g_d, sm2, sc2, 1e-5)
+    torch.cuda.synchronize()
+    assert sk >= 1
+    assert torch.equal(x1.view(torch.int16), x2.view(torch.int16))
+    assert torch.equal(q1, q2) and torch.equal(sc1.view(torch.int16), sc2.view(torch.int16))
+    assert torch.equal(sm1.view(torch.int16), sm2.view(torch.int16))
+    # and against the oracle
+    want = w4a8.gemm_per_chn(a, qw, s1h, sa, szh, asum)
+    xs = (resid.astype(np.float32) + want.astype(np.float32)).astype(np.float16)
+    qo, so, smo = oe.rms_norm_general(xs, g, 1e-5, True)
+    assert np.array_equal(q2.cpu().numpy(), qo)
+    assert_f16_equal(sm2, smo, "sum")
