@@ -328,7 +328,21 @@ struct SrcSlabAddChn {  // residual += h(per-channel GEMM epilogue(sum of split-
   }
   __device__ __forceinline__ void load8(int i, float (&x)[VT]) const {
     v4i s0 = (v4i){0, 0, 0, 0}, s1 = s0;
-    for (int k = 0; k < sk; ++k) {
+    {  // up to 8 slabs: all loads in flight at once (slabs beyond sk re-read slab 0 and are dropped)
+      v4i t0[8], t1[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const size_t off = (size_t)(k < sk ? k : 0) * sstride + i;
+        t0[k] = *reinterpret_cast<const v4i*>(slab + off);
+        t1[k] = *reinterpret_cast<const v4i*>(slab + off + 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s0 += k < sk ? t0[k] : (v4i){0, 0, 0, 0};
+        s1 += k < sk ? t1[k] : (v4i){0, 0, 0, 0};
+      }
+    }
+    for (int k = 8; k < sk; ++k) {
       s0 += *reinterpret_cast<const v4i*>(slab + (size_t)k * sstride + i);
       s1 += *reinterpret_cast<const v4i*>(slab + (size_t)k * sstride + i + 4);
     }
@@ -371,34 +385,72 @@ __device__ __forceinline__ void store8_i8(int8_t* dst, const float (&x)[VT], flo
   *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
 }
 
-// quant[_fuse_sum]: NV = min(hidden, 1024)
-template <int J, bool FUSE_SUM, typename Src>
-__global__ __launch_bounds__(128) void quant_v2_kernel(int8_t* __restrict__ out, Src src0,
-                                                        half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
-                                                        int hidden, int nv) {
+// Row kernels, final form: RT threads compute the element values in parallel (8 consecutive elements
+// = one 16-B access per thread and iteration) and park them as f32 in LDS; the first NV/8 threads then
+// replay the reference's per-virtual-thread accumulation ORDER from LDS (cheap: hidden/NV adds per
+// value) and run the reference reduction tree.  Heavy per-element work (silu, split-K slab sums) is
+// spread over the whole workgroup, the ordered part stays bit-identical to oracle/elementwise.py.
+constexpr int RT = 512;       // threads per row
+constexpr int RV = 4;         // 8-element vectors per thread held in registers: hidden <= 16384
+
+__device__ __forceinline__ float block_max_rt(float m, float* red) {
+  m = wave_max64(m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[64 + (threadIdx.x >> 6)] = m;
+  __syncthreads();
+  float r = red[64];
+#pragma unroll
+  for (int w = 1; w < RT / 64; ++w) r = __builtin_fmaxf(r, red[64 + w]);
+  return r;
+}
+
+// ordered per-virtual-thread accumulation of NQ quantities from the LDS copy of the row
+template <int NQ, typename F>
+__device__ __forceinline__ void ordered_partials(const float* xs, int p, int nv, int hidden, float (&v)[NQ][VT], F f) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int e = 0; e < VT; ++e) v[q][e] = 0.0f;
+  if (VT * p < nv) {
+    for (int i = VT * p; i < hidden; i += nv) {
+      const v4f a = *reinterpret_cast<const v4f*>(xs + i);
+      const v4f b = *reinterpret_cast<const v4f*>(xs + i + 4);
+#pragma unroll
+      for (int e = 0; e < VT; ++e) f(v, e, e < 4 ? a[e] : b[e - 4]);
+    }
+  }
+}
+
+// quant[_fuse_sum] (NV = min(hidden,1024)) with a pluggable source
+template <bool FUSE_SUM, typename Src>
+__global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, Src src0,
+                                                       half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
+                                                       int hidden, int nv) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // [hidden]
   __shared__ float red[96];
   const int p = threadIdx.x;
   const Src src = src0.at_row(blockIdx.x);
-  float x[J][VT];
-  float s[1][VT];
-#pragma unroll
-  for (int e = 0; e < VT; ++e) s[0][e] = 0.0f;
+  float x[RV][VT];
   float amax = 0.0f;
 #pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int i = j * nv + VT * p;
-    const bool ok = VT * p < nv && i < hidden;
-    if (ok) src.load8(i, x[j]);
+  for (int it = 0; it < RV; ++it) {
+    const int i = (p + it * RT) * VT;
+    const bool ok = i < hidden;
+    if (ok) src.load8(i, x[it]);
 #pragma unroll
     for (int e = 0; e < VT; ++e) {
-      x[j][e] = ok ? x[j][e] : 0.0f;
-      if constexpr (FUSE_SUM) s[0][e] = ok ? s[0][e] + x[j][e] : s[0][e];
-      amax = __builtin_fmaxf(amax, __builtin_fabsf(x[j][e]));
+      x[it][e] = ok ? x[it][e] : 0.0f;
+      amax = __builtin_fmaxf(amax, __builtin_fabsf(x[it][e]));
+    }
+    if (FUSE_SUM && ok) {
+      *reinterpret_cast<v4f*>(xs + i) = (v4f){x[it][0], x[it][1], x[it][2], x[it][3]};
+      *reinterpret_cast<v4f*>(xs + i + 4) = (v4f){x[it][4], x[it][5], x[it][6], x[it][7]};
     }
   }
-  amax = block_max_small(amax, red);
+  amax = block_max_rt(amax, red);   // (its barriers also publish xs)
   if constexpr (FUSE_SUM) {
-    float tot[1];
+    float s[1][VT], tot[1];
+    ordered_partials<1>(xs, p, nv, hidden, s, [](float (&v)[1][VT], int e, float val) { v[0][e] = v[0][e] + val; });
     tree_sum8<1>(s, red, p, nv >> 5, tot);
     if (p == 0) sum_out[blockIdx.x] = (half_t)tot[0];
   }
@@ -406,63 +458,69 @@ __global__ __launch_bounds__(128) void quant_v2_kernel(int8_t* __restrict__ out,
   const float q = 127.0f / amax;
   int8_t* orow = out + (size_t)blockIdx.x * hidden;
 #pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int i = j * nv + VT * p;
-    if (VT * p < nv && i < hidden) store8_i8(orow + i, x[j], q);
+  for (int it = 0; it < RV; ++it) {
+    const int i = (p + it * RT) * VT;
+    if (i < hidden) store8_i8(orow + i, x[it], q);
   }
 }
 
 // rms_norm_general[_fuse_sum] (+ fused residual sources): NV = roundup32(min(hidden,1024))
-template <int J, bool FUSE_SUM, typename Src>
-__global__ __launch_bounds__(128) void general_norm_v2_kernel(int8_t* __restrict__ out, Src src0, const half_t* __restrict__ gamma,
-                                                               half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
-                                                               float eps, int hidden, int nv) {
+template <bool FUSE_SUM, typename Src>
+__global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict__ out, Src src0, const half_t* __restrict__ gamma,
+                                                              half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
+                                                              float eps, int hidden, int nv) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // [hidden]
   __shared__ float red[96];
   const int p = threadIdx.x;
   const Src src = src0.at_row(blockIdx.x);
-  float x[J][VT];
-  float st[2][VT];
+  float x[RV][VT];
 #pragma unroll
-  for (int e = 0; e < VT; ++e) { st[0][e] = 0.0f; st[1][e] = 0.0f; }
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int i = j * nv + VT * p;
-    const bool ok = VT * p < nv && i < hidden;
-    if (ok) src.load8(i, x[j]);
-#pragma unroll
-    for (int e = 0; e < VT; ++e) {
-      x[j][e] = ok ? x[j][e] : 0.0f;
-      st[0][e] = ok ? st[0][e] + x[j][e] : st[0][e];
-      st[1][e] = ok ? st[1][e] + x[j][e] * x[j][e] : st[1][e];
+  for (int it = 0; it < RV; ++it) {
+    const int i = (p + it * RT) * VT;
+    const bool ok = i < hidden;
+    if (ok) {
+      src.load8(i, x[it]);
+      *reinterpret_cast<v4f*>(xs + i) = (v4f){x[it][0], x[it][1], x[it][2], x[it][3]};
+      *reinterpret_cast<v4f*>(xs + i + 4) = (v4f){x[it][4], x[it][5], x[it][6], x[it][7]};
     }
   }
-  float tv[2];
-  tree_sum8<2>(st, red, p, nv >> 5, tv);
+  __syncthreads();
+  float st[2][VT], tv[2];
+  ordered_partials<2>(xs, p, nv, hidden, st, [](float (&v)[2][VT], int e, float val) {
+    v[0][e] = v[0][e] + val;
+    v[1][e] = v[1][e] + val * val;
+  });
+  tree_sum8<2>(st, red, p, nv >> 5, tv);   // first barrier inside: everyone is done reading xs
   const float mean = tv[0] / (float)hidden;
   const float rstd = 1.0f / __builtin_sqrtf(tv[1] / (float)hidden + eps);
   float amax_h = (float)(half_t)1e-6f;
-  float hs[1][VT];
 #pragma unroll
-  for (int e = 0; e < VT; ++e) hs[0][e] = 0.0f;
+  for (int it = 0; it < RV; ++it) {
+    const int i = (p + it * RT) * VT;
+    const bool ok = i < hidden;
+    if (ok) {
+      const v8h g8 = *reinterpret_cast<const v8h*>(gamma + i);
+      float yh[VT];
 #pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int i = j * nv + VT * p;
-    const bool ok = VT * p < nv && i < hidden;
-    v8h g8 = {};
-    if (ok) g8 = *reinterpret_cast<const v8h*>(gamma + i);
-#pragma unroll
-    for (int e = 0; e < VT; ++e) {
-      float y = (x[j][e] - mean) * rstd;
-      y = rounded_f32(y * (float)g8[e]);
-      x[j][e] = y;
-      const float yh = ok ? (float)(half_t)y : 0.0f;
-      amax_h = __builtin_fmaxf(amax_h, __builtin_fabsf(yh));
-      if constexpr (FUSE_SUM) hs[0][e] = ok ? (float)(half_t)(hs[0][e] + yh) : hs[0][e];
+      for (int e = 0; e < VT; ++e) {
+        float y = (x[it][e] - mean) * rstd;
+        y = rounded_f32(y * (float)g8[e]);
+        x[it][e] = y;
+        yh[e] = (float)(half_t)y;
+        amax_h = __builtin_fmaxf(amax_h, __builtin_fabsf(yh[e]));
+      }
+      if constexpr (FUSE_SUM) {
+        *reinterpret_cast<v4f*>(xs + i) = (v4f){yh[0], yh[1], yh[2], yh[3]};
+        *reinterpret_cast<v4f*>(xs + i + 4) = (v4f){yh[4], yh[5], yh[6], yh[7]};
+      }
     }
   }
-  const float amax = block_max_small(amax_h, red);
+  const float amax = block_max_rt(amax_h, red);   // barriers publish the fp16-rounded y in xs
   if constexpr (FUSE_SUM) {
-    float tot[1];
+    float hs[1][VT], tot[1];
+    ordered_partials<1>(xs, p, nv, hidden, hs, [](float (&v)[1][VT], int e, float val) {
+      v[0][e] = (float)(half_t)(v[0][e] + val);   // the reference accumulates this sum in fp16
+    });
     tree_sum8<1>(hs, red, p, nv >> 5, tot);
     if (p == 0) sum_out[blockIdx.x] = (half_t)tot[0];
   }
@@ -470,47 +528,44 @@ __global__ __launch_bounds__(128) void general_norm_v2_kernel(int8_t* __restrict
   const float q = 127.0f / amax;
   int8_t* orow = out + (size_t)blockIdx.x * hidden;
 #pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int i = j * nv + VT * p;
-    if (VT * p < nv && i < hidden) store8_i8(orow + i, x[j], q);
+  for (int it = 0; it < RV; ++it) {
+    const int i = (p + it * RT) * VT;
+    if (i < hidden) store8_i8(orow + i, x[it], q);
   }
 }
 
 // rms_norm (fp16 out): NV = min(hidden,1024)
-template <int J>
-__global__ __launch_bounds__(128) void rms_norm_v2_kernel(half_t* __restrict__ out, const half_t* __restrict__ in,
-                                                           const half_t* __restrict__ weight, float eps, int hidden, int nv) {
+__global__ __launch_bounds__(RT) void rms_norm_v2_kernel(half_t* __restrict__ out, const half_t* __restrict__ in,
+                                                          const half_t* __restrict__ weight, float eps, int hidden, int nv) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
   __shared__ float red[96];
   const int p = threadIdx.x;
   const SrcPlain src{in + (size_t)blockIdx.x * hidden, hidden};
-  float x[J][VT];
-  float st[1][VT];
+  float x[RV][VT];
 #pragma unroll
-  for (int e = 0; e < VT; ++e) st[0][e] = 0.0f;
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int i = j * nv + VT * p;
-    const bool ok = VT * p < nv && i < hidden;
-    if (ok) src.load8(i, x[j]);
-#pragma unroll
-    for (int e = 0; e < VT; ++e) {
-      x[j][e] = ok ? x[j][e] : 0.0f;
-      st[0][e] = ok ? st[0][e] + x[j][e] * x[j][e] : st[0][e];
+  for (int it = 0; it < RV; ++it) {
+    const int i = (p + it * RT) * VT;
+    if (i < hidden) {
+      src.load8(i, x[it]);
+      *reinterpret_cast<v4f*>(xs + i) = (v4f){x[it][0], x[it][1], x[it][2], x[it][3]};
+      *reinterpret_cast<v4f*>(xs + i + 4) = (v4f){x[it][4], x[it][5], x[it][6], x[it][7]};
     }
   }
-  float tv[1];
+  __syncthreads();
+  float st[1][VT], tv[1];
+  ordered_partials<1>(xs, p, nv, hidden, st, [](float (&v)[1][VT], int e, float val) { v[0][e] = v[0][e] + val * val; });
   tree_sum8<1>(st, red, p, nv >> 5, tv);
   const float rstd = 1.0f / __builtin_sqrtf(tv[0] / (float)hidden + eps);
   half_t* orow = out + (size_t)blockIdx.x * hidden;
 #pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int i = j * nv + VT * p;
-    if (VT * p < nv && i < hidden) {
+  for (int it = 0; it < RV; ++it) {
+    const int i = (p + it * RT) * VT;
+    if (i < hidden) {
       const v8h w8 = *reinterpret_cast<const v8h*>(weight + i);
       v8h o;
 #pragma unroll
       for (int e = 0; e < VT; ++e) {
-        const half_t t = (half_t)rounded_f32(x[j][e] * rstd);
+        const half_t t = (half_t)rounded_f32(x[it][e] * rstd);
         o[e] = (half_t)((float)t * (float)w8[e]);
       }
       *reinterpret_cast<v8h*>(orow + i) = o;
@@ -519,21 +574,11 @@ __global__ __launch_bounds__(128) void rms_norm_v2_kernel(half_t* __restrict__ o
 }
 
 // dispatch helpers ------------------------------------------------------------------------------------
-static inline bool v2_ok(int hidden, int nv) { return hidden % 8 == 0 && nv % 32 == 0 && hidden <= 16 * nv; }
-static inline int v2_chunks(int hidden, int nv) {
-  const int need = (hidden + nv - 1) / nv;
-  return need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 8 ? 8 : 16)));
+static inline bool v2_ok(int hidden, int nv) {
+  return hidden % 8 == 0 && nv % 32 == 0 && nv <= 1024 && hidden <= RT * RV * VT && (size_t)hidden * 4 <= 64 * 1024;
 }
-static inline dim3 v2_block(int nv) { return dim3(((nv / 8) + 63) / 64 * 64); }
-
-#define OMNI_V2_DISPATCH_J(J_, CALL)            \
-  switch (J_) {                                 \
-    case 1: { constexpr int J = 1; CALL; } break;   \
-    case 2: { constexpr int J = 2; CALL; } break;   \
-    case 4: { constexpr int J = 4; CALL; } break;   \
-    case 8: { constexpr int J = 8; CALL; } break;   \
-    default: { constexpr int J = 16; CALL; } break; \
-  }
+#define OMNI_V2_LAUNCH(KERNEL, tokens, hidden, ...) \
+  hipLaunchKernelGGL(KERNEL, dim3(tokens), dim3(RT), (size_t)(hidden) * sizeof(float), (hipStream_t)stream, __VA_ARGS__)
 
 static inline int norm_block(int hidden, bool round32) {
   int b = hidden < NT_MAX ? hidden : NT_MAX;
@@ -552,10 +597,8 @@ extern "C" int omni_quant(void* out_i8, const void* in_f16, void* scale_f16, int
   if (tokens == 0) return OMNI_OK;
   const int nv = norm_block(hidden, false);
   if (v2_ok(hidden, nv)) {
-    OMNI_V2_DISPATCH_J(v2_chunks(hidden, nv),
-                       hipLaunchKernelGGL((quant_v2_kernel<J, false, SrcPlain>), dim3(tokens), v2_block(nv), 0,
-                                          (hipStream_t)stream, (int8_t*)out_i8, SrcPlain{(const half_t*)in_f16, hidden},
-                                          (half_t*)nullptr, (half_t*)scale_f16, hidden, nv));
+    OMNI_V2_LAUNCH((quant_v2_kernel<false, SrcPlain>), tokens, 8, (int8_t*)out_i8, SrcPlain{(const half_t*)in_f16, hidden},
+                   (half_t*)nullptr, (half_t*)scale_f16, hidden, nv);
     return omni_launch_status();
   }
   hipLaunchKernelGGL((quant_kernel<false>), dim3(tokens), dim3(norm_block(hidden, false)), 0,
@@ -571,10 +614,8 @@ extern "C" int omni_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f
   if (tokens == 0) return OMNI_OK;
   const int nv = norm_block(hidden, false);
   if (v2_ok(hidden, nv)) {
-    OMNI_V2_DISPATCH_J(v2_chunks(hidden, nv),
-                       hipLaunchKernelGGL((quant_v2_kernel<J, true, SrcPlain>), dim3(tokens), v2_block(nv), 0,
-                                          (hipStream_t)stream, (int8_t*)out_i8, SrcPlain{(const half_t*)in_f16, hidden},
-                                          (half_t*)sum_f16, (half_t*)scale_f16, hidden, nv));
+    OMNI_V2_LAUNCH((quant_v2_kernel<true, SrcPlain>), tokens, hidden, (int8_t*)out_i8, SrcPlain{(const half_t*)in_f16, hidden},
+                   (half_t*)sum_f16, (half_t*)scale_f16, hidden, nv);
     return omni_launch_status();
   }
   hipLaunchKernelGGL((quant_kernel<true>), dim3(tokens), dim3(norm_block(hidden, false)), 0,
@@ -591,10 +632,8 @@ extern "C" int omni_rms_norm(void* out_f16, const void* in_f16, const void* weig
   {
     const int nv = norm_block(hidden, false);
     if (v2_ok(hidden, nv)) {
-      OMNI_V2_DISPATCH_J(v2_chunks(hidden, nv),
-                         hipLaunchKernelGGL((rms_norm_v2_kernel<J>), dim3(tokens), v2_block(nv), 0, (hipStream_t)stream,
-                                            (half_t*)out_f16, (const half_t*)in_f16, (const half_t*)weight_f16, eps,
-                                            hidden, nv));
+      OMNI_V2_LAUNCH(rms_norm_v2_kernel, tokens, hidden, (half_t*)out_f16, (const half_t*)in_f16,
+                     (const half_t*)weight_f16, eps, hidden, nv);
       return omni_launch_status();
     }
   }
@@ -613,10 +652,9 @@ extern "C" int omni_rms_norm_general(void* out_i8, const void* in_f16, const voi
   {
     const int nv = norm_block(hidden, true);
     if (v2_ok(hidden, nv)) {
-      OMNI_V2_DISPATCH_J(v2_chunks(hidden, nv),
-                         hipLaunchKernelGGL((general_norm_v2_kernel<J, false, SrcPlain>), dim3(tokens), v2_block(nv), 0,
-                                            (hipStream_t)stream, (int8_t*)out_i8, SrcPlain{(const half_t*)in_f16, hidden},
-                                            (const half_t*)weight_f16, (half_t*)nullptr, (half_t*)scale_f16, eps, hidden, nv));
+      OMNI_V2_LAUNCH((general_norm_v2_kernel<false, SrcPlain>), tokens, hidden, (int8_t*)out_i8,
+                     SrcPlain{(const half_t*)in_f16, hidden}, (const half_t*)weight_f16, (half_t*)nullptr,
+                     (half_t*)scale_f16, eps, hidden, nv);
       return omni_launch_status();
     }
   }
@@ -637,10 +675,9 @@ extern "C" int omni_rms_norm_general_fuse_sum(void* out_i8, const void* in_f16,
   {
     const int nv = norm_block(hidden, true);
     if (v2_ok(hidden, nv)) {
-      OMNI_V2_DISPATCH_J(v2_chunks(hidden, nv),
-                         hipLaunchKernelGGL((general_norm_v2_kernel<J, true, SrcPlain>), dim3(tokens), v2_block(nv), 0,
-                                            (hipStream_t)stream, (int8_t*)out_i8, SrcPlain{(const half_t*)in_f16, hidden},
-                                            (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv));
+      OMNI_V2_LAUNCH((general_norm_v2_kernel<true, SrcPlain>), tokens, hidden, (int8_t*)out_i8,
+                     SrcPlain{(const half_t*)in_f16, hidden}, (const half_t*)weight_f16, (half_t*)sum_f16,
+                     (half_t*)scale_f16, eps, hidden, nv);
       return omni_launch_status();
     }
   }
@@ -713,11 +750,9 @@ extern "C" int omni_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f
   {
     const int nv = norm_block(hidden, true);
     if (v2_ok(hidden, nv)) {
-      OMNI_V2_DISPATCH_J(v2_chunks(hidden, nv),
-                         hipLaunchKernelGGL((general_norm_v2_kernel<J, true, SrcAdd>), dim3(tokens), v2_block(nv), 0,
-                                            (hipStream_t)stream, (int8_t*)out_i8,
-                                            SrcAdd{(half_t*)residual_f16, (const half_t*)delta_f16, hidden},
-                                            (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv));
+      OMNI_V2_LAUNCH((general_norm_v2_kernel<true, SrcAdd>), tokens, hidden, (int8_t*)out_i8,
+                     SrcAdd{(half_t*)residual_f16, (const half_t*)delta_f16, hidden}, (const half_t*)weight_f16,
+                     (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
       return omni_launch_status();
     }
   }
@@ -735,10 +770,8 @@ extern "C" int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, vo
   {
     const int nv = norm_block(d, false);
     if (v2_ok(d, nv)) {
-      OMNI_V2_DISPATCH_J(v2_chunks(d, nv),
-                         hipLaunchKernelGGL((quant_v2_kernel<J, true, SrcSilu>), dim3(tokens), v2_block(nv), 0,
-                                            (hipStream_t)stream, (int8_t*)out_i8, SrcSilu{(const half_t*)in_f16, d},
-                                            (half_t*)sum_f16, (half_t*)scale_f16, d, nv));
+      OMNI_V2_LAUNCH((quant_v2_kernel<true, SrcSilu>), tokens, d, (int8_t*)out_i8, SrcSilu{(const half_t*)in_f16, d},
+                     (half_t*)sum_f16, (half_t*)scale_f16, d, nv);
       return omni_launch_status();
     }
   }
@@ -761,9 +794,7 @@ extern "C" int omni_splitk_add_rms_norm_general_fuse_sum(void* out_i8, void* res
   SrcSlabAddChn src{(half_t*)residual_f16, (const int32_t*)slab_i32, (size_t)tokens * hidden, sk, hidden,
                     (const half_t*)wscales_f16, (const half_t*)w_szs_f16, (const half_t*)ascales_in_f16,
                     (const half_t*)a_ssums_in_f16, 0.f, 0.f};
-  OMNI_V2_DISPATCH_J(v2_chunks(hidden, nv),
-                     hipLaunchKernelGGL((general_norm_v2_kernel<J, true, SrcSlabAddChn>), dim3(tokens), v2_block(nv), 0,
-                                        (hipStream_t)stream, (int8_t*)out_i8, src, (const half_t*)weight_f16,
-                                        (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv));
+  OMNI_V2_LAUNCH((general_norm_v2_kernel<true, SrcSlabAddChn>), tokens, hidden, (int8_t*)out_i8, src,
+                 (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
   return omni_launch_status();
 }

@@ -534,7 +534,7 @@ typedef __fp16 v4hp __attribute__((__vector_size__(4 * sizeof(__fp16))));
 constexpr int VROW = 272;        // bytes per token row of the V tile in LDS (256 + 16: conflict-free b128 writes)
 constexpr int VTILE = 32 * VROW;  // one 32-token tile per wave
 constexpr int MF_UK = 8;          // K groups (16 tokens) in flight per wave
-constexpr int MF_UT = 2;          // V tiles (32 tokens) in flight per wave
+constexpr int MF_UT = 2;          // V tiles (32 tokens) per batch; one batch is always in flight
 
 __device__ __forceinline__ int unperm_pos(int q) { return (q & ~7) | ((q >> 1) & 3) | ((q & 1) << 2); }
 
@@ -664,6 +664,28 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
       }
     }
   }
+  // V loads are issued one batch ahead: the first batch flies during the softmax below
+  const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
+  const size_t vhead_off = (size_t)hk * lay.tpb * ROW_BYTES + vpiece * 16;
+  uint4 vraw[MF_UT][2];
+  half_t vsc[MF_UT][2], vze[MF_UT][2];
+  auto load_v_batch = [&](int tl0) {   // branch-free: out-of-range tokens re-read token t0
+#pragma unroll
+    for (int u = 0; u < MF_UT; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ti = (tl0 + u * DEC_WAVES) * 32 + h * 16 + vtok;
+        const int tok = ti < nt ? t0 + ti : t0;
+        const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[40 + (tok >> lay.tpb_log2) - page0]);
+        const int slot = tok & (lay.tpb - 1);
+        vraw[u][h] = *reinterpret_cast<const uint4*>(pg + vhead_off + (size_t)slot * ROW_BYTES);
+        const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
+        vsc[u][h] = tail[0];
+        vze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
+      }
+  };
+  load_v_batch(wave);
+
   float scur[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) scur[g] = 0.0f;
@@ -726,8 +748,6 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
   for (int c = 0; c < 8; ++c) oacc[c] = (v4f){0.f, 0.f, 0.f, 0.f};
   {
     uint8_t* vt = vtile + wave * VTILE;
-    const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
-    const size_t vhead_off = (size_t)hk * lay.tpb * ROW_BYTES + vpiece * 16;
     // transposed-read address of this lane inside a 16-dim column block: row (l15>>2) of the 4-token
     // block owned by lane group l4, halves [4*(l15&3), +4)
     const int tr_off = (4 * l4 + (l15 >> 2)) * VROW + (l15 & 3) * 8;
@@ -737,16 +757,8 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
 #pragma unroll
       for (int u = 0; u < MF_UT; ++u)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int ti = (tl0 + u * DEC_WAVES) * 32 + h * 16 + vtok;
-          const int tok = ti < nt ? t0 + ti : t0;
-          const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[40 + (tok >> lay.tpb_log2) - page0]);
-          const int slot = tok & (lay.tpb - 1);
-          raw[u][h] = *reinterpret_cast<const uint4*>(pg + vhead_off + (size_t)slot * ROW_BYTES);
-          const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
-          sc[u][h] = tail[0];
-          ze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
-        }
+        for (int h = 0; h < 2; ++h) { raw[u][h] = vraw[u][h]; sc[u][h] = vsc[u][h]; ze[u][h] = vze[u][h]; }
+      load_v_batch(tl0 + DEC_WAVES * MF_UT);   // next batch in flight while this one is consumed
 #pragma unroll
       for (int u = 0; u < MF_UT; ++u) {
         const int tbase = (tl0 + u * DEC_WAVES) * 32;
