@@ -132,6 +132,19 @@ int omni_splitk_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, 
                                               const void* weight_f16, void* sum_f16, void* scale_f16,
                                               float eps, int tokens, int hidden, void* stream);
 
+/* Decode attention with the flash-decoding merge fused into the following activation quantisation
+ * (llama_w4a8_unpad.py:354): omni_kv4_decode_attention_partial = omni_kv4_decode_attention without its
+ * merge step (*nsplit_out = S, partials stay in `workspace`: f32 [B,Hq,S,2] then f32 [B,Hq,S,128]);
+ * omni_attn_merge_quant_fuse_sum = merge + omni_quant_fuse_sum of the [B, Hq*128] attention output. */
+int omni_kv4_decode_attention_partial(const void* q_f16, const void* k_f16, const void* v_f16,
+                                      int64_t q_stride, int64_t kv_stride, const void* kv_pointers_i64,
+                                      const void* lengths_i32, int batch, int max_blocks, int num_heads,
+                                      int num_kv_heads, int head_dim, int tokens_per_block, int max_context,
+                                      const void* rope_cos_sin_f32, int rope_max_pos, void* workspace,
+                                      size_t workspace_bytes, int* nsplit_out, void* stream);
+int omni_attn_merge_quant_fuse_sum(void* out_i8, const void* part_ml_f32, const void* part_o_f32, int nsplit,
+                                   void* sum_f16, void* scale_f16, int batch, int num_heads, void* stream);
+
 /* omni_silu_and_mul followed by omni_quant_fuse_sum without materialising the fp16 product
  * (activation.py:54-64 calls them back to back).  in fp16 [tokens, 2d] -> out int8 [tokens, d]. */
 int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f16, void* scale_f16,

@@ -52,3 +52,28 @@ def splitk_add_rms_norm_general_fuse_sum(out, residual, slab, sk, wscales, ascal
         w_szs.data_ptr(), a_ssums_in.data_ptr(), weight.data_ptr(), input_sum.data_ptr(), scaling.data_ptr(),
         float(epsilon), tokens, hidden, _lib.current_stream())
     _lib.check(rc, "fused_ext.splitk_add_rms_norm_general_fuse_sum")
+
+
+def decode_attention_quant_fuse_sum(out_i8, q, k, v, kv_pointers, lengths, tokens_per_block, timestep,
+                                    rotary_base, input_sum, scale):
+    """single_query_attention (KV4 + zeros, neox RoPE) followed by invoke_quant_fuse_sum of its
+    [B, Hq*Dh] output, with the flash-decoding merge fused into the quantisation kernel."""
+    import ctypes
+    from ..rope import rope_table
+    _lib.require_cuda(out_i8, q, k, v, kv_pointers, lengths, input_sum, scale)
+    B, Hq, D = q.shape
+    Hkv = k.shape[1]
+    max_ctx = max(int(timestep), 1)
+    table = rope_table(max_ctx + 1, D, float(rotary_base), 1.0, q.device)
+    need = _lib.lib().omni_kv4_decode_workspace_bytes(B, Hq, D, max_ctx)
+    ws = _lib.workspace(need, q.device, "attn")
+    ns = ctypes.c_int(0)
+    rc = _lib.lib().omni_kv4_decode_attention_partial(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), kv_pointers.data_ptr(),
+        lengths.data_ptr(), B, kv_pointers.shape[-1], Hq, Hkv, D, int(tokens_per_block), max_ctx,
+        table.data_ptr(), table.shape[0], ws.data_ptr(), ws.numel(), ctypes.byref(ns), _lib.current_stream())
+    _lib.check(rc, "fused_ext.decode_attention_quant_fuse_sum (partials)")
+    ml_bytes = B * Hq * ns.value * 2 * 4
+    rc = _lib.lib().omni_attn_merge_quant_fuse_sum(out_i8.data_ptr(), ws.data_ptr(), ws.data_ptr() + ml_bytes, ns.value,
+                                                   input_sum.data_ptr(), scale.data_ptr(), B, Hq, _lib.current_stream())
+    _lib.check(rc, "fused_ext.decode_attention_quant_fuse_sum (merge+quant)")

@@ -375,6 +375,34 @@ struct SrcSilu {  // h(h(silu(gate)) * up) of a [2d] row
   }
 };
 
+struct SrcAttnMerge {  // merged decode-attention output (flash-decoding partials) of one token: [Hq*128] fp16
+  const float* part_ml;   // [B,Hq,S,2]
+  const float* part_o;    // [B,Hq,S,128]
+  int nsplit, num_heads, token;
+  __device__ __forceinline__ SrcAttnMerge at_row(int m) const { SrcAttnMerge r = *this; r.token = m; return r; }
+  __device__ __forceinline__ void load8(int i, float (&x)[VT]) const {
+    const size_t bh = (size_t)token * num_heads + (i >> 7);
+    const int d = i & 127;
+    float M = -1e30f;
+    for (int s = 0; s < nsplit; ++s) M = __builtin_fmaxf(M, part_ml[(bh * nsplit + s) * 2]);
+    float l = 0.0f;
+    float o[VT];
+#pragma unroll
+    for (int e = 0; e < VT; ++e) o[e] = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+      const float w = __expf(part_ml[(bh * nsplit + s) * 2] - M);
+      l += w * part_ml[(bh * nsplit + s) * 2 + 1];
+      const v4f a = *reinterpret_cast<const v4f*>(part_o + (bh * nsplit + s) * 128 + d);
+      const v4f b = *reinterpret_cast<const v4f*>(part_o + (bh * nsplit + s) * 128 + d + 4);
+#pragma unroll
+      for (int e = 0; e < VT; ++e) o[e] += w * (e < 4 ? a[e] : b[e - 4]);
+    }
+    const float inv = 1.0f / (l + 1e-6f);
+#pragma unroll
+    for (int e = 0; e < VT; ++e) x[e] = (float)(half_t)(o[e] * inv);   // = kv4_decode_merge_kernel's fp16 output
+  }
+};
+
 __device__ __forceinline__ void store8_i8(int8_t* dst, const float (&x)[VT], float q) {
   uint32_t lo = 0, hi = 0;
 #pragma unroll
@@ -796,5 +824,20 @@ extern "C" int omni_splitk_add_rms_norm_general_fuse_sum(void* out_i8, void* res
                     (const half_t*)a_ssums_in_f16, 0.f, 0.f};
   OMNI_V2_LAUNCH((general_norm_v2_kernel<true, SrcSlabAddChn>), tokens, hidden, (int8_t*)out_i8, src,
                  (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
+  return omni_launch_status();
+}
+
+// Fused extension: kv4_decode_merge_kernel + omni_quant_fuse_sum in one kernel (one workgroup per token).
+extern "C" int omni_attn_merge_quant_fuse_sum(void* out_i8, const void* part_ml_f32, const void* part_o_f32, int nsplit,
+                                              void* sum_f16, void* scale_f16, int batch, int num_heads, void* stream) {
+  if (!out_i8 || !part_ml_f32 || !part_o_f32 || !sum_f16 || !scale_f16 || nsplit < 1 || batch < 0 || num_heads < 1)
+    return OMNI_EINVAL;
+  const int hidden = num_heads * 128;
+  const int nv = norm_block(hidden, false);
+  if (!v2_ok(hidden, nv)) return OMNI_EINVAL;
+  if (batch == 0) return OMNI_OK;
+  SrcAttnMerge src{(const float*)part_ml_f32, (const float*)part_o_f32, nsplit, num_heads, 0};
+  OMNI_V2_LAUNCH((quant_v2_kernel<true, SrcAttnMerge>), batch, hidden, (int8_t*)out_i8, src, (half_t*)sum_f16,
+                 (half_t*)scale_f16, hidden, nv);
   return omni_launch_status();
 }

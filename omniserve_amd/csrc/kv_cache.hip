@@ -614,6 +614,29 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
   const int tail_off = lay.bytes_per_seq + hk * lay.tpb * 2;
   const int zero_off = lay.num_kv_heads * lay.tpb * 2;
 
+  // V loads are issued one batch ahead; the first batch goes out before any K work, so with the usual
+  // split sizes every K and V byte of the workgroup is requested in the same memory round trip
+  const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
+  const size_t vhead_off = (size_t)hk * lay.tpb * ROW_BYTES + vpiece * 16;
+  uint4 vraw[MF_UT][2];
+  half_t vsc[MF_UT][2], vze[MF_UT][2];
+  auto load_v_batch = [&](int tl0) {   // branch-free: out-of-range tokens re-read token t0
+#pragma unroll
+    for (int u = 0; u < MF_UT; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ti = (tl0 + u * DEC_WAVES) * 32 + h * 16 + vtok;
+        const int tok = ti < nt ? t0 + ti : t0;
+        const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[40 + (tok >> lay.tpb_log2) - page0]);
+        const int slot = tok & (lay.tpb - 1);
+        vraw[u][h] = *reinterpret_cast<const uint4*>(pg + vhead_off + (size_t)slot * ROW_BYTES);
+        const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
+        vsc[u][h] = tail[0];
+        vze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
+      }
+  };
+  load_v_batch(wave);
+
   // ---- pass 1: scores = q.K / sqrt(Dh) on MFMA ------------------------------------------------------
   float mloc = -1e30f;   // running max of this lane's head column (valid for l15 < G)
   {
@@ -664,28 +687,6 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
       }
     }
   }
-  // V loads are issued one batch ahead: the first batch flies during the softmax below
-  const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
-  const size_t vhead_off = (size_t)hk * lay.tpb * ROW_BYTES + vpiece * 16;
-  uint4 vraw[MF_UT][2];
-  half_t vsc[MF_UT][2], vze[MF_UT][2];
-  auto load_v_batch = [&](int tl0) {   // branch-free: out-of-range tokens re-read token t0
-#pragma unroll
-    for (int u = 0; u < MF_UT; ++u)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int ti = (tl0 + u * DEC_WAVES) * 32 + h * 16 + vtok;
-        const int tok = ti < nt ? t0 + ti : t0;
-        const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[40 + (tok >> lay.tpb_log2) - page0]);
-        const int slot = tok & (lay.tpb - 1);
-        vraw[u][h] = *reinterpret_cast<const uint4*>(pg + vhead_off + (size_t)slot * ROW_BYTES);
-        const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
-        vsc[u][h] = tail[0];
-        vze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
-      }
-  };
-  load_v_batch(wave);
-
   float scur[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) scur[g] = 0.0f;
@@ -882,9 +883,9 @@ static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int ma
   pl.g = group >= 4 ? 4 : group;  // group in {1,2,4,8,...}
   const int wgs_per_split = batch * num_kv_heads * (group / pl.g);
   // the kernel runs one 256-thread workgroup per CU (it spends the register file on the P.V
-  // accumulators): split the KV range until there is ~1 workgroup per CU; a single split skips
+  // accumulators): split the KV range until there are ~2 workgroups per CU; a single split skips
   // the merge kernel
-  int s = wgs_per_split >= 256 ? 1 : (256 + wgs_per_split - 1) / wgs_per_split;
+  int s = wgs_per_split >= 512 ? 1 : (512 + wgs_per_split - 1) / wgs_per_split;
   if (g_override_nsplit > 0) s = g_override_nsplit;
   const int max_s = (max_context + 63) / 64;
   if (s > max_s) s = max_s;
@@ -957,15 +958,13 @@ extern "C" size_t omni_kv4_decode_workspace_bytes(int batch, int num_heads, int 
   return (size_t)batch * num_heads * 64 * (DH + 2) * sizeof(float);
 }
 
-extern "C" int omni_kv4_decode_attention(void* out_f16, const void* q_f16, const void* k_f16,
-                                         const void* v_f16, int64_t q_stride, int64_t kv_stride,
-                                         const void* kv_pointers_i64, const void* lengths_i32,
-                                         int batch, int max_blocks, int num_heads, int num_kv_heads,
-                                         int head_dim, int tokens_per_block, int max_context,
-                                         const void* rope_cos_sin_f32, int rope_max_pos,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
-  if (!out_f16 || !q_f16 || !k_f16 || !v_f16 || !kv_pointers_i64 || !lengths_i32 || !rope_cos_sin_f32 ||
-      !workspace)
+static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride,
+                         int64_t kv_stride, const void* kv_pointers_i64, const void* lengths_i32, int batch,
+                         int max_blocks, int num_heads, int num_kv_heads, int head_dim, int tokens_per_block,
+                         int max_context, const void* rope_cos_sin_f32, int rope_max_pos, void* workspace,
+                         size_t workspace_bytes, void* stream, bool partials_only, int* nsplit_out) {
+  if ((!out_f16 && !partials_only) || !q_f16 || !k_f16 || !v_f16 || !kv_pointers_i64 || !lengths_i32 ||
+      !rope_cos_sin_f32 || !workspace)
     return OMNI_EINVAL;
   if (head_dim != DH || batch < 1 || num_heads < 1 || num_kv_heads < 1 || num_heads % num_kv_heads != 0 ||
       tokens_per_block < 16 || (tokens_per_block & (tokens_per_block - 1)) != 0 || max_context < 1 ||
@@ -1003,7 +1002,7 @@ extern "C" int omni_kv4_decode_attention(void* out_f16, const void* q_f16, const
       hipLaunchKernelGGL((kv4_decode_kernel<G_, D_>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a);  \
     }                                                                                                 \
   } while (0)
-  if (pl.nsplit == 1) {
+  if (pl.nsplit == 1 && !partials_only) {
     switch (pl.g) {
       case 1: OMNI_LAUNCH_DEC(1, true); break;
       case 2: OMNI_LAUNCH_DEC(2, true); break;
@@ -1015,9 +1014,39 @@ extern "C" int omni_kv4_decode_attention(void* out_f16, const void* q_f16, const
       case 2: OMNI_LAUNCH_DEC(2, false); break;
       default: OMNI_LAUNCH_DEC(4, false); break;
     }
-    hipLaunchKernelGGL(kv4_decode_merge_kernel, dim3(batch * num_heads), dim3(128), 0, st, (half_t*)out_f16,
-                       a.part_ml, a.part_o, pl.nsplit);
+    if (!partials_only)
+      hipLaunchKernelGGL(kv4_decode_merge_kernel, dim3(batch * num_heads), dim3(128), 0, st, (half_t*)out_f16,
+                         a.part_ml, a.part_o, pl.nsplit);
   }
 #undef OMNI_LAUNCH_DEC
+  if (nsplit_out) *nsplit_out = pl.nsplit;
   return omni_launch_status();
+}
+
+extern "C" int omni_kv4_decode_attention(void* out_f16, const void* q_f16, const void* k_f16,
+                                         const void* v_f16, int64_t q_stride, int64_t kv_stride,
+                                         const void* kv_pointers_i64, const void* lengths_i32,
+                                         int batch, int max_blocks, int num_heads, int num_kv_heads,
+                                         int head_dim, int tokens_per_block, int max_context,
+                                         const void* rope_cos_sin_f32, int rope_max_pos,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  return decode_common(out_f16, q_f16, k_f16, v_f16, q_stride, kv_stride, kv_pointers_i64, lengths_i32, batch,
+                       max_blocks, num_heads, num_kv_heads, head_dim, tokens_per_block, max_context,
+                       rope_cos_sin_f32, rope_max_pos, workspace, workspace_bytes, stream, false, nullptr);
+}
+
+// Fused extension: same as omni_kv4_decode_attention but stops after the per-split partials
+// (workspace = part_ml f32 [B,Hq,S,2] | part_o f32 [B,Hq,S,128], *nsplit_out = S); the merge is then fused
+// with the following per-token quantisation by omni_attn_merge_quant_fuse_sum.
+extern "C" int omni_kv4_decode_attention_partial(const void* q_f16, const void* k_f16, const void* v_f16,
+                                                 int64_t q_stride, int64_t kv_stride, const void* kv_pointers_i64,
+                                                 const void* lengths_i32, int batch, int max_blocks, int num_heads,
+                                                 int num_kv_heads, int head_dim, int tokens_per_block,
+                                                 int max_context, const void* rope_cos_sin_f32, int rope_max_pos,
+                                                 void* workspace, size_t workspace_bytes, int* nsplit_out,
+                                                 void* stream) {
+  if (!nsplit_out) return OMNI_EINVAL;
+  return decode_common(nullptr, q_f16, k_f16, v_f16, q_stride, kv_stride, kv_pointers_i64, lengths_i32, batch,
+                       max_blocks, num_heads, num_kv_heads, head_dim, tokens_per_block, max_context,
+                       rope_cos_sin_f32, rope_max_pos, workspace, workspace_bytes, stream, true, nsplit_out);
 }

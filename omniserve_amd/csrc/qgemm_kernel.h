@@ -295,7 +295,7 @@ struct GemvCfg {
 };
 
 template <int MB, int MODE, bool TO_SLAB>
-__global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES)) void w4a8_gemv_kernel(GemmArgs p) {
+__global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES), 1) void w4a8_gemv_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
   constexpr int WAVES = GemvCfg<MB, MODE>::WAVES;
   constexpr int NTHREADS = 64 * WAVES;

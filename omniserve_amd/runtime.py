@@ -208,10 +208,14 @@ class DecodeRunner:
             q = self.qkv_buf[:, : hq * d].view(B, hq, d)
             k = self.qkv_buf[:, hq * d:(hq + hk) * d].view(B, hk, d)
             v = self.qkv_buf[:, (hq + hk) * d:].view(B, hk, d)
-            attn = fused_attention_pure_dense.single_query_attention(
-                q, k, v, self.block_tables[li], self.lengths, None, 65536, self.tpb, hk * d // 2,
-                self.max_context, d, c.rope_theta, True, True, True)
-            fused_kernels.invoke_quant_fuse_sum(self._q_attn, attn.view(B, hq * d), mA, sA)
+            if self.fused >= 2:     # attention with its split merge fused into the activation quant
+                fused_ext.decode_attention_quant_fuse_sum(self._q_attn, q, k, v, self.block_tables[li], self.lengths,
+                                                          self.tpb, self.max_context, c.rope_theta, mA, sA)
+            else:
+                attn = fused_attention_pure_dense.single_query_attention(
+                    q, k, v, self.block_tables[li], self.lengths, None, 65536, self.tpb, hk * d // 2,
+                    self.max_context, d, c.rope_theta, True, True, True)
+                fused_kernels.invoke_quant_fuse_sum(self._q_attn, attn.view(B, hq * d), mA, sA)
             if self.fused >= 2:
                 sk = fused_ext.gemm_partial_per_chn(self._q_attn, L["o"].qweight, self.slab)
                 fused_ext.splitk_add_rms_norm_general_fuse_sum(qa_h, self.x, self.slab, sk, L["o"].s1_scales, sA,

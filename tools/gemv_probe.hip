@@ -110,13 +110,13 @@ float time_us(F launch, int iters) {
 }
 
 
-// ---- v3 structure: activations staged one ring round ahead (single-wave workgroup, no barrier) ------
-template <bool PIN, int MINW>
-__global__ __launch_bounds__(64, MINW) void probe_round(const uint8_t* W, const int8_t* A, int* out, int N, int K, int nsteps) {
-  constexpr int RK = RING * 64, APT = (MT * RK / 16) / 64;
+// ---- v3 structure: activations staged one ring round ahead; WAVES waves share the staged tile ------
+template <bool PIN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void probe_round(const uint8_t* W, const int8_t* A, int* out, int N, int K, int nsteps) {
+  constexpr int RK = RING * 64, NT = 64 * WAVES, APT = (MT * RK / 16) / NT;
   __shared__ __attribute__((aligned(16))) uint8_t lds[2][MT * RK];
-  const int tid = threadIdx.x, lane = tid;
-  const int ng = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ng = blockIdx.x * WAVES + wave;
   const int lx = (lane >> 3) & 1, lc = lane & 7, le = lane >> 4;
   const uint8_t* base = W + ((size_t)(2 * ng + lx) * (K / 32)) * 512 + (lc * 4 + le) * 16;
   const int k0 = blockIdx.y * nsteps;
@@ -127,14 +127,14 @@ __global__ __launch_bounds__(64, MINW) void probe_round(const uint8_t* W, const 
   auto load_a = [&](int kr) {
 #pragma unroll
     for (int j = 0; j < APT; ++j) {
-      const int id = tid + j * 64; const int m = id / (RK / 16), kk = id % (RK / 16);
+      const int id = tid + j * NT; const int m = id / (RK / 16), kk = id % (RK / 16);
       areg[j] = *reinterpret_cast<const uint4*>(A + (size_t)m * K + kr + kk * 16);
     }
   };
   auto store_a = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < APT; ++j) {
-      const int id = tid + j * 64; const int m = id / (RK / 16), kk = id % (RK / 16);
+      const int id = tid + j * NT; const int m = id / (RK / 16), kk = id % (RK / 16);
       const int kp = kk >> 2, tp = (kk >> 1) & 1, d = kk & 1;
       uint8_t* dst = &lds[buf][(kp * MT + m) * 64 + tp * 8 + d * 4];
       *reinterpret_cast<uint32_t*>(dst + 0) = areg[j].x; *reinterpret_cast<uint32_t*>(dst + 16) = areg[j].y;
@@ -145,6 +145,7 @@ __global__ __launch_bounds__(64, MINW) void probe_round(const uint8_t* W, const 
 #pragma unroll
   for (int s = 0; s < RING; ++s) { q[s][0] = ld(s, 0); q[s][1] = ld(s, 1); }
   load_a(k0 * 64); store_a(0);
+  if (WAVES > 1) __syncthreads();
   v4i acc[4] = {{0,0,0,0},{0,0,0,0},{0,0,0,0},{0,0,0,0}};
   auto step = [&](const v4i (&w)[2], const uint8_t* abuf, int s) {
     const uint32_t d[2][4] = {{(uint32_t)w[0][0], (uint32_t)w[0][2], (uint32_t)w[1][0], (uint32_t)w[1][2]},
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(64, MINW) void probe_round(const uint8_t* W, const 
       if (PIN) __builtin_amdgcn_sched_barrier(0);
     }
     store_a((r + 1) & 1);
+    if (WAVES > 1) __syncthreads();
   }
   {
     const uint8_t* abuf = lds[(rounds - 1) & 1];
@@ -187,21 +189,21 @@ __global__ __launch_bounds__(64, MINW) void probe_round(const uint8_t* W, const 
     const int n = ng * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
     if (gridDim.y > 1) {
       *reinterpret_cast<v4i*>(out + ((size_t)blockIdx.y * 16 + m) * N + n) = acc[ab];
-    } else {  // direct epilogue stand-in: 8-byte store per lane
+    } else {
       int2 o = {acc[ab][0] ^ acc[ab][1], acc[ab][2] ^ acc[ab][3]};
       *reinterpret_cast<int2*>(reinterpret_cast<char*>(out) + ((size_t)m * N + n) * 2) = o;
     }
   }
 }
 
-template <bool PIN, int MINW>
+template <bool PIN, int WAVES>
 void run_round(const uint8_t* W, const int8_t* A, int* out, int N, int K, size_t bytes, int copies) {
-  for (int sk : {1, 2, 4, 8}) {
+  for (int sk : {1, 2, 4}) {
     const int nsteps = K / 64 / sk;
-    dim3 grid(N / 64, sk);
-    float us = time_us([&](int i) { hipLaunchKernelGGL((probe_round<PIN, MINW>), grid, dim3(64), 0, 0,
+    dim3 grid(N / 64 / WAVES, sk);
+    float us = time_us([&](int i) { hipLaunchKernelGGL((probe_round<PIN, WAVES>), grid, dim3(64 * WAVES), 0, 0,
                                     W + bytes * (i % copies), A, out, N, K, nsteps); }, 24);
-    printf("round-staged pin=%d minwaves=%d sk=%d : %7.2f us  %7.1f GB/s\n", (int)PIN, MINW, sk, us, bytes / us / 1e3);
+    printf("round-staged pin=%d waves=%d sk=%d : %7.2f us  %7.1f GB/s\n", (int)PIN, WAVES, sk, us, bytes / us / 1e3);
   }
 }
 
@@ -226,9 +228,8 @@ int main() {
   hipMalloc(&W, bytes * copies); hipMalloc(&A, 16 * K); hipMalloc(&out, (size_t)8 * 16 * N * 4);
   hipMemset(W, 0x5a, bytes * copies); hipMemset(A, 1, 16 * K);
   printf("levels: 0 stream, 1 +unpack, 2 +lds B reads, 3 +mfma, 4 +A staging, 5 +slab store\n");
-  run_round<false, 1>(W, A, out, N, K, bytes, copies); run_round<true, 1>(W, A, out, N, K, bytes, copies);
-  run_round<false, 3>(W, A, out, N, K, bytes, copies); run_round<true, 3>(W, A, out, N, K, bytes, copies);
-  run_round<false, 4>(W, A, out, N, K, bytes, copies); run_round<true, 4>(W, A, out, N, K, bytes, copies);
+  run_round<false, 1>(W, A, out, N, K, bytes, copies); run_round<false, 2>(W, A, out, N, K, bytes, copies);
+  run_round<false, 4>(W, A, out, N, K, bytes, copies); run_round<true, 2>(W, A, out, N, K, bytes, copies);
   run<1, 0>(W, A, out, N, K, bytes, copies); run<1, 1>(W, A, out, N, K, bytes, copies);
   run<1, 3>(W, A, out, N, K, bytes, copies);
   return 0;
