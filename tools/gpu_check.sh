@@ -14,3 +14,6 @@ echo "== sweep" ; timeout 900 python tools/sweep_graph.py 16 2>&1 | tail -120 | 
 echo "== debug" ; timeout 300 python tools/debug_norm.py 2>&1 | tail -40 | tee $O/debug_norm.log
 echo "== rocprof" ; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof -o bench -- python $OLDPWD/bench.py --steps 32 --warmup 4 --no-extras) 2>&1 | tail -15 | tee $O/rocprof.log
 ls -R $O/prof 2>/dev/null | head -30
+echo "== pmc" ; (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OLDPWD/$O/pmc_fetch -o gemv -- python $OLDPWD/tools/gemv_loop.py) 2>&1 | tail -3 | tee $O/pmc.log
+(cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OLDPWD/$O/pmc_write -o gemv -- python $OLDPWD/tools/gemv_loop.py) 2>&1 | tail -3 | tee -a $O/pmc.log
+ls $O/pmc_fetch $O/pmc_write 2>/dev/null
