@@ -200,6 +200,21 @@ int omni_kv4_decode_attention(void* out_f16, const void* q_f16, const void* k_f1
                               const void* rope_cos_sin_f32, int rope_max_pos, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Prefill attention (varlen, causal; dense heads and token-streaming heads)
+ * Replaces the un-vendored block_sparse_attn.flash_attn_varlen_func / token_streaming_attn_func the
+ * reference calls for every prefill (omniserve/modeling/layers/ctx_attn/ctx_attn_func.py:39-45,68-73).
+ * q fp16 [Lq, Hq, 128], k,v fp16 [Lk, Hkv, 128] with token strides q/k/v_stride (elements; heads contiguous),
+ * out fp16 [Lq, Hq, 128] contiguous; cu_seqlens int32 [B+1]; head_mask_type int32 [Hq] (0 dense, <0
+ * streaming) and streaming_info int32 [2*Hq] = (sink, local) per head, or both NULL for all-dense.
+ * mask = causal (bottom-right aligned) AND (dense OR k_pos < sink OR q_pos - k_pos < local).
+ * -------------------------------------------------------------------------------------------- */
+int omni_prefill_attention(void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16,
+                           int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                           const void* cu_seqlens_q_i32, const void* cu_seqlens_k_i32, int batch,
+                           int max_seqlen_q, int num_heads, int num_kv_heads, int head_dim, int causal,
+                           const void* head_mask_type_i32, const void* streaming_info_i32, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,11 @@ REFERENCE_API = {
     "fused_attention_fine_grained_dense": {"apply_bias_rope_update_kv_cache": 27, "compute_padding_offsets": 3},
 }
 
+THIRD_PARTY_API = {   # un-vendored packages the reference imports for prefill attention
+    "block_sparse_attn": ["flash_attn_varlen_func", "token_streaming_attn_func", "block_streaming_attn_func"],
+    "flash_attn.flash_attn_interface": ["flash_attn_varlen_func"],
+}
+
 
 def test_python_mirror_has_reference_names_and_arities():
     import importlib
@@ -56,6 +61,14 @@ def test_python_mirror_has_reference_names_and_arities():
         for fn, n in fns.items():
             f = getattr(m, fn)
             assert len(inspect.signature(f).parameters) == n, (mod, fn)
+
+
+def test_third_party_shims_importable():
+    import importlib
+    for mod, fns in THIRD_PARTY_API.items():
+        m = importlib.import_module(mod)
+        for fn in fns:
+            assert callable(getattr(m, fn))
 
 
 def test_ops_fail_loudly_without_device_tensors():

@@ -1,0 +1,55 @@
+"""Prefill attention (block_sparse_attn / flash_attn shims) vs the f64 oracle: 1e-3 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention as oa
+from tests.util import dev, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seq_lens, Hq, Hk, seed, streaming=None, strided=True):
+    import block_sparse_attn as bsa
+    rng = np.random.default_rng(seed)
+    L = int(sum(seq_lens))
+    D = 128
+    qkv = rng.standard_normal((L, (Hq + 2 * Hk) * D)).astype(np.float16)
+    q = qkv[:, : Hq * D].reshape(L, Hq, D); k = qkv[:, Hq * D:(Hq + Hk) * D].reshape(L, Hk, D)
+    v = qkv[:, (Hq + Hk) * D:].reshape(L, Hk, D)
+    cu = np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)
+    d = to_dev(qkv)
+    if strided:   # views of the fused qkv buffer, as the reference passes them
+        qd = d[:, : Hq * D].view(L, Hq, D); kd = d[:, Hq * D:(Hq + Hk) * D].view(L, Hk, D); vd = d[:, (Hq + Hk) * D:].view(L, Hk, D)
+    else:
+        qd, kd, vd = to_dev(q), to_dev(k), to_dev(v)
+    cu_d = to_dev(cu)
+    if streaming is None:
+        out = bsa.flash_attn_varlen_func(qd, kd, vd, cu_d, cu_d, max(seq_lens), max(seq_lens), dropout_p=0.0, causal=True)
+        want = oa.varlen_attention(q, k, v, cu, cu, True)
+    else:
+        hmt, sink, local = streaming
+        hm = np.repeat(np.asarray(hmt, np.int32), Hq // Hk)
+        si = np.asarray([sink, local] * Hq, np.int32)
+        out = bsa.token_streaming_attn_func(qd, kd, vd, cu_d, cu_d, to_dev(hm), to_dev(si), max(seq_lens), max(seq_lens))
+        want = oa.varlen_attention(q, k, v, cu, cu, True, hm, si)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.float32)
+    ref = want.astype(np.float32)
+    tol = 1e-3 * np.abs(ref) + 1e-3 * np.abs(ref).max()
+    assert (np.abs(got - ref) <= tol).all(), "max err %g" % np.abs(got - ref).max()
+
+
+@pytest.mark.parametrize("seq_lens,Hq,Hk", [([1], 4, 1), ([5, 64, 65], 8, 2), ([200, 33], 32, 8), ([300], 8, 8), ([1000, 17], 4, 4)])
+def test_dense_causal(seq_lens, Hq, Hk):
+    _case(seq_lens, Hq, Hk, seed=sum(seq_lens))
+
+
+def test_dense_contiguous_inputs():
+    _case([70, 130], 8, 2, seed=1, strided=False)
+
+
+@pytest.mark.parametrize("seq_lens,sink,local", [([300], 16, 64), ([513, 90], 128, 256), ([40], 128, 256), ([700], 4, 33)])
+def test_token_streaming_heads(seq_lens, sink, local):
+    # kv heads alternate dense (0) / streaming (-1), expanded to q heads like ctx_attn_init.py:28-47
+    _case(seq_lens, 8, 4, seed=len(seq_lens) + sink, streaming=([0, -1, -1, 0], sink, local))

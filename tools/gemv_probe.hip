@@ -111,9 +111,9 @@ float time_us(F launch, int iters) {
 
 
 // ---- v3 structure: activations staged one ring round ahead; WAVES waves share the staged tile ------
-template <bool PIN, int WAVES>
+template <bool PIN, int WAVES, int RG = 8, bool DMA = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void probe_round(const uint8_t* W, const int8_t* A, int* out, int N, int K, int nsteps) {
-  constexpr int RK = RING * 64, NT = 64 * WAVES, APT = (MT * RK / 16) / NT;
+  constexpr int RING = RG; constexpr int RK = RING * 64, NT = 64 * WAVES, APT = (MT * RK / 16) / NT;
   __shared__ __attribute__((aligned(16))) uint8_t lds[2][MT * RK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ng = blockIdx.x * WAVES + wave;
@@ -124,6 +124,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void probe_round(const uint8_t* W, c
     return __builtin_nontemporal_load(reinterpret_cast<const v4i*>(base + (size_t)((k0 + st) * 2 + j) * 512));
   };
   uint4 areg[APT];
+  auto dma_a = [&](int kr, int buf) {   // LDS-DMA: 256 B (4 rows x 64 B of one k-pair) per instruction
+#pragma unroll
+    for (int kp = 0; kp < RING; ++kp)
+#pragma unroll
+      for (int mq = 0; mq < MT / 4; ++mq) {
+        const int m = mq * 4 + (lane >> 4);
+        const int e = (lane >> 2) & 3, tp = (lane >> 1) & 1, d = lane & 1;
+        const int8_t* src = A + (size_t)m * K + kr + kp * 64 + tp * 32 + d * 16 + e * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(&lds[buf][(kp * MT + mq * 4) * 64]), 4, 0, 0);
+      }
+  };
   auto load_a = [&](int kr) {
 #pragma unroll
     for (int j = 0; j < APT; ++j) {
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void probe_round(const uint8_t* W, c
   v4i q[RING][2];
 #pragma unroll
   for (int s = 0; s < RING; ++s) { q[s][0] = ld(s, 0); q[s][1] = ld(s, 1); }
-  load_a(k0 * 64); store_a(0);
+  if (DMA) dma_a(k0 * 64, 0); else { load_a(k0 * 64); store_a(0); }
   if (WAVES > 1) __syncthreads();
   v4i acc[4] = {{0,0,0,0},{0,0,0,0},{0,0,0,0},{0,0,0,0}};
   auto step = [&](const v4i (&w)[2], const uint8_t* abuf, int s) {
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void probe_round(const uint8_t* W, c
   };
   const int rounds = nsteps / RING;
   for (int r = 0; r + 1 < rounds; ++r) {
-    load_a((k0 + (r + 1) * RING) * 64);
+    if (DMA) dma_a((k0 + (r + 1) * RING) * 64, (r + 1) & 1); else load_a((k0 + (r + 1) * RING) * 64);
     const uint8_t* abuf = lds[r & 1];
 #pragma unroll
     for (int s = 0; s < RING; ++s) {
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void probe_round(const uint8_t* W, c
       step(w, abuf, s);
       if (PIN) __builtin_amdgcn_sched_barrier(0);
     }
-    store_a((r + 1) & 1);
+    if (!DMA) store_a((r + 1) & 1);
     if (WAVES > 1) __syncthreads();
   }
   {
@@ -196,14 +208,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void probe_round(const uint8_t* W, c
   }
 }
 
-template <bool PIN, int WAVES>
+template <bool PIN, int WAVES, int RG = 8, bool DMA = false>
 void run_round(const uint8_t* W, const int8_t* A, int* out, int N, int K, size_t bytes, int copies) {
   for (int sk : {1, 2, 4}) {
     const int nsteps = K / 64 / sk;
     dim3 grid(N / 64 / WAVES, sk);
-    float us = time_us([&](int i) { hipLaunchKernelGGL((probe_round<PIN, WAVES>), grid, dim3(64 * WAVES), 0, 0,
+    float us = time_us([&](int i) { hipLaunchKernelGGL((probe_round<PIN, WAVES, RG, DMA>), grid, dim3(64 * WAVES), 0, 0,
                                     W + bytes * (i % copies), A, out, N, K, nsteps); }, 24);
-    printf("round-staged pin=%d waves=%d sk=%d : %7.2f us  %7.1f GB/s\n", (int)PIN, WAVES, sk, us, bytes / us / 1e3);
+    printf("round-staged pin=%d waves=%d ring=%d dma=%d sk=%d : %7.2f us  %7.1f GB/s\n", (int)PIN, WAVES, RG, (int)DMA, sk, us, bytes / us / 1e3);
   }
 }
 
@@ -228,8 +240,11 @@ int main() {
   hipMalloc(&W, bytes * copies); hipMalloc(&A, 16 * K); hipMalloc(&out, (size_t)8 * 16 * N * 4);
   hipMemset(W, 0x5a, bytes * copies); hipMemset(A, 1, 16 * K);
   printf("levels: 0 stream, 1 +unpack, 2 +lds B reads, 3 +mfma, 4 +A staging, 5 +slab store\n");
-  run_round<false, 1>(W, A, out, N, K, bytes, copies); run_round<false, 2>(W, A, out, N, K, bytes, copies);
-  run_round<false, 4>(W, A, out, N, K, bytes, copies); run_round<true, 2>(W, A, out, N, K, bytes, copies);
+  run_round<false, 1>(W, A, out, N, K, bytes, copies);
+  run_round<false, 1, 16>(W, A, out, N, K, bytes, copies);
+  run_round<false, 1, 4>(W, A, out, N, K, bytes, copies);
+  run_round<false, 1, 8, true>(W, A, out, N, K, bytes, copies);
+  run_round<false, 1, 16, true>(W, A, out, N, K, bytes, copies);
   run<1, 0>(W, A, out, N, K, bytes, copies); run<1, 1>(W, A, out, N, K, bytes, copies);
   run<1, 3>(W, A, out, N, K, bytes, copies);
   return 0;
