@@ -215,6 +215,32 @@ int omni_prefill_attention(void* out_f16, const void* q_f16, const void* k_f16, 
                            int max_seqlen_q, int num_heads, int num_kv_heads, int head_dim, int causal,
                            const void* head_mask_type_i32, const void* streaming_info_i32, void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * LServe dynamic sparsity: K statistics in the page tail and the page selector.
+ * K page of a retrieval pool with H_r heads: int4 data | fp16 scale [H_r][tpb] | fp16 zero [H_r][tpb]
+ *   | fp16 kmax [tpb/sub][H_r][128] | fp16 kmin [tpb/sub][H_r][128].
+ * -------------------------------------------------------------------------------------------- */
+
+/* Replaces omniserve_backend.fused_attention_ctx_pool.paged_min_max_pool
+ *   (sparse_utils/ContextPool/context_pool_kernel.cu:145-213): per sequence, pooled head r
+ *   (input head pooling_heads_idx[r]) and sub-chunk of `pooling_size` tokens, the elementwise max / min of
+ *   the post-RoPE keys k fp16 [L, Hin, 128] are written into the K page tails. */
+int omni_kv_min_max_pool(const void* k_f16, const void* kv_pointers_i64, const void* cu_seqlens_i32,
+                         const void* pooling_heads_idx_i32, int batch, int max_blocks, int num_input_heads,
+                         int num_pool_heads, int head_dim, int max_seqlen, int pooling_size, int page_size,
+                         void* stream);
+
+/* Replaces omniserve_backend.fused_attention_selector.single_query_page_selector
+ *   (sparse_utils/KVPageSelector/fused_kv_page_selector.cpp:262-334): for retrieval heads,
+ *   out[b,h,c] = fp16( sum_d max(q_d*kmax[c,d], q_d*kmin[c,d]) ) over the sub-chunks c of the history
+ *   (q rotated at position lengths[b]-1); out fp16 [B,Hq,padded_sub_chunks] must be zero filled. */
+int omni_kv_page_selector(void* out_f16, const void* q_f16, int64_t q_stride, const void* kv_pointers_i64,
+                          const void* retrieval_head_flags_i32, const void* head_rank_table_i32,
+                          const void* lengths_i32, int batch, int max_blocks, int num_heads, int num_kv_heads,
+                          int num_retrieval_kv_heads, int head_dim, int tokens_per_block,
+                          int tokens_per_sub_chunk, int padded_sub_chunks, const void* rope_cos_sin_f32,
+                          int rope_max_pos, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

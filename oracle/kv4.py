@@ -214,3 +214,71 @@ def decode_attention(q_h, k_h, v_h, lengths, k_cache: PagedKV4, v_cache: PagedKV
             k_cache.write_token(int(k_table[b][tlen // k_cache.TPB]), tlen % k_cache.TPB, hk, kr[hk])
             v_cache.write_token(int(v_table[b][tlen // v_cache.TPB]), tlen % v_cache.TPB, hk, vr[hk])
     return out
+
+
+# ---- LServe dynamic sparsity (sparse_utils/ContextPool, sparse_utils/KVPageSelector) --------------------
+def stats_page_bytes(num_heads_in_pool, head_dim, tokens_per_block, sub_chunk):
+    """K page with min/max statistics (cache_engine.py:75-88)."""
+    return page_bytes(num_heads_in_pool, head_dim, tokens_per_block) + \
+        2 * (tokens_per_block // sub_chunk) * num_heads_in_pool * head_dim * 2
+
+
+def pool_views(pool_row, num_heads_in_pool, head_dim, tokens_per_block, sub_chunk):
+    """(kmax, kmin) fp16 views [subs][H][D] of one K page (uint8 row)."""
+    base = page_bytes(num_heads_in_pool, head_dim, tokens_per_block)
+    subs = tokens_per_block // sub_chunk
+    n = subs * num_heads_in_pool * head_dim
+    kmax = pool_row[base: base + 2 * n].view(F16).reshape(subs, num_heads_in_pool, head_dim)
+    kmin = pool_row[base + 2 * n: base + 4 * n].view(F16).reshape(subs, num_heads_in_pool, head_dim)
+    return kmax, kmin
+
+
+def paged_min_max_pool(k_h, cu_seqlens, pooling_heads_idx, pool, k_table, tokens_per_block, sub_chunk):
+    """context_pool_kernel.cu:33-71: per (sequence, pooled head, sub-chunk) elementwise max/min of the keys
+    (tokens past the end repeat the last one; a sub-chunk is stored only if its first token exists).
+    pool: uint8 [pages, stats_page_bytes]; k_table [B][pages] page indices."""
+    k_h = np.asarray(k_h, F16)
+    H = len(pooling_heads_idx)
+    D = k_h.shape[2]
+    for b in range(len(cu_seqlens) - 1):
+        s0, s1 = int(cu_seqlens[b]), int(cu_seqlens[b + 1])
+        L = s1 - s0
+        for r, hin in enumerate(pooling_heads_idx):
+            for c in range((L + sub_chunk - 1) // sub_chunk):
+                t0 = c * sub_chunk
+                toks = np.minimum(np.arange(t0, t0 + sub_chunk), L - 1)
+                blk = k_h[s0 + toks, int(hin)]
+                page = int(k_table[b][t0 // tokens_per_block])
+                kmax, kmin = pool_views(pool[page], H, D, tokens_per_block, sub_chunk)
+                sc = (t0 % tokens_per_block) // sub_chunk
+                kmax[sc, r] = blk.max(axis=0)
+                kmin[sc, r] = blk.min(axis=0)
+
+
+def page_selector(q_h, lengths, retrieval_head_flags, head_rank_table, pool, k_table, num_kv_heads,
+                  num_retrieval_kv_heads, tokens_per_block, sub_chunk, rope_base, rope_scale=1.0):
+    """KVPageSelectorTemplate.hpp:482-493: score[b,h,c] = sum_d max(h(q_d*kmax_d), h(q_d*kmin_d)) with fp16
+    products; q rotated at position lengths[b]-1.  Streaming heads stay zero.  Returns fp16 [B,Hq,padded]."""
+    q_h = np.asarray(q_h, F16)
+    B, Hq, D = q_h.shape
+    g = Hq // num_kv_heads
+    tmax = int(max(lengths)) - 1
+    n_sub_max = (tmax + sub_chunk - 1) // sub_chunk
+    grp = tokens_per_block // sub_chunk
+    padded = (n_sub_max + grp - 1) // grp * grp
+    out = np.zeros((B, Hq, padded), F16)
+    for b in range(B):
+        tlen = int(lengths[b]) - 1
+        qr = rope_neox(q_h[b], np.full((Hq,), tlen), rope_base, rope_scale)
+        for h in range(Hq):
+            hk = h // g
+            if int(retrieval_head_flags[hk]) == 0:
+                continue
+            rank = int(head_rank_table[hk])
+            for c in range((tlen + sub_chunk - 1) // sub_chunk):
+                page = int(k_table[b][(c * sub_chunk) // tokens_per_block])
+                kmax, kmin = pool_views(pool[page], num_retrieval_kv_heads, D, tokens_per_block, sub_chunk)
+                a = (qr[h] * kmax[c % grp, rank]).astype(F16)
+                bb = (qr[h] * kmin[c % grp, rank]).astype(F16)
+                out[b, h, c] = np.maximum(a, bb).astype(np.float64).sum()
+    return out
