@@ -241,6 +241,43 @@ int omni_kv_page_selector(void* out_f16, const void* q_f16, int64_t q_stride, co
                           int tokens_per_sub_chunk, int padded_sub_chunks, const void* rope_cos_sin_f32,
                           int rope_max_pos, void* stream);
 
+/* ---- LServe fine-grained head classes ----------------------------------------
+ * Every kv head is a retrieval head (retrieval_head_flags[h] != 0: whole history in the retrieval pool)
+ * or a streaming head (sink + local window, kept in a ring of sink_blocks + local_blocks pages of the
+ * streaming pool); head_rank_table[h] = index of the head inside its pool's pages, which hold
+ * num_retrieval_kv_heads / num_streaming_kv_heads heads.  Page tables: retrieval_kv_pointers i64
+ * [B,2,retrieval_blocks], streaming_kv_pointers i64 [B,2,streaming_blocks].
+ *
+ * omni_kv4_prefill_write_fine_grained replaces
+ *   omniserve_backend.fused_attention_fine_grained_dense.apply_bias_rope_update_kv_cache with streaming
+ *   heads (fine_grained_common/update_kv_cache.h:16-43, applyBiasRopeUpdateKVCache.h:296-311): a
+ *   streaming head stores token pos only if pos < sink_tokens or pos >= len - local_tokens. */
+int omni_kv4_prefill_write_fine_grained(
+    void* qkv_f16, const void* seq_lens_i32, const void* padding_offsets_i32, const void* retrieval_kv_pointers_i64,
+    const void* streaming_kv_pointers_i64, const void* retrieval_head_flags_i32, const void* head_rank_table_i32,
+    int tokens, int batch, int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads,
+    int num_retrieval_kv_heads, int num_streaming_kv_heads, int head_dim, int max_seq_len, int tokens_per_block,
+    int sink_tokens, int local_tokens, int sink_blocks, int local_blocks, const void* rope_cos_sin_f32,
+    int rope_max_pos, int max_position_embeddings, void* stream);
+
+/* omni_kv4_decode_attention_fine_grained replaces
+ *   omniserve_backend.fused_attention_fine_grained_dense.single_query_attention
+ *     (fused_attention_fine_grained/dense_attention/fused_attention.h:18-46) and, with
+ *   dynamic_sparse_page_idx_i32 != NULL, omniserve_backend.fused_attention_fine_grained_sparse
+ *     .single_query_attention (sparse_attention/fused_attention.h): retrieval q head h of sequence b attends
+ *   only the num_dynamic_pages pages dynamic_sparse_page_idx[b,h,:] (the last one being the newest page) and
+ *   the appended key is folded into the page's min/max statistics (tokens_per_sub_chunk).  Streaming heads
+ *   attend min(sink+local-1, len-1) cached tokens through the ring.  Workspace as omni_kv4_decode_attention. */
+int omni_kv4_decode_attention_fine_grained(
+    void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride, int64_t kv_stride,
+    const void* retrieval_kv_pointers_i64, const void* streaming_kv_pointers_i64,
+    const void* retrieval_head_flags_i32, const void* head_rank_table_i32, const void* lengths_i32,
+    const void* dynamic_sparse_page_idx_i32, int num_dynamic_pages, int tokens_per_sub_chunk, int batch,
+    int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads, int num_retrieval_kv_heads,
+    int num_streaming_kv_heads, int head_dim, int tokens_per_block, int sink_tokens, int local_tokens,
+    int sink_blocks, int local_blocks, int max_context, const void* rope_cos_sin_f32, int rope_max_pos,
+    void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

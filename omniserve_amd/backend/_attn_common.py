@@ -74,3 +74,88 @@ def decode_attention(q, k, v, kv_pointers, lengths, tokens_per_block, size_per_t
         _lib.current_stream())
     _lib.check(rc, what)
     return out
+
+
+def _fg_tables(retrieval_kv_pointers, streaming_kv_pointers, num_retrieval_kv_heads, num_streaming_kv_heads, what):
+    if num_retrieval_kv_heads > 0 and (retrieval_kv_pointers is None or not retrieval_kv_pointers.is_contiguous()):
+        raise RuntimeError("%s: retrieval_kv_pointers must be a contiguous int64 [B,2,blocks] tensor" % what)
+    if num_streaming_kv_heads > 0 and (streaming_kv_pointers is None or not streaming_kv_pointers.is_contiguous()):
+        raise RuntimeError("%s: streaming_kv_pointers must be a contiguous int64 [B,2,blocks] tensor" % what)
+    rp = retrieval_kv_pointers.data_ptr() if num_retrieval_kv_heads > 0 else 0
+    rb = retrieval_kv_pointers.shape[-1] if num_retrieval_kv_heads > 0 else 0
+    sp = streaming_kv_pointers.data_ptr() if num_streaming_kv_heads > 0 else 0
+    sb = streaming_kv_pointers.shape[-1] if num_streaming_kv_heads > 0 else 0
+    return rp, rb, sp, sb
+
+
+def prefill_write_fine_grained(qkv, seq_lens, padding_offset, retrieval_kv_pointers, streaming_kv_pointers,
+                               retrieval_head_flags, head_rank_table, head_num, kv_head_num, seq_len,
+                               tokens_per_block, size_per_retrieval_token, size_per_streaming_token, sink_token_num,
+                               local_token_num, sink_block_num, local_block_num, num_retrieval_kv_heads,
+                               num_streaming_kv_heads, rotary_embedding_dim, rotary_embedding_base, rope_scale,
+                               rotary_embedding_max_positions, neox, int4, zeros, what):
+    _lib.require_cuda(qkv, seq_lens, padding_offset, retrieval_head_flags, head_rank_table)
+    head_dim = qkv.shape[-1] // (head_num + 2 * kv_head_num)
+    _check_cfg(rotary_embedding_dim, neox, int4, zeros, head_dim)
+    if size_per_retrieval_token != num_retrieval_kv_heads * head_dim // 2 or \
+            size_per_streaming_token != num_streaming_kv_heads * head_dim // 2:
+        raise RuntimeError("%s: size_per_*_token must be heads_in_pool*Dh/2" % what)
+    if not qkv.is_contiguous() or qkv.dtype != torch.float16:
+        raise RuntimeError("%s: qkv must be contiguous fp16" % what)
+    if retrieval_head_flags.dtype != torch.int32 or head_rank_table.dtype != torch.int32:
+        raise RuntimeError("%s: retrieval_head_flags / head_rank_table must be int32" % what)
+    rp, rb, sp, sb = _fg_tables(retrieval_kv_pointers, streaming_kv_pointers, num_retrieval_kv_heads,
+                                num_streaming_kv_heads, what)
+    table = rope_table(int(seq_len), head_dim, float(rotary_embedding_base), float(rope_scale), qkv.device)
+    rc = _lib.lib().omni_kv4_prefill_write_fine_grained(
+        qkv.data_ptr(), seq_lens.data_ptr(), padding_offset.data_ptr(), rp, sp, retrieval_head_flags.data_ptr(),
+        head_rank_table.data_ptr(), qkv.shape[0], seq_lens.shape[0], rb, sb, head_num, kv_head_num,
+        int(num_retrieval_kv_heads), int(num_streaming_kv_heads), head_dim, int(seq_len), int(tokens_per_block),
+        int(sink_token_num), int(local_token_num), int(sink_block_num), int(local_block_num), table.data_ptr(),
+        table.shape[0], int(rotary_embedding_max_positions), _lib.current_stream())
+    _lib.check(rc, what)
+
+
+def decode_attention_fine_grained(q, k, v, retrieval_kv_pointers, streaming_kv_pointers, retrieval_head_flags,
+                                  head_rank_table, dynamic_sparse_page_idxes, lengths, tokens_per_block,
+                                  size_per_retrieval_token, size_per_streaming_token, sink_token_num, local_token_num,
+                                  sink_block_num, local_block_num, num_retrieval_kv_heads, num_streaming_kv_heads,
+                                  timestep, rotary_embedding_dim, rotary_base, rope_scale, neox, int4, zeros,
+                                  tokens_per_sub_chunk, what):
+    _lib.require_cuda(q, k, v, lengths, retrieval_head_flags, head_rank_table)
+    B, Hq, D = q.shape
+    Hkv = k.shape[1]
+    _check_cfg(rotary_embedding_dim, neox, int4, zeros, D)
+    if size_per_retrieval_token != num_retrieval_kv_heads * D // 2 or \
+            size_per_streaming_token != num_streaming_kv_heads * D // 2:
+        raise RuntimeError("%s: size_per_*_token must be heads_in_pool*Dh/2" % what)
+    if q.dtype != torch.float16 or q.stride(2) != 1 or q.stride(1) != D:
+        raise RuntimeError("%s: q must be fp16 [B,H,D] with contiguous heads" % what)
+    if k.stride(2) != 1 or k.stride(1) != D or v.stride(2) != 1 or v.stride(1) != D:
+        raise RuntimeError("%s: k/v heads must be contiguous" % what)
+    if k.stride(0) != v.stride(0):
+        raise RuntimeError("%s: k and v must share the row stride" % what)
+    if lengths.dtype != torch.int32 or retrieval_head_flags.dtype != torch.int32 or \
+            head_rank_table.dtype != torch.int32:
+        raise RuntimeError("%s: lengths / retrieval_head_flags / head_rank_table must be int32" % what)
+    rp, rb, sp, sb = _fg_tables(retrieval_kv_pointers, streaming_kv_pointers, num_retrieval_kv_heads,
+                                num_streaming_kv_heads, what)
+    dyn_ptr, ndyn = 0, 0
+    if dynamic_sparse_page_idxes is not None:
+        d = dynamic_sparse_page_idxes
+        if d.dtype != torch.int32 or not d.is_contiguous() or d.dim() != 3 or d.shape[0] != B or d.shape[1] != Hq:
+            raise RuntimeError("%s: dynamic_sparse_page_idxes must be contiguous int32 [B,Hq,pages]" % what)
+        dyn_ptr, ndyn = d.data_ptr(), d.shape[2]
+    max_ctx = max(int(timestep), 1)
+    table = rope_table(max_ctx + 1, D, float(rotary_base), float(rope_scale), q.device)
+    need = _lib.lib().omni_kv4_decode_workspace_bytes(B, Hq, D, max_ctx)
+    ws = _lib.workspace(need, q.device, "attn")
+    out = torch.empty((B, Hq, D), dtype=q.dtype, device=q.device)
+    rc = _lib.lib().omni_kv4_decode_attention_fine_grained(
+        out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), rp, sp,
+        retrieval_head_flags.data_ptr(), head_rank_table.data_ptr(), lengths.data_ptr(), dyn_ptr, ndyn,
+        int(tokens_per_sub_chunk), B, rb, sb, Hq, Hkv, int(num_retrieval_kv_heads), int(num_streaming_kv_heads), D,
+        int(tokens_per_block), int(sink_token_num), int(local_token_num), int(sink_block_num), int(local_block_num),
+        max_ctx, table.data_ptr(), table.shape[0], ws.data_ptr(), ws.numel(), _lib.current_stream())
+    _lib.check(rc, what)
+    return out

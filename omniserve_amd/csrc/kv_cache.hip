@@ -39,6 +39,24 @@ __host__ __device__ inline KvLayout make_layout(int tpb, int hkv) {
   return l;
 }
 
+// LServe fine-grained head classes (fused_attention_fine_grained/...): every kv head is either a
+// retrieval head (full history in the retrieval pool) or a streaming head (sink + local window in a
+// ring of pages in the streaming pool); head_rank = index of the head inside its pool's pages.
+struct FgArgs {
+  const int64_t* strm_pointers;  // [B,2,strm_blocks]
+  const int* flags;              // [Hkv] != 0: retrieval head      (nullptr: every head is a dense head)
+  const int* rank;               // [Hkv]
+  const int* dyn;                // [B,Hq,num_dyn] selected retrieval pages (nullptr: all pages)
+  int strm_blocks, num_dyn;
+  int num_retr, num_strm;        // heads per page of the two pools
+  int sink, local, sink_blocks, local_blocks;
+  int sub_chunk;                 // > 0: K pages carry min/max statistics, updated on append
+};
+
+__device__ __forceinline__ int ring_block(int blk, int sink_blocks, int local_blocks) {
+  return blk < sink_blocks ? blk : sink_blocks + (blk - sink_blocks) % local_blocks;
+}
+
 // ------------------------------------------------------------------------------------------
 // compute_padding_offsets  (common/input_metadata_helper.cu:16-50)
 // ------------------------------------------------------------------------------------------
@@ -66,7 +84,7 @@ __device__ __forceinline__ uint32_t kv4_code(float x, float inv_scale, float zer
 __global__ __launch_bounds__(256) void kv4_prefill_write_kernel(
     half_t* __restrict__ qkv, const int* __restrict__ seq_lens, const int* __restrict__ padding_offsets,
     const int64_t* __restrict__ kv_pointers, int tokens, int max_blocks, int num_heads, int num_kv_heads,
-    int max_seq_len, KvLayout lay, const float* __restrict__ rope, int rope_max_pos, int cyclic_len) {
+    int max_seq_len, KvLayout lay, const float* __restrict__ rope, int rope_max_pos, int cyclic_len, FgArgs fg) {
   const int slots_per_token = num_heads + num_kv_heads;
   const long long slot_id = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l = threadIdx.x & 15;
@@ -107,13 +125,29 @@ __global__ __launch_bounds__(256) void kv4_prefill_write_kernel(
   *reinterpret_cast<v4h*>(x + 64 + 4 * l) = rhi;
   if (!is_kv) return;
 
-  // retrieval-head validity window (applyBiasRopeUpdateKVCache.h:300-304, sink_token_len = 0)
-  int lower = actual_len - cyclic_len;
-  if (lower < 0) lower = 0;
-  if (pos < lower) return;
-
-  const int page = pos >> lay.tpb_log2, slot = pos & (lay.tpb - 1);
+  // which tokens a head stores (applyBiasRopeUpdateKVCache.h:296-311): retrieval / dense heads the last
+  // cyclic_len tokens (all of them in practice), streaming heads the sinks and the local window
+  int page = pos >> lay.tpb_log2;
+  const int slot = pos & (lay.tpb - 1);
   const int64_t* tab = kv_pointers + (size_t)b * 2 * max_blocks;
+  int tab_blocks = max_blocks, hrank = hk, hpool = lay.num_kv_heads;
+  bool streaming = false;
+  if (fg.flags) {
+    hrank = fg.rank[hk];
+    streaming = fg.flags[hk] == 0;
+    hpool = streaming ? fg.num_strm : fg.num_retr;
+  }
+  if (streaming) {
+    if (!(pos < fg.sink || pos >= actual_len - fg.local)) return;
+    page = ring_block(page, fg.sink_blocks, fg.local_blocks);
+    tab = fg.strm_pointers + (size_t)b * 2 * fg.strm_blocks;
+    tab_blocks = fg.strm_blocks;
+  } else {
+    int lower = actual_len - cyclic_len;
+    if (lower < 0) lower = 0;
+    if (pos < lower) return;
+  }
+  const int pool_bytes_per_seq = hpool * lay.tpb * ROW_BYTES;
   const half_t* v = row + (size_t)(num_heads + num_kv_heads + hk) * DH;
   const v4h vlo = *reinterpret_cast<const v4h*>(v + 4 * l);
   const v4h vhi = *reinterpret_cast<const v4h*>(v + 64 + 4 * l);
@@ -139,8 +173,8 @@ __global__ __launch_bounds__(256) void kv4_prefill_write_kernel(
     const half_t zero_h = (half_t)(nm / range);
     const float inv = 1.0f / (float)scale_h;
     const float z = (float)zero_h;
-    uint8_t* base = reinterpret_cast<uint8_t*>(tab[which * max_blocks + page]);
-    uint8_t* dst = base + ((size_t)hk * lay.tpb + slot) * ROW_BYTES;
+    uint8_t* base = reinterpret_cast<uint8_t*>(tab[which * tab_blocks + page]);
+    uint8_t* dst = base + ((size_t)hrank * lay.tpb + slot) * ROW_BYTES;
     uint32_t q[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -150,9 +184,9 @@ __global__ __launch_bounds__(256) void kv4_prefill_write_kernel(
     *reinterpret_cast<uint16_t*>(dst + 2 * l) = (uint16_t)(q[0] | (q[1] << 4) | (q[2] << 8) | (q[3] << 12));
     *reinterpret_cast<uint16_t*>(dst + 32 + 2 * l) = (uint16_t)(q[4] | (q[5] << 4) | (q[6] << 8) | (q[7] << 12));
     if (l == 0) {
-      half_t* sc = reinterpret_cast<half_t*>(base + lay.bytes_per_seq) + hk * lay.tpb + slot;
+      half_t* sc = reinterpret_cast<half_t*>(base + pool_bytes_per_seq) + hrank * lay.tpb + slot;
       sc[0] = scale_h;
-      sc[lay.num_kv_heads * lay.tpb] = zero_h;
+      sc[hpool * lay.tpb] = zero_h;
     }
   }
 }
@@ -206,6 +240,7 @@ struct DecodeArgs {
   int rope_max_pos;
   float* part_ml;          // [B,Hq,S,2]
   float* part_o;           // [B,Hq,S,128]
+  FgArgs fg;               // fine-grained (retrieval / streaming) extension, used by the FG instantiations
 };
 
 constexpr int DEC_THREADS = 256;
@@ -538,7 +573,12 @@ constexpr int MF_UT = 2;          // V tiles (32 tokens) per batch; one batch is
 
 __device__ __forceinline__ int unperm_pos(int q) { return (q & ~7) | ((q >> 1) & 3) | ((q & 1) << 2); }
 
-template <int G, bool DIRECT>
+// FG: LServe fine-grained mode.  The split runs over a head's list of *attended* cached tokens
+// ("virtual" tokens): all of them for a retrieval head, the tokens of the selected pages with
+// fg.dyn (one list per q head, hence G = 1), min(sink+local-1, tlen) tokens read through the page
+// ring for a streaming head (decoderMaskedMultiheadAttentionTemplate.hpp:1475-1537 of
+// fused_attention_fine_grained/dense_attention, :1566-1641 of sparse_attention).
+template <int G, bool DIRECT, bool FG = false>
 __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int sstride = p.split_tokens + 32;
@@ -563,26 +603,72 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
   const int b = blockIdx.z;
   const int tlen = p.lengths[b] - 1;
   const KvLayout lay = p.lay;
+  // head class: pool geometry and page table of this kv head
+  int hrank = hk, hpool = lay.num_kv_heads, tab_blocks = p.max_blocks;
+  bool streaming = false;
   const int64_t* ktab = p.kv_pointers + (size_t)b * 2 * p.max_blocks;
-  const int64_t* vtab = ktab + p.max_blocks;
+  int nvirt = tlen, gap = 0;   // attended cached tokens; streaming: virtual i >= sink is token i + gap
+  const int* dyn = nullptr;
+  if constexpr (FG) {
+    hrank = p.fg.rank[hk];
+    streaming = p.fg.flags[hk] == 0;
+    hpool = streaming ? p.fg.num_strm : p.fg.num_retr;
+    if (streaming) {
+      tab_blocks = p.fg.strm_blocks;
+      ktab = p.fg.strm_pointers + (size_t)b * 2 * tab_blocks;
+      nvirt = min(p.fg.sink + p.fg.local - 1, tlen);
+      gap = tlen - nvirt;
+    } else if (p.fg.dyn) {
+      dyn = p.fg.dyn + ((size_t)b * p.num_heads + hq0) * p.fg.num_dyn;
+      nvirt = tlen > 0 ? (p.fg.num_dyn - 1) * lay.tpb + ((tlen - 1) & (lay.tpb - 1)) + 1 : 0;
+    }
+  }
+  const int64_t* vtab = ktab + tab_blocks;
+  const int pool_bytes_per_seq = hpool * lay.tpb * ROW_BYTES;
   const float inv_sqrt_dh = 0.08838834764831845f;
 
-  int per = (tlen + p.nsplit - 1) / p.nsplit;
+  int per = (nvirt + p.nsplit - 1) / p.nsplit;
   per = (per + 15) & ~15;
   if (per > p.split_tokens) per = p.split_tokens;
-  const int t0 = min(tlen, split * per);
-  const int t1 = (split == p.nsplit - 1) ? min(tlen, t0 + p.split_tokens) : min(tlen, t0 + per);
+  const int t0 = min(nvirt, split * per);
+  const int t1 = (split == p.nsplit - 1) ? min(nvirt, t0 + p.split_tokens) : min(nvirt, t0 + per);
   const int nt = t1 - t0;
   const bool owns_cur = split == p.nsplit - 1;
-  const int page0 = t0 >> lay.tpb_log2;
+  const int page0 = (FG && streaming) ? 0 : (t0 >> lay.tpb_log2);
 
   // ---- stage: page pointers, RoPE(q) (and k of the current token) ------------------------------
   if (tid < 80) {
     const int pi = tid < 40 ? tid : tid - 40;
     const int64_t* tab = tid < 40 ? ktab : vtab;
     const int pg = page0 + pi;
-    pages[tid] = (pg < p.max_blocks && (pg << lay.tpb_log2) <= tlen) ? tab[pg] : 0;
+    if constexpr (FG) {
+      int64_t ptr = 0;
+      if (streaming) {               // the whole ring (<= 40 pages, checked on the host)
+        if (pg < tab_blocks) ptr = tab[pg];
+      } else if (dyn) {              // selected pages, in selection order
+        if (pg < p.fg.num_dyn) {
+          const int sel = dyn[pg];
+          if (sel >= 0 && sel < tab_blocks) ptr = tab[sel];
+        }
+      } else if (pg < tab_blocks && (pg << lay.tpb_log2) <= tlen) {
+        ptr = tab[pg];
+      }
+      pages[tid] = ptr;
+    } else {
+      pages[tid] = (pg < p.max_blocks && (pg << lay.tpb_log2) <= tlen) ? tab[pg] : 0;
+    }
   }
+  // virtual token -> (index into pages[], slot in the page)
+  auto locate = [&](int vt, int& pidx, int& slot) {
+    if (FG && streaming) {
+      const int lt = vt < p.fg.sink ? vt : vt + gap;
+      pidx = ring_block(lt >> lay.tpb_log2, p.fg.sink_blocks, p.fg.local_blocks);
+      slot = lt & (lay.tpb - 1);
+    } else {
+      pidx = (vt >> lay.tpb_log2) - page0;
+      slot = vt & (lay.tpb - 1);
+    }
+  };
   {
     const int rp = tlen < p.rope_max_pos ? tlen : p.rope_max_pos - 1;
     const float* cs = p.rope + (size_t)rp * DH;
@@ -611,13 +697,13 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
   const int ntiles = (nt + 31) >> 5;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int jh = l15 < G ? l15 : 0;                               // this lane's q-head column (clamped)
-  const int tail_off = lay.bytes_per_seq + hk * lay.tpb * 2;
-  const int zero_off = lay.num_kv_heads * lay.tpb * 2;
+  const int tail_off = pool_bytes_per_seq + hrank * lay.tpb * 2;
+  const int zero_off = hpool * lay.tpb * 2;
 
   // V loads are issued one batch ahead; the first batch goes out before any K work, so with the usual
   // split sizes every K and V byte of the workgroup is requested in the same memory round trip
   const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
-  const size_t vhead_off = (size_t)hk * lay.tpb * ROW_BYTES + vpiece * 16;
+  const size_t vhead_off = (size_t)hrank * lay.tpb * ROW_BYTES + vpiece * 16;
   uint4 vraw[MF_UT][2];
   half_t vsc[MF_UT][2], vze[MF_UT][2];
   auto load_v_batch = [&](int tl0) {   // branch-free: out-of-range tokens re-read token t0
@@ -627,8 +713,9 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
       for (int h = 0; h < 2; ++h) {
         const int ti = (tl0 + u * DEC_WAVES) * 32 + h * 16 + vtok;
         const int tok = ti < nt ? t0 + ti : t0;
-        const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[40 + (tok >> lay.tpb_log2) - page0]);
-        const int slot = tok & (lay.tpb - 1);
+        int pidx, slot;
+        locate(tok, pidx, slot);
+        const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[40 + pidx]);
         vraw[u][h] = *reinterpret_cast<const uint4*>(pg + vhead_off + (size_t)slot * ROW_BYTES);
         const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
         vsc[u][h] = tail[0];
@@ -644,7 +731,7 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx)
       qb[sidx] = *reinterpret_cast<const v8h*>(q_lds + jh * DH + 32 * l4 + 8 * sidx);
-    const size_t khead_off = (size_t)hk * lay.tpb * ROW_BYTES + l4 * 16;  // lane: token l15, 16-B piece l4
+    const size_t khead_off = (size_t)hrank * lay.tpb * ROW_BYTES + l4 * 16;  // lane: token l15, 16-B piece l4
     for (int g0 = wave; g0 < ngroups; g0 += DEC_WAVES * MF_UK) {
       uint4 raw[MF_UK];
       half_t sc[MF_UK], ze[MF_UK];
@@ -652,8 +739,9 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
       for (int u = 0; u < MF_UK; ++u) {
         const int ti = (g0 + u * DEC_WAVES) * 16 + l15;
         const int tok = ti < nt ? t0 + ti : t0;
-        const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[(tok >> lay.tpb_log2) - page0]);
-        const int slot = tok & (lay.tpb - 1);
+        int pidx, slot;
+        locate(tok, pidx, slot);
+        const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[pidx]);
         raw[u] = *reinterpret_cast<const uint4*>(pg + khead_off + (size_t)slot * ROW_BYTES);
         const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
         sc[u] = tail[0];
@@ -834,9 +922,11 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
     const float nm = -15.0f * mn;
     const half_t zero_h = (half_t)(nm / range);
     const float inv = 1.0f / (float)scale_h, z = (float)zero_h;
-    uint8_t* pg = reinterpret_cast<uint8_t*>(tab[tlen >> lay.tpb_log2]);
+    int blk = tlen >> lay.tpb_log2;
+    if (FG && streaming) blk = ring_block(blk, p.fg.sink_blocks, p.fg.local_blocks);
+    uint8_t* pg = reinterpret_cast<uint8_t*>(tab[blk]);
     const int slot = tlen & (lay.tpb - 1);
-    uint8_t* dst = pg + ((size_t)hk * lay.tpb + slot) * ROW_BYTES;
+    uint8_t* dst = pg + ((size_t)hrank * lay.tpb + slot) * ROW_BYTES;
     const uint32_t c0 = kv4_code(x0, inv, z), c1 = kv4_code(x1, inv, z);
     const uint32_t n0 = __shfl_down(c0, 1, 64), n1 = __shfl_down(c1, 1, 64);
     if ((lane & 1) == 0) {
@@ -844,9 +934,26 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
       dst[32 + (lane >> 1)] = (uint8_t)(c1 | (n1 << 4));
     }
     if (lane == 0) {
-      half_t* scp = reinterpret_cast<half_t*>(pg + lay.bytes_per_seq) + hk * lay.tpb + slot;
+      half_t* scp = reinterpret_cast<half_t*>(pg + pool_bytes_per_seq) + hrank * lay.tpb + slot;
       scp[0] = scale_h;
-      scp[lay.num_kv_heads * lay.tpb] = zero_h;
+      scp[hpool * lay.tpb] = zero_h;
+    }
+    if constexpr (FG) {
+      // K pages with min/max statistics: fold the new key into its sub-chunk's indicators
+      // (sparse_attention/decoderMaskedMultiheadAttentionTemplate.hpp:1414-1428)
+      if (wave == 0 && !streaming && p.fg.sub_chunk > 0) {
+        const int subs = lay.tpb / p.fg.sub_chunk;
+        half_t* kmax = reinterpret_cast<half_t*>(pg + pool_bytes_per_seq) + 2 * hpool * lay.tpb +
+                       ((size_t)(slot / p.fg.sub_chunk) * hpool + hrank) * DH;
+        half_t* kmin = kmax + (size_t)subs * hpool * DH;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int d = lane + 64 * h;
+          const half_t kv = src[d], omx = kmax[d], omn = kmin[d];
+          kmax[d] = (half_t)__builtin_fmaxf((float)omx, (float)kv);
+          kmin[d] = (half_t)__builtin_fminf((float)omn, (float)kv);
+        }
+      }
     }
   }
 }
@@ -877,10 +984,12 @@ struct DecodePlan {
 static int g_override_nsplit = 0;
 static int g_use_valu_kernel = 0;   // tuning / A-B hook: 1 = the VALU kernel (kv4_decode_kernel)
 
-static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int max_context) {
+static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int max_context, int tokens_per_block,
+                              bool per_q_head = false, bool per_q_head_or_fg = false) {
   DecodePlan pl;
   const int group = num_heads / num_kv_heads;
   pl.g = group >= 4 ? 4 : group;  // group in {1,2,4,8,...}
+  if (per_q_head) pl.g = 1;       // every q head walks its own page list
   const int wgs_per_split = batch * num_kv_heads * (group / pl.g);
   // the kernel runs one 256-thread workgroup per CU (it spends the register file on the P.V
   // accumulators): split the KV range until there are ~2 workgroups per CU; a single split skips
@@ -892,13 +1001,16 @@ static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int ma
   if (s < 1) s = 1;
   if (s > 64) s = 64;
   int st = ((max_context + s - 1) / s + 15) & ~15;
-  while (st > 2048 && s < 64) {  // LDS bound on the score buffer
+  // LDS bound on the score buffer; the kernel keeps a window of 40 page pointers per split
+  const int st_cap = 38 * tokens_per_block < 2048 ? 38 * tokens_per_block : 2048;
+  while (st > st_cap && s < 64) {
     ++s;
     st = ((max_context + s - 1) / s + 15) & ~15;
   }
+  if (st > st_cap) st = st_cap;   // caller rejects: max_context > 64 * st_cap
   pl.nsplit = s;
   pl.split_tokens = st;
-  pl.mfma = !g_use_valu_kernel;
+  pl.mfma = per_q_head_or_fg || !g_use_valu_kernel;
   if (pl.mfma)
     pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * pl.g * DH * 4 +
                    (size_t)DEC_WAVES * VTILE + (size_t)pl.g * (st + 32) * 6;
@@ -940,7 +1052,61 @@ extern "C" int omni_kv4_prefill_write(void* qkv_f16, const void* seq_lens_i32,
                      (half_t*)qkv_f16, (const int*)seq_lens_i32, (const int*)padding_offsets_i32,
                      (const int64_t*)kv_pointers_i64, tokens, max_blocks, num_heads, num_kv_heads,
                      max_seq_len, make_layout(tokens_per_block, num_kv_heads),
-                     (const float*)rope_cos_sin_f32, rope_max_pos, max_position_embeddings);
+                     (const float*)rope_cos_sin_f32, rope_max_pos, max_position_embeddings, FgArgs{});
+  return omni_launch_status();
+}
+
+static int fill_fg(FgArgs* fg, const void* streaming_kv_pointers_i64, const void* retrieval_head_flags_i32,
+                   const void* head_rank_table_i32, int streaming_blocks, int num_kv_heads,
+                   int num_retrieval_kv_heads, int num_streaming_kv_heads, int sink_tokens, int local_tokens,
+                   int sink_blocks, int local_blocks) {
+  if (!retrieval_head_flags_i32 || !head_rank_table_i32) return OMNI_EINVAL;
+  if (num_retrieval_kv_heads < 0 || num_streaming_kv_heads < 0 ||
+      num_retrieval_kv_heads + num_streaming_kv_heads != num_kv_heads)
+    return OMNI_EINVAL;
+  if (num_streaming_kv_heads > 0) {
+    if (!streaming_kv_pointers_i64 || sink_tokens < 0 || local_tokens < 1 || sink_blocks < 0 || local_blocks < 1 ||
+        streaming_blocks < sink_blocks + local_blocks || sink_blocks + local_blocks > 40)
+      return OMNI_EINVAL;
+  }
+  *fg = FgArgs{};
+  fg->strm_pointers = (const int64_t*)streaming_kv_pointers_i64;
+  fg->flags = (const int*)retrieval_head_flags_i32;
+  fg->rank = (const int*)head_rank_table_i32;
+  fg->strm_blocks = streaming_blocks;
+  fg->num_retr = num_retrieval_kv_heads;
+  fg->num_strm = num_streaming_kv_heads;
+  fg->sink = sink_tokens; fg->local = local_tokens;
+  fg->sink_blocks = sink_blocks; fg->local_blocks = local_blocks > 0 ? local_blocks : 1;
+  return OMNI_OK;
+}
+
+extern "C" int omni_kv4_prefill_write_fine_grained(
+    void* qkv_f16, const void* seq_lens_i32, const void* padding_offsets_i32, const void* retrieval_kv_pointers_i64,
+    const void* streaming_kv_pointers_i64, const void* retrieval_head_flags_i32, const void* head_rank_table_i32,
+    int tokens, int batch, int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads,
+    int num_retrieval_kv_heads, int num_streaming_kv_heads, int head_dim, int max_seq_len, int tokens_per_block,
+    int sink_tokens, int local_tokens, int sink_blocks, int local_blocks, const void* rope_cos_sin_f32,
+    int rope_max_pos, int max_position_embeddings, void* stream) {
+  if (!qkv_f16 || !seq_lens_i32 || !padding_offsets_i32 || !rope_cos_sin_f32) return OMNI_EINVAL;
+  if (head_dim != DH || tokens < 0 || batch < 1 || num_heads < 1 || num_kv_heads < 1 ||
+      num_heads % num_kv_heads != 0 || tokens_per_block < 16 ||
+      (tokens_per_block & (tokens_per_block - 1)) != 0 || rope_max_pos < 1 || max_seq_len < 1)
+    return OMNI_EINVAL;
+  FgArgs fg;
+  const int rc = fill_fg(&fg, streaming_kv_pointers_i64, retrieval_head_flags_i32, head_rank_table_i32,
+                         streaming_blocks, num_kv_heads, num_retrieval_kv_heads, num_streaming_kv_heads, sink_tokens,
+                         local_tokens, sink_blocks, local_blocks);
+  if (rc != OMNI_OK) return rc;
+  if (num_retrieval_kv_heads > 0 && !retrieval_kv_pointers_i64) return OMNI_EINVAL;
+  if (tokens == 0) return OMNI_OK;
+  const long long slots = (long long)tokens * (num_heads + num_kv_heads);
+  const unsigned blocks = (unsigned)((slots + 15) / 16);
+  hipLaunchKernelGGL(kv4_prefill_write_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     (half_t*)qkv_f16, (const int*)seq_lens_i32, (const int*)padding_offsets_i32,
+                     (const int64_t*)retrieval_kv_pointers_i64, tokens, retrieval_blocks, num_heads, num_kv_heads,
+                     max_seq_len, make_layout(tokens_per_block, num_kv_heads),
+                     (const float*)rope_cos_sin_f32, rope_max_pos, max_position_embeddings, fg);
   return omni_launch_status();
 }
 
@@ -972,7 +1138,8 @@ static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, co
     return OMNI_EINVAL;
   const int group = num_heads / num_kv_heads;
   if (group != 1 && group != 2 && group % 4 != 0) return OMNI_EINVAL;
-  const DecodePlan pl = plan_decode(batch, num_heads, num_kv_heads, max_context);
+  const DecodePlan pl = plan_decode(batch, num_heads, num_kv_heads, max_context, tokens_per_block);
+  if ((long long)pl.nsplit * pl.split_tokens < max_context) return OMNI_EINVAL;
   const size_t need = (size_t)batch * num_heads * pl.nsplit * (DH + 2) * sizeof(float);
   if (workspace_bytes < need) return OMNI_ENOMEM;
   DecodeArgs a;
@@ -985,6 +1152,7 @@ static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, co
   a.rope = (const float*)rope_cos_sin_f32; a.rope_max_pos = rope_max_pos;
   a.part_ml = (float*)workspace;
   a.part_o = a.part_ml + (size_t)batch * num_heads * pl.nsplit * 2;
+  a.fg = FgArgs{};
   dim3 grid(pl.nsplit, num_kv_heads * (group / pl.g), batch);
   hipStream_t st = (hipStream_t)stream;
   if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;  // context beyond 64 splits x 2048 tokens
@@ -1049,4 +1217,74 @@ extern "C" int omni_kv4_decode_attention_partial(const void* q_f16, const void* 
   return decode_common(nullptr, q_f16, k_f16, v_f16, q_stride, kv_stride, kv_pointers_i64, lengths_i32, batch,
                        max_blocks, num_heads, num_kv_heads, head_dim, tokens_per_block, max_context,
                        rope_cos_sin_f32, rope_max_pos, workspace, workspace_bytes, stream, true, nsplit_out);
+}
+
+// LServe fine-grained decode attention: retrieval heads (optionally restricted to the pages in
+// dynamic_sparse_page_idx [B,Hq,num_dynamic_pages]) + streaming heads; replaces
+// fused_attention_fine_grained_{dense,sparse}.single_query_attention (KV4 with zeros).
+extern "C" int omni_kv4_decode_attention_fine_grained(
+    void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride, int64_t kv_stride,
+    const void* retrieval_kv_pointers_i64, const void* streaming_kv_pointers_i64,
+    const void* retrieval_head_flags_i32, const void* head_rank_table_i32, const void* lengths_i32,
+    const void* dynamic_sparse_page_idx_i32, int num_dynamic_pages, int tokens_per_sub_chunk, int batch,
+    int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads, int num_retrieval_kv_heads,
+    int num_streaming_kv_heads, int head_dim, int tokens_per_block, int sink_tokens, int local_tokens,
+    int sink_blocks, int local_blocks, int max_context, const void* rope_cos_sin_f32, int rope_max_pos,
+    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!out_f16 || !q_f16 || !k_f16 || !v_f16 || !lengths_i32 || !rope_cos_sin_f32 || !workspace) return OMNI_EINVAL;
+  if (head_dim != DH || batch < 1 || num_heads < 1 || num_kv_heads < 1 || num_heads % num_kv_heads != 0 ||
+      tokens_per_block < 16 || (tokens_per_block & (tokens_per_block - 1)) != 0 || max_context < 1 ||
+      rope_max_pos < 1)
+    return OMNI_EINVAL;
+  const int group = num_heads / num_kv_heads;
+  if (group != 1 && group != 2 && group % 4 != 0) return OMNI_EINVAL;
+  DecodeArgs a;
+  int rc = fill_fg(&a.fg, streaming_kv_pointers_i64, retrieval_head_flags_i32, head_rank_table_i32, streaming_blocks,
+                   num_kv_heads, num_retrieval_kv_heads, num_streaming_kv_heads, sink_tokens, local_tokens,
+                   sink_blocks, local_blocks);
+  if (rc != OMNI_OK) return rc;
+  if (num_retrieval_kv_heads > 0 && !retrieval_kv_pointers_i64) return OMNI_EINVAL;
+  const bool sparse = dynamic_sparse_page_idx_i32 != nullptr;
+  if (sparse && (num_dynamic_pages < 1 || tokens_per_sub_chunk < 1 || tokens_per_block % tokens_per_sub_chunk != 0))
+    return OMNI_EINVAL;
+  a.fg.dyn = (const int*)dynamic_sparse_page_idx_i32;
+  a.fg.num_dyn = sparse ? num_dynamic_pages : 0;
+  a.fg.sub_chunk = sparse ? tokens_per_sub_chunk : 0;
+  // longest attended token list of any head
+  int span = sparse ? num_dynamic_pages * tokens_per_block : max_context;
+  if (num_streaming_kv_heads > 0 && num_retrieval_kv_heads == 0) span = sink_tokens + local_tokens;
+  if (span > max_context && !sparse) span = max_context;
+  if (span < 1) span = 1;
+  const DecodePlan pl = plan_decode(batch, num_heads, num_kv_heads, span, tokens_per_block, sparse, true);
+  if ((long long)pl.nsplit * pl.split_tokens < span) return OMNI_EINVAL;
+  if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;
+  const size_t need = (size_t)batch * num_heads * pl.nsplit * (DH + 2) * sizeof(float);
+  if (workspace_bytes < need) return OMNI_ENOMEM;
+  a.out = (half_t*)out_f16; a.q = (const half_t*)q_f16; a.k = (const half_t*)k_f16; a.v = (const half_t*)v_f16;
+  a.q_stride = q_stride; a.kv_stride = kv_stride;
+  a.kv_pointers = (const int64_t*)retrieval_kv_pointers_i64; a.lengths = (const int*)lengths_i32;
+  a.batch = batch; a.max_blocks = retrieval_blocks; a.num_heads = num_heads; a.num_kv_heads = num_kv_heads;
+  a.lay = make_layout(tokens_per_block, num_kv_heads);
+  a.nsplit = pl.nsplit; a.split_tokens = pl.split_tokens;
+  a.rope = (const float*)rope_cos_sin_f32; a.rope_max_pos = rope_max_pos;
+  a.part_ml = (float*)workspace;
+  a.part_o = a.part_ml + (size_t)batch * num_heads * pl.nsplit * 2;
+  dim3 grid(pl.nsplit, num_kv_heads * (group / pl.g), batch);
+  hipStream_t st = (hipStream_t)stream;
+#define OMNI_LAUNCH_FG(G_)                                                                              \
+  do {                                                                                                  \
+    if (pl.lds_bytes > 64 * 1024)                                                                       \
+      (void)hipFuncSetAttribute((const void*)kv4_decode_mfma_kernel<G_, false, true>,                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);         \
+    hipLaunchKernelGGL((kv4_decode_mfma_kernel<G_, false, true>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); \
+  } while (0)
+  switch (pl.g) {
+    case 1: OMNI_LAUNCH_FG(1); break;
+    case 2: OMNI_LAUNCH_FG(2); break;
+    default: OMNI_LAUNCH_FG(4); break;
+  }
+#undef OMNI_LAUNCH_FG
+  hipLaunchKernelGGL(kv4_decode_merge_kernel, dim3(batch * num_heads), dim3(128), 0, st, (half_t*)out_f16, a.part_ml,
+                     a.part_o, pl.nsplit);
+  return omni_launch_status();
 }

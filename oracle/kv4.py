@@ -103,10 +103,12 @@ def kv4_dequant(packed: np.ndarray, scale_h, zero_h, fp16_math: bool = True) -> 
 class PagedKV4:
     """Page-pool view helper (numpy).  pool: uint8 [num_pages, page_bytes]."""
 
-    def __init__(self, num_pages, num_kv_heads, head_dim, tokens_per_block=64, fill=0):
+    def __init__(self, num_pages, num_kv_heads, head_dim, tokens_per_block=64, fill=0, stats_sub_chunk=0):
         self.H, self.D, self.TPB = num_kv_heads, head_dim, tokens_per_block
         self.bytes_per_seq = num_kv_heads * tokens_per_block * (head_dim // 2)
         self.page_bytes = page_bytes(num_kv_heads, head_dim, tokens_per_block)
+        if stats_sub_chunk:   # K page with min/max statistics appended (cache_engine.py:75-88)
+            self.page_bytes += 2 * (tokens_per_block // stats_sub_chunk) * num_kv_heads * head_dim * 2
         self.pool = np.full((num_pages, self.page_bytes), fill, np.uint8)
 
     def data(self, page):
@@ -281,4 +283,134 @@ def page_selector(q_h, lengths, retrieval_head_flags, head_rank_table, pool, k_t
                 a = (qr[h] * kmax[c % grp, rank]).astype(F16)
                 bb = (qr[h] * kmin[c % grp, rank]).astype(F16)
                 out[b, h, c] = np.maximum(a, bb).astype(np.float64).sum()
+    return out
+
+
+# ---- LServe fine-grained caches: retrieval + streaming heads ------------------------------------------
+# Citations: fused_attention_fine_grained/fine_grained_common/applyBiasRopeUpdateKVCache.h:296-311
+# (which tokens a head stores), common/kvCacheUtils.h:119-126 (ring of streaming pages),
+# fused_attention_fine_grained/dense_attention/decoderMaskedMultiheadAttentionTemplate.hpp:1475,1486-1490,1537
+# (which cached tokens a streaming head attends to), sparse_attention/...Template.hpp:1566-1570,1632-1641
+# (dynamic page indirection), :1414-1429 (statistics update on append), SURVEY.md Appendix B.
+
+def ring_block(blk: int, sink_blocks: int, local_blocks: int) -> int:
+    return blk if blk < sink_blocks else sink_blocks + (blk - sink_blocks) % local_blocks
+
+
+class FineGrainedKV:
+    """The two page pools of one layer: retrieval (K pages optionally with min/max statistics) and streaming
+    (ring of sink_blocks + local_blocks pages per sequence).  Tables hold page indices [B][blocks]."""
+
+    def __init__(self, retr_k, retr_v, retr_k_table, retr_v_table, strm_k, strm_v, strm_k_table, strm_v_table,
+                 flags, rank, sink, local, sink_blocks, local_blocks, sub_chunk=0):
+        self.retr_k, self.retr_v, self.retr_k_table, self.retr_v_table = retr_k, retr_v, retr_k_table, retr_v_table
+        self.strm_k, self.strm_v, self.strm_k_table, self.strm_v_table = strm_k, strm_v, strm_k_table, strm_v_table
+        self.flags, self.rank = [int(f) for f in flags], [int(r) for r in rank]
+        self.sink, self.local, self.sink_blocks, self.local_blocks = sink, local, sink_blocks, local_blocks
+        self.sub_chunk = sub_chunk
+
+    def locate(self, b, hk, t):
+        """(k cache, v cache, k page, v page, slot) of logical token t of kv head hk."""
+        if self.flags[hk]:
+            blk = t // self.retr_k.TPB
+            return (self.retr_k, self.retr_v, int(self.retr_k_table[b][blk]), int(self.retr_v_table[b][blk]),
+                    t % self.retr_k.TPB)
+        blk = ring_block(t // self.strm_k.TPB, self.sink_blocks, self.local_blocks)
+        return (self.strm_k, self.strm_v, int(self.strm_k_table[b][blk]), int(self.strm_v_table[b][blk]),
+                t % self.strm_k.TPB)
+
+    def write(self, b, hk, t, k_row, v_row, update_stats=False):
+        kc, vc, kp, vp, slot = self.locate(b, hk, t)
+        kc.write_token(kp, slot, self.rank[hk], k_row)
+        vc.write_token(vp, slot, self.rank[hk], v_row)
+        if update_stats and self.flags[hk] and self.sub_chunk:
+            kmax, kmin = pool_views(kc.pool[kp], kc.H, kc.D, kc.TPB, self.sub_chunk)
+            sc = slot // self.sub_chunk
+            kf = np.asarray(k_row, F16)
+            kmax[sc, self.rank[hk]] = np.fmax(kmax[sc, self.rank[hk]], kf)
+            kmin[sc, self.rank[hk]] = np.fmin(kmin[sc, self.rank[hk]], kf)
+
+    def read(self, b, hk, toks):
+        """Dequantised K, V float32 [len(toks), D] of the logical tokens `toks`."""
+        D = self.retr_k.D if self.flags[hk] else self.strm_k.D
+        K = np.zeros((len(toks), D), F32)
+        V = np.zeros((len(toks), D), F32)
+        r = self.rank[hk]
+        for i, t in enumerate(toks):
+            kc, vc, kp, vp, slot = self.locate(b, hk, int(t))
+            K[i] = kv4_dequant(kc.data(kp)[r, slot], kc.scales(kp)[r, slot], kc.zeros(kp)[r, slot])
+            V[i] = kv4_dequant(vc.data(vp)[r, slot], vc.scales(vp)[r, slot], vc.zeros(vp)[r, slot])
+        return K, V
+
+
+def prefill_write_fine_grained(qkv_h, seq_lens, fg: FineGrainedKV, num_heads, num_kv_heads, head_dim, rope_base,
+                               rope_scale_factor=1.0):
+    """apply_bias_rope_update_kv_cache with both head classes: RoPE q,k in place; a retrieval head stores every
+    token, a streaming head only pos < sink or pos >= len - local (in its ring)."""
+    qkv = np.array(qkv_h, dtype=F16, copy=True)
+    D, Hq, Hk = head_dim, num_heads, num_kv_heads
+    tok = 0
+    for b, L in enumerate(seq_lens):
+        L = int(L)
+        for p in range(L):
+            row = qkv[tok]
+            q = row[: Hq * D].reshape(Hq, D)
+            k = row[Hq * D: (Hq + Hk) * D].reshape(Hk, D)
+            v = row[(Hq + Hk) * D:].reshape(Hk, D)
+            q[:] = rope_neox(q, np.full((Hq,), p), rope_base, 1.0 / rope_scale_factor)
+            k[:] = rope_neox(k, np.full((Hk,), p), rope_base, 1.0 / rope_scale_factor)
+            for h in range(Hk):
+                if fg.flags[h] or p < fg.sink or p >= L - fg.local:
+                    fg.write(b, h, p, k[h], v[h])
+            tok += 1
+    return qkv
+
+
+def attended_tokens(fg: FineGrainedKV, b, hk, hq, tlen, dyn_pages=None):
+    """Logical indices of the cached tokens q head hq attends, in kernel order."""
+    if fg.flags[hk]:
+        if dyn_pages is None:
+            return np.arange(tlen, dtype=np.int64)
+        tpb = fg.retr_k.TPB
+        P = dyn_pages.shape[-1]
+        nvirt = (P - 1) * tpb + (tlen - 1) % tpb + 1 if tlen > 0 else 0
+        i = np.arange(nvirt, dtype=np.int64)
+        return np.asarray(dyn_pages[b, hq], np.int64)[i // tpb] * tpb + i % tpb
+    valid = min(fg.sink + fg.local - 1, tlen)
+    gap = tlen - valid
+    i = np.arange(valid, dtype=np.int64)
+    return np.where(i < fg.sink, i, i + gap)
+
+
+def decode_attention_fine_grained(q_h, k_h, v_h, lengths, fg: FineGrainedKV, rope_base, rope_scale_factor=1.0,
+                                  dyn_pages=None):
+    """fused_attention_fine_grained_{dense,sparse}.single_query_attention (KV4 + zeros).  The current token
+    enters un-quantised and is appended (quantised) to the pool of its head class; with dyn_pages (sparse
+    variant) the appended key is folded into the page statistics.  f64 softmax reference -> fp16 [B,Hq,D]."""
+    q_h = np.asarray(q_h, F16)
+    B, Hq, D = q_h.shape
+    Hk = k_h.shape[1]
+    g = Hq // Hk
+    inv_sqrt = 1.0 / np.sqrt(D)
+    out = np.zeros((B, Hq, D), F16)
+    for b in range(B):
+        tlen = int(lengths[b]) - 1
+        qr = rope_neox(q_h[b], np.full((Hq,), tlen), rope_base, 1.0 / rope_scale_factor)
+        kr = rope_neox(k_h[b], np.full((Hk,), tlen), rope_base, 1.0 / rope_scale_factor)
+        vr = np.asarray(v_h[b], F16)
+        for hk in range(Hk):
+            cache = {}
+            for hq in range(hk * g, (hk + 1) * g):
+                toks = attended_tokens(fg, b, hk, hq, tlen, dyn_pages)
+                key = toks.tobytes()
+                if key not in cache:
+                    cache[key] = fg.read(b, hk, toks)
+                Kc, Vc = cache[key]
+                qf = qr[hq].astype(np.float64)
+                s = np.concatenate([Kc.astype(np.float64) @ qf, [np.dot(qf, kr[hk].astype(np.float64))]]) * inv_sqrt
+                e = np.exp(s - s.max())
+                p = e / (e.sum() + 1e-6)
+                vals = np.concatenate([Vc.astype(np.float64), vr[hk][None, :].astype(np.float64)], axis=0)
+                out[b, hq] = (p[:, None] * vals).sum(axis=0).astype(F16)
+            fg.write(b, hk, tlen, kr[hk], vr[hk], update_stats=dyn_pages is not None)
     return out

@@ -45,7 +45,9 @@ REFERENCE_API = {
     "activation_ops": {"silu_and_mul": 2},
     "fused_attention_pure_dense": {"single_query_attention": 15, "apply_bias_rope_update_kv_cache": 15,
                                    "compute_padding_offsets": 3},
-    "fused_attention_fine_grained_dense": {"apply_bias_rope_update_kv_cache": 27, "compute_padding_offsets": 3},
+    "fused_attention_fine_grained_dense": {"apply_bias_rope_update_kv_cache": 27, "compute_padding_offsets": 3,
+                                           "single_query_attention": 27},
+    "fused_attention_fine_grained_sparse": {"single_query_attention": 30},
 }
 
 THIRD_PARTY_API = {   # un-vendored packages the reference imports for prefill attention

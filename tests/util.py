@@ -49,11 +49,10 @@ class GpuPagedKV:
     def __init__(self, oracle_k, oracle_v, k_table_idx, v_table_idx):
         self.kpool = to_dev(oracle_k.pool.copy())
         self.vpool = to_dev(oracle_v.pool.copy())
-        pb = oracle_k.page_bytes
         B, M = k_table_idx.shape
         tab = np.zeros((B, 2, M), np.int64)
-        tab[:, 0, :] = self.kpool.data_ptr() + k_table_idx.astype(np.int64) * pb
-        tab[:, 1, :] = self.vpool.data_ptr() + v_table_idx.astype(np.int64) * pb
+        tab[:, 0, :] = self.kpool.data_ptr() + k_table_idx.astype(np.int64) * oracle_k.page_bytes
+        tab[:, 1, :] = self.vpool.data_ptr() + v_table_idx.astype(np.int64) * oracle_v.page_bytes
         self.table = to_dev(tab)
 
     def pools(self):
