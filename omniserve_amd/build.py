@@ -55,7 +55,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        extra = os.environ.get("OMNI_HIPCC_EXTRA", "").split()   # tuning experiments only (e.g. -DOMNI_GEMM_MIN_BLOCKS=2)
+        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -282,33 +282,45 @@ __device__ __forceinline__ float block_max_small(float m, float* red) {
 }
 
 // ---- sources: 8 consecutive fp16-valued elements starting at element i of a row --------------------
+// A source is split into fetch() (loads only) and finish() (arithmetic, in-place side effects).  Sources
+// with BATCH = true have their fetches for all of a thread's vectors issued back to back, branch-free
+// (out-of-range vectors re-read element 0), before any finish(): these kernels are latency chains and a
+// branch between two loads costs a whole extra memory round trip.
 struct SrcPlain {
+  static constexpr bool BATCH = true;
+  struct Raw { v8h t; };
   const half_t* row;
   int stride;
   __device__ __forceinline__ SrcPlain at_row(int m) const { return SrcPlain{row + (size_t)m * stride, stride}; }
-  __device__ __forceinline__ void load8(int i, float (&x)[VT]) const {
-    const v8h t = *reinterpret_cast<const v8h*>(row + i);
+  __device__ __forceinline__ void fetch(int i, Raw& r) const { r.t = *reinterpret_cast<const v8h*>(row + i); }
+  __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
 #pragma unroll
-    for (int e = 0; e < VT; ++e) x[e] = (float)t[e];
+    for (int e = 0; e < VT; ++e) x[e] = (float)r.t[e];
   }
 };
 struct SrcAdd {  // residual += delta (fp16 add), in place
+  static constexpr bool BATCH = true;
+  struct Raw { v8h a, d; };
   half_t* res;
   const half_t* delta;
   int stride;
   __device__ __forceinline__ SrcAdd at_row(int m) const {
     return SrcAdd{res + (size_t)m * stride, delta + (size_t)m * stride, stride};
   }
-  __device__ __forceinline__ void load8(int i, float (&x)[VT]) const {
-    const v8h a = *reinterpret_cast<const v8h*>(res + i);
-    const v8h d = *reinterpret_cast<const v8h*>(delta + i);
+  __device__ __forceinline__ void fetch(int i, Raw& r) const {
+    r.a = *reinterpret_cast<const v8h*>(res + i);
+    r.d = *reinterpret_cast<const v8h*>(delta + i);
+  }
+  __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
     v8h o;
 #pragma unroll
-    for (int e = 0; e < VT; ++e) { o[e] = (half_t)((float)a[e] + (float)d[e]); x[e] = (float)o[e]; }
+    for (int e = 0; e < VT; ++e) { o[e] = (half_t)((float)r.a[e] + (float)r.d[e]); x[e] = (float)o[e]; }
     *reinterpret_cast<v8h*>(res + i) = o;
   }
 };
 struct SrcSlabAddChn {  // residual += h(per-channel GEMM epilogue(sum of split-K slabs)), in place
+  static constexpr bool BATCH = false;   // 76 registers per vector: fetched per valid vector (hidden <= 4096: one)
+  struct Raw { v4i s0, s1; v8h a, sw, sz; };
   half_t* res;
   const int32_t* slab;    // [sk][M][N]
   size_t sstride;         // M*N
@@ -326,7 +338,10 @@ struct SrcSlabAddChn {  // residual += h(per-channel GEMM epilogue(sum of split-
     r.as = (float)asum[m];
     return r;
   }
-  __device__ __forceinline__ void load8(int i, float (&x)[VT]) const {
+  __device__ __forceinline__ void fetch(int i, Raw& r) const {
+    r.a = *reinterpret_cast<const v8h*>(res + i);
+    r.sw = *reinterpret_cast<const v8h*>(wscales + i);
+    r.sz = *reinterpret_cast<const v8h*>(wsz + i);
     v4i s0 = (v4i){0, 0, 0, 0}, s1 = s0;
     {  // up to 8 slabs: all loads in flight at once (slabs beyond sk re-read slab 0 and are dropped)
       v4i t0[8], t1[8];
@@ -346,50 +361,82 @@ struct SrcSlabAddChn {  // residual += h(per-channel GEMM epilogue(sum of split-
       s0 += *reinterpret_cast<const v4i*>(slab + (size_t)k * sstride + i);
       s1 += *reinterpret_cast<const v4i*>(slab + (size_t)k * sstride + i + 4);
     }
-    const v8h a = *reinterpret_cast<const v8h*>(res + i);
-    const v8h sw = *reinterpret_cast<const v8h*>(wscales + i);
-    const v8h sz = *reinterpret_cast<const v8h*>(wsz + i);
+    r.s0 = s0; r.s1 = s1;
+  }
+  __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
     v8h o;
 #pragma unroll
     for (int e = 0; e < VT; ++e) {
-      const int acc = e < 4 ? s0[e] : s1[e - 4];
-      float t = (float)acc * (float)sw[e];
+      const int acc = e < 4 ? r.s0[e] : r.s1[e - 4];
+      float t = (float)acc * (float)r.sw[e];
       t = t * sa;
-      const float c = (float)sz[e] * as;
+      const float c = (float)r.sz[e] * as;
       const half_t ep = (half_t)(t - c);                       // = the GEMM's fp16 output
-      o[e] = (half_t)((float)a[e] + (float)ep);
+      o[e] = (half_t)((float)r.a[e] + (float)ep);
       x[e] = (float)o[e];
     }
     *reinterpret_cast<v8h*>(res + i) = o;
   }
 };
 struct SrcSilu {  // h(h(silu(gate)) * up) of a [2d] row
+  static constexpr bool BATCH = true;
+  struct Raw { v8h a, b; };
   const half_t* row;
   int d;
   __device__ __forceinline__ SrcSilu at_row(int m) const { return SrcSilu{row + (size_t)m * 2 * d, d}; }
-  __device__ __forceinline__ void load8(int i, float (&x)[VT]) const {
-    const v8h a = *reinterpret_cast<const v8h*>(row + i);
-    const v8h b = *reinterpret_cast<const v8h*>(row + d + i);
+  __device__ __forceinline__ void fetch(int i, Raw& r) const {
+    r.a = *reinterpret_cast<const v8h*>(row + i);
+    r.b = *reinterpret_cast<const v8h*>(row + d + i);
+  }
+  __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
 #pragma unroll
-    for (int e = 0; e < VT; ++e) x[e] = (float)silu_mul_h(a[e], b[e]);
+    for (int e = 0; e < VT; ++e) x[e] = (float)silu_mul_h(r.a[e], r.b[e]);
   }
 };
 
 struct SrcAttnMerge {  // merged decode-attention output (flash-decoding partials) of one token: [Hq*128] fp16
+  static constexpr bool BATCH = false;
+  static constexpr int NS = 8;   // splits whose loads are issued together (further ones: plain loop)
+  struct Raw { float m[NS], l[NS]; v4f a[NS], b[NS]; };
   const float* part_ml;   // [B,Hq,S,2]
   const float* part_o;    // [B,Hq,S,128]
   int nsplit, num_heads, token;
   __device__ __forceinline__ SrcAttnMerge at_row(int m) const { SrcAttnMerge r = *this; r.token = m; return r; }
-  __device__ __forceinline__ void load8(int i, float (&x)[VT]) const {
+  __device__ __forceinline__ void fetch(int i, Raw& r) const {
     const size_t bh = (size_t)token * num_heads + (i >> 7);
     const int d = i & 127;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {   // branch-free: splits >= nsplit re-read split 0 and get weight 0
+      const size_t pi = bh * nsplit + (s < nsplit ? s : 0);
+      const float2 ml = *reinterpret_cast<const float2*>(part_ml + pi * 2);
+      r.m[s] = s < nsplit ? ml.x : -1e30f;
+      r.l[s] = ml.y;
+      r.a[s] = *reinterpret_cast<const v4f*>(part_o + pi * 128 + d);
+      r.b[s] = *reinterpret_cast<const v4f*>(part_o + pi * 128 + d + 4);
+    }
+  }
+  __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
+    const size_t bh = (size_t)token * num_heads + (i >> 7);
+    const int d = i & 127;
+    // same operation order as kv4_decode_merge_kernel: max over s, then s ascending accumulation
     float M = -1e30f;
-    for (int s = 0; s < nsplit; ++s) M = __builtin_fmaxf(M, part_ml[(bh * nsplit + s) * 2]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) M = __builtin_fmaxf(M, r.m[s]);
+    for (int s = NS; s < nsplit; ++s) M = __builtin_fmaxf(M, part_ml[(bh * nsplit + s) * 2]);
     float l = 0.0f;
     float o[VT];
 #pragma unroll
     for (int e = 0; e < VT; ++e) o[e] = 0.0f;
-    for (int s = 0; s < nsplit; ++s) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (s < nsplit) {
+        const float w = __expf(r.m[s] - M);
+        l += w * r.l[s];
+#pragma unroll
+        for (int e = 0; e < VT; ++e) o[e] += w * (e < 4 ? r.a[s][e] : r.b[s][e - 4]);
+      }
+    }
+    for (int s = NS; s < nsplit; ++s) {
       const float w = __expf(part_ml[(bh * nsplit + s) * 2] - M);
       l += w * part_ml[(bh * nsplit + s) * 2 + 1];
       const v4f a = *reinterpret_cast<const v4f*>(part_o + (bh * nsplit + s) * 128 + d);
@@ -460,11 +507,26 @@ __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, 
   const Src src = src0.at_row(blockIdx.x);
   float x[RV][VT];
   float amax = 0.0f;
+  typename Src::Raw raw[Src::BATCH ? RV : 1];
+  if constexpr (Src::BATCH) {
+#pragma unroll
+    for (int it = 0; it < RV; ++it) {
+      const int i = (p + it * RT) * VT;
+      src.fetch(i < hidden ? i : 0, raw[it]);
+    }
+  }
 #pragma unroll
   for (int it = 0; it < RV; ++it) {
     const int i = (p + it * RT) * VT;
     const bool ok = i < hidden;
-    if (ok) src.load8(i, x[it]);
+    if (ok) {
+      if constexpr (Src::BATCH) {
+        src.finish(i, raw[it], x[it]);
+      } else {
+        src.fetch(i, raw[0]);
+        src.finish(i, raw[0], x[it]);
+      }
+    }
 #pragma unroll
     for (int e = 0; e < VT; ++e) {
       x[it][e] = ok ? x[it][e] : 0.0f;
@@ -502,12 +564,26 @@ __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict_
   const int p = threadIdx.x;
   const Src src = src0.at_row(blockIdx.x);
   float x[RV][VT];
+  typename Src::Raw raw[Src::BATCH ? RV : 1];
+  v8h g8[RV];   // gamma is requested with the inputs, not after the statistics
+#pragma unroll
+  for (int it = 0; it < RV; ++it) {
+    const int i = (p + it * RT) * VT;
+    const int ic = i < hidden ? i : 0;
+    if constexpr (Src::BATCH) src.fetch(ic, raw[it]);
+    g8[it] = *reinterpret_cast<const v8h*>(gamma + ic);
+  }
 #pragma unroll
   for (int it = 0; it < RV; ++it) {
     const int i = (p + it * RT) * VT;
     const bool ok = i < hidden;
     if (ok) {
-      src.load8(i, x[it]);
+      if constexpr (Src::BATCH) {
+        src.finish(i, raw[it], x[it]);
+      } else {
+        src.fetch(i, raw[0]);
+        src.finish(i, raw[0], x[it]);
+      }
       *reinterpret_cast<v4f*>(xs + i) = (v4f){x[it][0], x[it][1], x[it][2], x[it][3]};
       *reinterpret_cast<v4f*>(xs + i + 4) = (v4f){x[it][4], x[it][5], x[it][6], x[it][7]};
     }
@@ -527,12 +603,11 @@ __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict_
     const int i = (p + it * RT) * VT;
     const bool ok = i < hidden;
     if (ok) {
-      const v8h g8 = *reinterpret_cast<const v8h*>(gamma + i);
       float yh[VT];
 #pragma unroll
       for (int e = 0; e < VT; ++e) {
         float y = (x[it][e] - mean) * rstd;
-        y = rounded_f32(y * (float)g8[e]);
+        y = rounded_f32(y * (float)g8[it][e]);
         x[it][e] = y;
         yh[e] = (float)(half_t)y;
         amax_h = __builtin_fmaxf(amax_h, __builtin_fabsf(yh[e]));
@@ -570,11 +645,20 @@ __global__ __launch_bounds__(RT) void rms_norm_v2_kernel(half_t* __restrict__ ou
   const int p = threadIdx.x;
   const SrcPlain src{in + (size_t)blockIdx.x * hidden, hidden};
   float x[RV][VT];
+  SrcPlain::Raw raw[RV];
+  v8h w8[RV];
+#pragma unroll
+  for (int it = 0; it < RV; ++it) {
+    const int i = (p + it * RT) * VT;
+    const int ic = i < hidden ? i : 0;
+    src.fetch(ic, raw[it]);
+    w8[it] = *reinterpret_cast<const v8h*>(weight + ic);
+  }
 #pragma unroll
   for (int it = 0; it < RV; ++it) {
     const int i = (p + it * RT) * VT;
     if (i < hidden) {
-      src.load8(i, x[it]);
+      src.finish(i, raw[it], x[it]);
       *reinterpret_cast<v4f*>(xs + i) = (v4f){x[it][0], x[it][1], x[it][2], x[it][3]};
       *reinterpret_cast<v4f*>(xs + i + 4) = (v4f){x[it][4], x[it][5], x[it][6], x[it][7]};
     }
@@ -589,12 +673,11 @@ __global__ __launch_bounds__(RT) void rms_norm_v2_kernel(half_t* __restrict__ ou
   for (int it = 0; it < RV; ++it) {
     const int i = (p + it * RT) * VT;
     if (i < hidden) {
-      const v8h w8 = *reinterpret_cast<const v8h*>(weight + i);
       v8h o;
 #pragma unroll
       for (int e = 0; e < VT; ++e) {
         const half_t t = (half_t)rounded_f32(x[it][e] * rstd);
-        o[e] = (half_t)((float)t * (float)w8[e]);
+        o[e] = (half_t)((float)t * (float)w8[it][e]);
       }
       *reinterpret_cast<v8h*>(orow + i) = o;
     }

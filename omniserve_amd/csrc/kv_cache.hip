@@ -601,13 +601,16 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
   const int sub = blockIdx.y % qg;
   const int hq0 = hk * group + sub * G;
   const int b = blockIdx.z;
-  const int tlen = p.lengths[b] - 1;
   const KvLayout lay = p.lay;
+  // The kernel is a chain of memory round trips, so the requests are ordered to need only two of them:
+  //   trip 1 (independent of the sequence length): length, page-table window, raw q / k / v rows;
+  //   trip 2: RoPE coefficients of position tlen, and every K and V byte of the split.
+  // The split geometry is fixed on the host (split s = virtual tokens [s*split_tokens, +split_tokens)),
+  // so the page window does not wait for the length.
   // head class: pool geometry and page table of this kv head
   int hrank = hk, hpool = lay.num_kv_heads, tab_blocks = p.max_blocks;
   bool streaming = false;
   const int64_t* ktab = p.kv_pointers + (size_t)b * 2 * p.max_blocks;
-  int nvirt = tlen, gap = 0;   // attended cached tokens; streaming: virtual i >= sink is token i + gap
   const int* dyn = nullptr;
   if constexpr (FG) {
     hrank = p.fg.rank[hk];
@@ -616,48 +619,67 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
     if (streaming) {
       tab_blocks = p.fg.strm_blocks;
       ktab = p.fg.strm_pointers + (size_t)b * 2 * tab_blocks;
-      nvirt = min(p.fg.sink + p.fg.local - 1, tlen);
-      gap = tlen - nvirt;
     } else if (p.fg.dyn) {
       dyn = p.fg.dyn + ((size_t)b * p.num_heads + hq0) * p.fg.num_dyn;
-      nvirt = tlen > 0 ? (p.fg.num_dyn - 1) * lay.tpb + ((tlen - 1) & (lay.tpb - 1)) + 1 : 0;
     }
   }
   const int64_t* vtab = ktab + tab_blocks;
   const int pool_bytes_per_seq = hpool * lay.tpb * ROW_BYTES;
   const float inv_sqrt_dh = 0.08838834764831845f;
-
-  int per = (nvirt + p.nsplit - 1) / p.nsplit;
-  per = (per + 15) & ~15;
-  if (per > p.split_tokens) per = p.split_tokens;
-  const int t0 = min(nvirt, split * per);
-  const int t1 = (split == p.nsplit - 1) ? min(nvirt, t0 + p.split_tokens) : min(nvirt, t0 + per);
-  const int nt = t1 - t0;
+  const int vt0 = split * p.split_tokens;
+  const int page0 = (FG && streaming) ? 0 : (vt0 >> lay.tpb_log2);
   const bool owns_cur = split == p.nsplit - 1;
-  const int page0 = (FG && streaming) ? 0 : (t0 >> lay.tpb_log2);
 
-  // ---- stage: page pointers, RoPE(q) (and k of the current token) ------------------------------
+  // ---- trip 1 -----------------------------------------------------------------------------------------
+  int64_t my_page = 0;
   if (tid < 80) {
     const int pi = tid < 40 ? tid : tid - 40;
     const int64_t* tab = tid < 40 ? ktab : vtab;
     const int pg = page0 + pi;
     if constexpr (FG) {
-      int64_t ptr = 0;
       if (streaming) {               // the whole ring (<= 40 pages, checked on the host)
-        if (pg < tab_blocks) ptr = tab[pg];
+        if (pg < tab_blocks) my_page = tab[pg];
       } else if (dyn) {              // selected pages, in selection order
         if (pg < p.fg.num_dyn) {
           const int sel = dyn[pg];
-          if (sel >= 0 && sel < tab_blocks) ptr = tab[sel];
+          if (sel >= 0 && sel < tab_blocks) my_page = tab[sel];
         }
-      } else if (pg < tab_blocks && (pg << lay.tpb_log2) <= tlen) {
-        ptr = tab[pg];
+      } else if (pg < tab_blocks) {
+        my_page = tab[pg];
       }
-      pages[tid] = ptr;
     } else {
-      pages[tid] = (pg < p.max_blocks && (pg << lay.tpb_log2) <= tlen) ? tab[pg] : 0;
+      if (pg < p.max_blocks) my_page = tab[pg];   // entries past the sequence's pages are never dereferenced
     }
   }
+  constexpr int QIT = ((G + 1) * 64 + DEC_THREADS - 1) / DEC_THREADS;
+  half_t qa[QIT], qbv[QIT];
+#pragma unroll
+  for (int j = 0; j < QIT; ++j) {
+    const int idx = tid + j * DEC_THREADS;
+    const int h = idx >> 6, i = idx & 63;
+    const half_t* src = h < G ? p.q + (size_t)b * p.q_stride + (size_t)(hq0 + h) * DH
+                              : p.k + (size_t)b * p.kv_stride + (size_t)hk * DH;   // h > G (idle slots): k again
+    qa[j] = src[i];
+    qbv[j] = src[i + 64];
+  }
+  half_t vcur_r = (half_t)0.0f;
+  if (tid < DH) vcur_r = p.v[(size_t)b * p.kv_stride + (size_t)hk * DH + tid];
+
+  const int tlen = p.lengths[b] - 1;
+  int nvirt = tlen, gap = 0;   // attended cached tokens; streaming: virtual i >= sink is token i + gap
+  if constexpr (FG) {
+    if (streaming) {
+      nvirt = min(p.fg.sink + p.fg.local - 1, tlen);
+      gap = tlen - nvirt;
+    } else if (dyn) {
+      nvirt = tlen > 0 ? (p.fg.num_dyn - 1) * lay.tpb + ((tlen - 1) & (lay.tpb - 1)) + 1 : 0;
+    }
+  }
+  const int t0 = min(nvirt, vt0);
+  const int t1 = min(nvirt, vt0 + p.split_tokens);
+  const int nt = t1 - t0;
+  if (tid < 80) pages[tid] = my_page;
+
   // virtual token -> (index into pages[], slot in the page)
   auto locate = [&](int vt, int& pidx, int& slot) {
     if (FG && streaming) {
@@ -669,29 +691,6 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
       slot = vt & (lay.tpb - 1);
     }
   };
-  {
-    const int rp = tlen < p.rope_max_pos ? tlen : p.rope_max_pos - 1;
-    const float* cs = p.rope + (size_t)rp * DH;
-    for (int idx = tid; idx < (G + 1) * 64; idx += DEC_THREADS) {
-      const int h = idx >> 6, i = idx & 63;
-      if (h == G && !owns_cur) continue;
-      const half_t* src = h < G ? p.q + (size_t)b * p.q_stride + (size_t)(hq0 + h) * DH
-                                : p.k + (size_t)b * p.kv_stride + (size_t)hk * DH;
-      const float c = cs[2 * i], sn = cs[2 * i + 1];
-      const float a = (float)src[i], bb = (float)src[i + 64];
-      const float t0f = c * a, t1f = sn * bb, t2f = c * bb, t3f = sn * a;
-      const half_t r0 = (half_t)(t0f - t1f), r1 = (half_t)(t2f + t3f);
-      if (h < G) {
-        q_lds[h * DH + perm_pos(i)] = r0;
-        q_lds[h * DH + perm_pos(i + 64)] = r1;
-      } else {
-        kcur[i] = r0; kcur[i + 64] = r1;
-        kcur_p[perm_pos(i)] = r0; kcur_p[perm_pos(i + 64)] = r1;
-      }
-    }
-    if (owns_cur && tid < DH) vcur[tid] = p.v[(size_t)b * p.kv_stride + (size_t)hk * DH + tid];
-  }
-  __syncthreads();
 
   const int ngroups = (nt + 15) >> 4;
   const int ntiles = (nt + 31) >> 5;
@@ -700,8 +699,20 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
   const int tail_off = pool_bytes_per_seq + hrank * lay.tpb * 2;
   const int zero_off = hpool * lay.tpb * 2;
 
-  // V loads are issued one batch ahead; the first batch goes out before any K work, so with the usual
-  // split sizes every K and V byte of the workgroup is requested in the same memory round trip
+  // ---- trip 2: RoPE coefficients + the first K and V batches (normally: all of the split) -------------------
+  float rc[QIT], rs[QIT];
+  {
+    const int rp = tlen < p.rope_max_pos ? tlen : p.rope_max_pos - 1;
+    const float* cs = p.rope + (size_t)rp * DH;
+#pragma unroll
+    for (int j = 0; j < QIT; ++j) {
+      const int i = (tid + j * DEC_THREADS) & 63;
+      const float2 t = *reinterpret_cast<const float2*>(cs + 2 * i);
+      rc[j] = t.x; rs[j] = t.y;
+    }
+  }
+  __syncthreads();   // pages[] visible
+
   const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
   const size_t vhead_off = (size_t)hrank * lay.tpb * ROW_BYTES + vpiece * 16;
   uint4 vraw[MF_UT][2];
@@ -722,7 +733,48 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
         vze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
       }
   };
-  load_v_batch(wave);
+  const size_t khead_off = (size_t)hrank * lay.tpb * ROW_BYTES + l4 * 16;  // lane: token l15, 16-B piece l4
+  uint4 kraw[MF_UK];
+  half_t ksc[MF_UK], kze[MF_UK];
+  auto load_k_batch = [&](int g0) {
+#pragma unroll
+    for (int u = 0; u < MF_UK; ++u) {
+      const int ti = (g0 + u * DEC_WAVES) * 16 + l15;
+      const int tok = ti < nt ? t0 + ti : t0;
+      int pidx, slot;
+      locate(tok, pidx, slot);
+      const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[pidx]);
+      kraw[u] = *reinterpret_cast<const uint4*>(pg + khead_off + (size_t)slot * ROW_BYTES);
+      const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
+      ksc[u] = tail[0];
+      kze[u] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
+    }
+  };
+  if (nt > 0) {   // (workgroup-uniform) an empty split has no valid page to touch
+    load_k_batch(wave);
+    load_v_batch(wave);
+  }
+
+  // RoPE(q) (and k of the current token) into LDS while the cache bytes are in flight
+#pragma unroll
+  for (int j = 0; j < QIT; ++j) {
+    const int idx = tid + j * DEC_THREADS;
+    const int h = idx >> 6, i = idx & 63;
+    if (h > G || (h == G && !owns_cur)) continue;
+    const float c = rc[j], sn = rs[j];
+    const float a = (float)qa[j], bb = (float)qbv[j];
+    const float t0f = c * a, t1f = sn * bb, t2f = c * bb, t3f = sn * a;
+    const half_t r0 = (half_t)(t0f - t1f), r1 = (half_t)(t2f + t3f);
+    if (h < G) {
+      q_lds[h * DH + perm_pos(i)] = r0;
+      q_lds[h * DH + perm_pos(i + 64)] = r1;
+    } else {
+      kcur[i] = r0; kcur[i + 64] = r1;
+      kcur_p[perm_pos(i)] = r0; kcur_p[perm_pos(i + 64)] = r1;
+    }
+  }
+  if (owns_cur && tid < DH) vcur[tid] = vcur_r;
+  __syncthreads();
 
   // ---- pass 1: scores = q.K / sqrt(Dh) on MFMA ------------------------------------------------------
   float mloc = -1e30f;   // running max of this lane's head column (valid for l15 < G)
@@ -731,22 +783,12 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx)
       qb[sidx] = *reinterpret_cast<const v8h*>(q_lds + jh * DH + 32 * l4 + 8 * sidx);
-    const size_t khead_off = (size_t)hrank * lay.tpb * ROW_BYTES + l4 * 16;  // lane: token l15, 16-B piece l4
     for (int g0 = wave; g0 < ngroups; g0 += DEC_WAVES * MF_UK) {
       uint4 raw[MF_UK];
       half_t sc[MF_UK], ze[MF_UK];
 #pragma unroll
-      for (int u = 0; u < MF_UK; ++u) {
-        const int ti = (g0 + u * DEC_WAVES) * 16 + l15;
-        const int tok = ti < nt ? t0 + ti : t0;
-        int pidx, slot;
-        locate(tok, pidx, slot);
-        const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[pidx]);
-        raw[u] = *reinterpret_cast<const uint4*>(pg + khead_off + (size_t)slot * ROW_BYTES);
-        const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
-        sc[u] = tail[0];
-        ze[u] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
-      }
+      for (int u = 0; u < MF_UK; ++u) { raw[u] = kraw[u]; sc[u] = ksc[u]; ze[u] = kze[u]; }
+      if (g0 + DEC_WAVES * MF_UK < ngroups) load_k_batch(g0 + DEC_WAVES * MF_UK);   // (rare) next batch
 #pragma unroll
       for (int u = 0; u < MF_UK; ++u) {
         const int gbase = (g0 + u * DEC_WAVES) * 16;
@@ -924,7 +966,10 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
     const float inv = 1.0f / (float)scale_h, z = (float)zero_h;
     int blk = tlen >> lay.tpb_log2;
     if (FG && streaming) blk = ring_block(blk, p.fg.sink_blocks, p.fg.local_blocks);
-    uint8_t* pg = reinterpret_cast<uint8_t*>(tab[blk]);
+    // the page pointer normally sits in the LDS window already (no dependent load at the kernel's end)
+    const int wi = blk - page0;
+    const bool in_window = !(FG && dyn != nullptr) && wi >= 0 && wi < 40;
+    uint8_t* pg = reinterpret_cast<uint8_t*>(in_window ? pages[(wave == 0 ? 0 : 40) + wi] : tab[blk]);
     const int slot = tlen & (lay.tpb - 1);
     uint8_t* dst = pg + ((size_t)hrank * lay.tpb + slot) * ROW_BYTES;
     const uint32_t c0 = kv4_code(x0, inv, z), c1 = kv4_code(x1, inv, z);

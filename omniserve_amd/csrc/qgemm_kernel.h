@@ -65,8 +65,11 @@ __device__ __forceinline__ half_t epilogue(int acc, float sw, float sa, float sz
 
 // One workgroup = WAVES waves; wave w owns output channels [64*(WAVES*bx + w), +64);
 // all waves share the LDS-staged activation tile of MB*16 rows.
+#ifndef OMNI_GEMM_MIN_BLOCKS
+#define OMNI_GEMM_MIN_BLOCKS 2
+#endif
 template <int MB, int MODE, int WAVES, bool TO_SLAB, bool NT>
-__global__ __launch_bounds__(64 * WAVES) void w4a8_gemm_kernel(GemmArgs p) {
+__global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
   constexpr int NTHREADS = 64 * WAVES;
   constexpr int A_LOADS = (MT * KCHUNK / 16 + NTHREADS - 1) / NTHREADS;  // 16-B pieces per thread
@@ -132,13 +135,15 @@ __global__ __launch_bounds__(64 * WAVES) void w4a8_gemm_kernel(GemmArgs p) {
         *reinterpret_cast<uint4*>(&lds[buf][(ks * MT + m) * 64 + g * 16]) = areg[j];
       } else {
         // kk = 16-byte piece: kp = k-pair (64 k), tp = tile parity, d = k5;
-        // piece bytes [e*4+f] scatter to [(kp*MT+m)*64 + e*16 + tp*8 + d*4 + f]
+        // piece bytes [e*4+f] scatter to [(kp*MT+m)*64 + pos(e)*16 + tp*8 + d*4 + f], pos(e) = (e+kp)&3:
+        // the rotation spreads the four k-pairs of one ds_write over all 64 banks (without it the
+        // k-pair stride of MT*64 B maps them onto the same bank: a 4-way conflict on every write)
         const int kp = kk >> 2, tp = (kk >> 1) & 1, d = kk & 1;
         uint8_t* dst = &lds[buf][(kp * MT + m) * 64 + tp * 8 + d * 4];
-        *reinterpret_cast<uint32_t*>(dst + 0) = areg[j].x;
-        *reinterpret_cast<uint32_t*>(dst + 16) = areg[j].y;
-        *reinterpret_cast<uint32_t*>(dst + 32) = areg[j].z;
-        *reinterpret_cast<uint32_t*>(dst + 48) = areg[j].w;
+        *reinterpret_cast<uint32_t*>(dst + ((0 + kp) & 3) * 16) = areg[j].x;
+        *reinterpret_cast<uint32_t*>(dst + ((1 + kp) & 3) * 16) = areg[j].y;
+        *reinterpret_cast<uint32_t*>(dst + ((2 + kp) & 3) * 16) = areg[j].z;
+        *reinterpret_cast<uint32_t*>(dst + ((3 + kp) & 3) * 16) = areg[j].w;
       }
     }
   };
@@ -221,8 +226,8 @@ __global__ __launch_bounds__(64 * WAVES) void w4a8_gemm_kernel(GemmArgs p) {
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          const v4i bf = *reinterpret_cast<const v4i*>(
-              abuf + ((s * MT + mb * 16 + (lane & 15)) * 4 + (lane >> 4)) * 16);
+          const int pos = (MODE == MODE_W8) ? (lane >> 4) : (((lane >> 4) + s) & 3);
+          const v4i bf = *reinterpret_cast<const v4i*>(abuf + ((s * MT + mb * 16 + (lane & 15)) * 4 + pos) * 16);
 #pragma unroll
           for (int ab = 0; ab < 4; ++ab)
             acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf, acc[mb][ab], 0, 0, 0);
@@ -294,25 +299,34 @@ struct GemvCfg {
   static constexpr int WAVES = MB == 1 ? 1 : (MB == 2 ? 2 : 4);
 };
 
-template <int MB, int MODE, bool TO_SLAB>
-__global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES), 1) void w4a8_gemv_kernel(GemmArgs p) {
+//   * KW > 1 (single 64-channel group per workgroup only): KW waves split the workgroup's K-slice,
+//     each streaming its own part with its own LDS buffers and no barrier; the int32 partials meet in
+//     LDS at the end and wave w finishes the 4/KW row blocks it owns.  More waves in flight per CU
+//     without the slab round trip of a grid-level split.
+template <int MB, int MODE, bool TO_SLAB, int KW = 1>
+__global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_gemv_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
   constexpr int WAVES = GemvCfg<MB, MODE>::WAVES;
-  constexpr int NTHREADS = 64 * WAVES;
+  static_assert(KW == 1 || (WAVES == 1 && MB == 1), "in-workgroup K split is for single-wave tiles");
+  static_assert(KW == 1 || KW == 2 || KW == 4, "KW");
+  constexpr int NTHREADS = 64 * WAVES;                   // threads sharing one staged activation tile
   constexpr int WL = GemvCfg<MB, MODE>::WL;
   constexpr int RING = GemvCfg<MB, MODE>::RING;
   constexpr int RK = RING * KSTEP;                       // k per round
   constexpr int APT = (MT * RK / 16) / NTHREADS;          // 16-B activation pieces per thread per round
   static_assert((MT * RK / 16) % NTHREADS == 0, "activation round must tile the workgroup");
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2][MT * RK];
+  __shared__ __attribute__((aligned(16))) uint8_t lds_all[KW][2][MT * RK];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int ng = blockIdx.x * WAVES + wave;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int kw = KW > 1 ? wave : 0;                       // K part of this wave
+  const int tid = KW > 1 ? lane : threadIdx.x;            // index inside the staging group
+  uint8_t (*lds)[MT * RK] = lds_all[kw];
+  const int ng = KW > 1 ? blockIdx.x : blockIdx.x * WAVES + wave;
   const bool wave_active = (ng * 64) < p.N;
-  const int k_begin = blockIdx.y * p.kslice;
-  const int k_end = min(p.K, k_begin + p.kslice);
+  const int kpart = p.kslice / KW;                        // host: kslice % (64 * KW) == 0 when KW > 1
+  const int k_begin = blockIdx.y * p.kslice + kw * kpart;
+  const int k_end = min(p.K, k_begin + kpart);
   const int nsteps = (k_end - k_begin) / KSTEP;
   const int rounds = nsteps / RING;
 
@@ -334,13 +348,26 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES), 1) void w4a8_gemv_
     return *reinterpret_cast<const uint32_t*>(base + (size_t)(k / 128) * p.N + gcol);
   };
 
-  // activation staging: piece id -> (row m, 16-byte piece kk of the round)
+  // activation staging: piece id -> (row m, 16-byte piece kk of the round).  A single-wave tile (MB = 1,
+  // RING = 8) lets every ds_write cover 4 rows x 16 pieces (4 k-steps): with the rotated piece position
+  // below that is one lane per LDS bank.
+  constexpr bool QUAD_ROWS = (NTHREADS == 64 && RK / 16 == 32 && MODE != MODE_W8);
+  auto piece = [&](int j, int& m, int& kk) {
+    if constexpr (QUAD_ROWS) {
+      m = 4 * (j >> 1) + (tid >> 4);
+      kk = (tid & 15) + 16 * (j & 1);
+    } else {
+      const int id = tid + j * NTHREADS;
+      m = id / (RK / 16);
+      kk = id % (RK / 16);
+    }
+  };
   uint4 areg[APT];
   auto load_a = [&](int kr) {  // kr = first k of the round
 #pragma unroll
     for (int j = 0; j < APT; ++j) {
-      const int id = tid + j * NTHREADS;
-      const int m = id / (RK / 16), kk = id % (RK / 16);
+      int m, kk;
+      piece(j, m, kk);
       const int mc = m < p.M ? m : p.M - 1;  // rows >= M re-read the last row (results never stored)
       areg[j] = *reinterpret_cast<const uint4*>(p.A + (size_t)mc * p.K + kr + kk * 16);
     }
@@ -348,17 +375,18 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES), 1) void w4a8_gemv_
   auto store_a = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < APT; ++j) {
-      const int id = tid + j * NTHREADS;
-      const int m = id / (RK / 16), kk = id % (RK / 16);
+      int m, kk;
+      piece(j, m, kk);
       if constexpr (MODE == MODE_W8) {
         *reinterpret_cast<uint4*>(&lds[buf][((kk >> 2) * MT + m) * 64 + (kk & 3) * 16]) = areg[j];
       } else {
+        // dword e of the piece goes to 16-B slot (e + kp) & 3 of row (kp, m): see w4a8_gemm_kernel
         const int kp = kk >> 2, tp = (kk >> 1) & 1, d = kk & 1;
         uint8_t* dst = &lds[buf][(kp * MT + m) * 64 + tp * 8 + d * 4];
-        *reinterpret_cast<uint32_t*>(dst + 0) = areg[j].x;
-        *reinterpret_cast<uint32_t*>(dst + 16) = areg[j].y;
-        *reinterpret_cast<uint32_t*>(dst + 32) = areg[j].z;
-        *reinterpret_cast<uint32_t*>(dst + 48) = areg[j].w;
+        *reinterpret_cast<uint32_t*>(dst + ((0 + kp) & 3) * 16) = areg[j].x;
+        *reinterpret_cast<uint32_t*>(dst + ((1 + kp) & 3) * 16) = areg[j].y;
+        *reinterpret_cast<uint32_t*>(dst + ((2 + kp) & 3) * 16) = areg[j].z;
+        *reinterpret_cast<uint32_t*>(dst + ((3 + kp) & 3) * 16) = areg[j].w;
       }
     }
   };
@@ -368,6 +396,34 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES), 1) void w4a8_gemv_
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) acc[mb][ab] = (v4i){0, 0, 0, 0};
+
+  // epilogue operands of the row blocks this wave finishes: requested now, so the kernel does not end
+  // on a dependent HBM round trip
+  constexpr int ABW = 4 / KW;
+  const int ab0 = kw * ABW;
+  const int mcol = lane & 15;
+  const int i0 = (lane >> 4) * 4;
+  auto chan = [&](int ab) -> int {
+    if constexpr (MODE == MODE_W8) return ng * 64 + ab * 16 + i0;
+    else return ng * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
+  };
+  uint2 swv[ABW], szv[ABW];
+  half_t sav[MB], asv[MB];
+  if constexpr (!TO_SLAB) {
+#pragma unroll
+    for (int j = 0; j < ABW; ++j) {
+      const int n = wave_active ? chan(ab0 + j) : 0;
+      swv[j] = *reinterpret_cast<const uint2*>(p.wscales + n);
+      if constexpr (MODE == MODE_CHN) szv[j] = *reinterpret_cast<const uint2*>(p.wsz + n);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int m = mb * 16 + mcol;
+      const int mc = m < p.M ? m : p.M - 1;
+      sav[mb] = p.ascales[mc];
+      if constexpr (MODE == MODE_CHN) asv[mb] = p.asum[mc];
+    }
+  }
 
   auto unpack = [&](const uint4 (&w)[WL], uint32_t sc4, uint32_t zr4, v4i (&wa)[4]) {
     if constexpr (MODE == MODE_W8) {
@@ -396,7 +452,8 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES), 1) void w4a8_gemv_
   auto mma_step = [&](const v4i (&wa)[4], const uint8_t* abuf, int s) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const v4i bf = *reinterpret_cast<const v4i*>(abuf + ((s * MT + mb * 16 + (lane & 15)) * 4 + (lane >> 4)) * 16);
+      const int pos = (MODE == MODE_W8) ? (lane >> 4) : (((lane >> 4) + s) & 3);
+      const v4i bf = *reinterpret_cast<const v4i*>(abuf + ((s * MT + mb * 16 + (lane & 15)) * 4 + pos) * 16);
 #pragma unroll
       for (int ab = 0; ab < 4; ++ab)
         acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf, acc[mb][ab], 0, 0, 0);
@@ -478,38 +535,46 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES), 1) void w4a8_gemv_
     unpack(w, sc4, zr4, wa);
     mma_step(wa, lds[0], 0);
   }
-  if (!wave_active) return;
+  if (!wave_active) return;   // (never taken with KW > 1: one group per workgroup)
 
-  // ---- write back (same mapping as w4a8_gemm_kernel) ------------------------------------------------
-  const int mcol = lane & 15;
-  const int i0 = (lane >> 4) * 4;
+  // ---- combine the K parts (KW > 1) and write back (same mapping as w4a8_gemm_kernel) ----------------
+  if constexpr (KW > 1) {
+    // every wave used only its own buffers so far: park the partials there, then meet
+    v4i* mine = reinterpret_cast<v4i*>(&lds_all[kw][0][0]);
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) mine[ab * 64 + lane] = acc[0][ab];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ABW; ++j) {
+      v4i t = (v4i){0, 0, 0, 0};
+#pragma unroll
+      for (int w = 0; w < KW; ++w) t += reinterpret_cast<const v4i*>(&lds_all[w][0][0])[(ab0 + j) * 64 + lane];
+      acc[0][ab0 + j] = t;
+    }
+  }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m = mb * 16 + mcol;
     if (m >= p.M) continue;
-    float sa = 0.f, as = 0.f;
-    if constexpr (!TO_SLAB) {
-      sa = (float)p.ascales[m];
-      if constexpr (MODE == MODE_CHN) as = (float)p.asum[m];
-    }
 #pragma unroll
-    for (int ab = 0; ab < 4; ++ab) {
-      int n;
-      if constexpr (MODE == MODE_W8) n = ng * 64 + ab * 16 + i0;
-      else n = ng * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
+    for (int j = 0; j < ABW; ++j) {
+      const int ab = ab0 + j;
+      const int n = chan(ab);
       const v4i a4 = acc[mb][ab];
       if constexpr (TO_SLAB) {
         int32_t* dst = p.slab + ((size_t)blockIdx.y * p.M + m) * p.N + n;
         *reinterpret_cast<v4i*>(dst) = a4;
       } else {
+        typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
+        const v4h_t sw4 = __builtin_bit_cast(v4h_t, swv[j]);
+        v4h_t sz4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        if constexpr (MODE == MODE_CHN) sz4 = __builtin_bit_cast(v4h_t, szv[j]);
+        const float sa = (float)sav[mb];
+        float as = 0.f;
+        if constexpr (MODE == MODE_CHN) as = (float)asv[mb];
         half_t o[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sw = (float)p.wscales[n + r];
-          float sz = 0.f;
-          if constexpr (MODE == MODE_CHN) sz = (float)p.wsz[n + r];
-          o[r] = epilogue<MODE>(a4[r], sw, sa, sz, as);
-        }
+        for (int r = 0; r < 4; ++r) o[r] = epilogue<MODE>(a4[r], (float)sw4[r], sa, (float)sz4[r], as);
         *reinterpret_cast<uint2*>(p.out + (size_t)m * p.out_stride + n) =
             *reinterpret_cast<const uint2*>(o);
       }
@@ -555,14 +620,15 @@ __global__ __launch_bounds__(64) void splitk_epilogue_kernel(GemmArgs p, int sk)
 struct GemmPlan {
   int mb;      // 16-row blocks per workgroup tile
   int waves;   // waves (64-channel groups) per workgroup
-  int sk;      // K splits
+  int sk;      // K splits (grid level, int32 slabs)
   int kslice;  // k per split
+  int kw;      // K parts inside a workgroup (decode kernel, M <= 16)
 };
 
 // Tuning hook (tests / bench sweeps): waves<=0 and sk<=0 restore the heuristic.
 extern "C" void omni_gemm_set_plan_override(int waves, int sk);
 extern "C" void omni_gemm_get_plan(int M, int N, int K, int kalign, int* mb, int* waves, int* sk);
-GemmPlan plan_gemm(int M, int N, int K, int kalign);
+GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred = false);
 
 template <int MODE, int MB, int WAVES>
 static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
@@ -571,16 +637,31 @@ static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st
   hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, false>), grid, dim3(64 * WAVES), 0, st, a);
 }
 
-template <int MODE, int MB>
-static void launch_gemv(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
+template <int MODE, int MB, bool TO_SLAB>
+static void launch_gemv_kernel(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
   constexpr int WAVES = GemvCfg<MB, MODE>::WAVES;
   dim3 grid((a.N / 64 + WAVES - 1) / WAVES, pl.sk, 1);
+  if constexpr (MB == 1) {
+    if (pl.kw == 4) {
+      hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, TO_SLAB, 4>), grid, dim3(256), 0, st, a);
+      return;
+    }
+    if (pl.kw == 2) {
+      hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, TO_SLAB, 2>), grid, dim3(128), 0, st, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 1>), grid, dim3(64 * WAVES), 0, st, a);
+}
+
+template <int MODE, int MB>
+static void launch_gemv(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
   if (pl.sk > 1) {
-    hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, true>), grid, dim3(64 * WAVES), 0, st, a);
+    launch_gemv_kernel<MODE, MB, true>(a, pl, st);
     const size_t total = (size_t)a.M * (a.N / 4);
     hipLaunchKernelGGL((splitk_epilogue_kernel<MODE>), dim3((total + 63) / 64), dim3(64), 0, st, a, pl.sk);
   } else {
-    hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, false>), grid, dim3(64 * WAVES), 0, st, a);
+    launch_gemv_kernel<MODE, MB, false>(a, pl, st);
   }
 }
 
@@ -614,15 +695,15 @@ template <int MODE>
 static int launch_gemm_partial(GemmArgs a, void* slab, size_t slab_bytes, int* sk_out, hipStream_t st) {
   if (a.M < 1 || a.M > 128 || a.N % 64 != 0 || a.K % 64 != 0 || a.K < 64 || !slab || !sk_out) return OMNI_EINVAL;
   if (MODE == MODE_GRP && a.K % 128 != 0) return OMNI_EINVAL;
-  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64);
+  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64, true);
   if (slab_bytes < (size_t)pl.sk * a.M * a.N * sizeof(int32_t)) return OMNI_ENOMEM;
   a.slab = static_cast<int32_t*>(slab);
   a.kslice = pl.kslice;
   switch (pl.mb) {
-    case 1: { constexpr int W = GemvCfg<1, MODE>::WAVES; hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, true>), dim3((a.N / 64 + W - 1) / W, pl.sk), dim3(64 * W), 0, st, a); } break;
-    case 2: { constexpr int W = GemvCfg<2, MODE>::WAVES; hipLaunchKernelGGL((w4a8_gemv_kernel<2, MODE, true>), dim3((a.N / 64 + W - 1) / W, pl.sk), dim3(64 * W), 0, st, a); } break;
-    case 4: { constexpr int W = GemvCfg<4, MODE>::WAVES; hipLaunchKernelGGL((w4a8_gemv_kernel<4, MODE, true>), dim3((a.N / 64 + W - 1) / W, pl.sk), dim3(64 * W), 0, st, a); } break;
-    default: { constexpr int W = GemvCfg<8, MODE>::WAVES; hipLaunchKernelGGL((w4a8_gemv_kernel<8, MODE, true>), dim3((a.N / 64 + W - 1) / W, pl.sk), dim3(64 * W), 0, st, a); } break;
+    case 1: launch_gemv_kernel<MODE, 1, true>(a, pl, st); break;
+    case 2: launch_gemv_kernel<MODE, 2, true>(a, pl, st); break;
+    case 4: launch_gemv_kernel<MODE, 4, true>(a, pl, st); break;
+    default: launch_gemv_kernel<MODE, 8, true>(a, pl, st); break;
   }
   *sk_out = pl.sk;
   return omni_launch_status();

@@ -1,0 +1,23 @@
+"""Time the BASELINE configs[0] shape (4096^3 per-channel W4A8 GEMM) and two prefill shapes on the GPU."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import event_time_ms  # noqa: E402
+from omniserve_amd.backend import qgemm_w4a8_per_chn  # noqa: E402
+
+dev = torch.device("cuda:0")
+for (M, N, K) in [(4096, 4096, 4096), (16384, 6144, 4096), (16384, 28672, 4096), (16384, 4096, 14336)]:
+    a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev)
+    w = torch.randint(0, 256, (N, K // 2), dtype=torch.uint8, device=dev).view(torch.int8)
+    sw = torch.full((N,), 0.01, dtype=torch.float16, device=dev)
+    sz = torch.full((N,), 0.05, dtype=torch.float16, device=dev)
+    sa = torch.full((M,), 0.01, dtype=torch.float16, device=dev)
+    asum = torch.zeros((M,), dtype=torch.float16, device=dev)
+    out = torch.empty((M, N), dtype=torch.float16, device=dev)
+    ms = event_time_ms(lambda i: qgemm_w4a8_per_chn.gemm_forward_cuda(a, w, sw, sa, sz, asum, out), iters=10)
+    print(json.dumps({"M": M, "N": N, "K": K, "ms": round(ms, 4), "int8_tops": round(2.0 * M * N * K / ms / 1e9, 1)}), flush=True)
+    del a, w, out
