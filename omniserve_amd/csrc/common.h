@@ -92,15 +92,59 @@ __device__ __forceinline__ float ref_block_max(float v, float* red, float pad) {
   return w;
 }
 
+// ---- DPP lane exchange (one VALU op, no LDS crossbar round trip like ds_bpermute / __shfl_xor) ----------
+// CTRL: quad_perm = p0 | p1<<2 | p2<<4 | p3<<6; row_shl:n = 0x100+n; row_shr:n = 0x110+n; row_ror:n = 0x120+n;
+// row_mirror = 0x140; row_half_mirror = 0x141.  A row = 16 lanes.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_mov<0xB1>(v); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v); }   // quad_perm [2,3,0,1]
+
+// 64-lane max / sum, result in every lane.  Pairing order: xor 1, 2 inside quads, mirrored halves and rows,
+// then the four 16-lane rows through v_readlane.  max is exact in any order; wave_sum64 is only used where
+// the summation order is not part of a parity contract (softmax denominators, q.k of the current token).
 __device__ __forceinline__ float wave_max64(float v) {
-#pragma unroll
-  for (int mask = 32; mask > 0; mask >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, mask, 64));
-  return v;
+  v = __builtin_fmaxf(v, lane_xor1(v));
+  v = __builtin_fmaxf(v, lane_xor2(v));
+  v = __builtin_fmaxf(v, dpp_mov<0x141>(v));
+  v = __builtin_fmaxf(v, dpp_mov<0x140>(v));
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return __builtin_fmaxf(__builtin_fmaxf(r0, r1), __builtin_fmaxf(r2, r3));
 }
 __device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int mask = 32; mask > 0; mask >>= 1) v = v + __shfl_xor(v, mask, 64);
-  return v;
+  v = v + lane_xor1(v);
+  v = v + lane_xor2(v);
+  v = v + dpp_mov<0x141>(v);
+  v = v + dpp_mov<0x140>(v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
 }
+
+// Phase clocks for latency debugging (tools/phase_clocks.py; build with OMNI_HIPCC_EXTRA=-DOMNI_DEBUG_CLOCKS).
+// Workgroup (0,0,0) thread 0 records the 100 MHz wall clock after draining its outstanding memory operations.
+#ifdef OMNI_DEBUG_CLOCKS
+static __device__ unsigned long long omni_dbg_clk[32];
+#define OMNI_CLK(k)                                                                          \
+  do {                                                                                       \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)           \
+      omni_dbg_clk[k] = wall_clock64();                                                      \
+  } while (0)
+#define OMNI_CLK_READER(name)                                                                \
+  extern "C" int name(unsigned long long* out32) {                                           \
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(omni::omni_dbg_clk), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5; \
+  }
+#else
+#define OMNI_CLK(k) do {} while (0)
+#define OMNI_CLK_READER(name)
+#endif
 
 }  // namespace omni

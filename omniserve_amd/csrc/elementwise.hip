@@ -20,9 +20,14 @@ constexpr int VPT = 16;  // elements per thread held in registers: hidden <= 163
 // ------------------------------------------------------------------------------------------
 // invoke_quant / invoke_quant_fuse_sum   (fused_kernels.cu:57-142)
 // ------------------------------------------------------------------------------------------
+// silu(x) = x / (1 + exp(-x)) in f32, rounded to fp16, times up in f32, rounded to fp16
+// (activation_kernels.cu:10-13,84-97).  The reference is built with --use_fast_math, i.e. ex2.approx and an
+// approximate division, so its f32 intermediate is not bit-defined; v_exp_f32 / v_rcp_f32 are the same class
+// of approximation (<= 1 fp16 ulp from the exact value after rounding; tests allow 2).
 __device__ __forceinline__ half_t silu_mul_h(half_t a, half_t b) {
   const float xf = (float)a;
-  const half_t s = (half_t)(xf / (1.0f + expf(-xf)));
+  const float e = __builtin_amdgcn_exp2f(xf * -1.4426950408889634f);
+  const half_t s = (half_t)(xf * __builtin_amdgcn_rcpf(1.0f + e));
   return (half_t)((float)s * (float)b);
 }
 
@@ -245,9 +250,9 @@ __device__ __forceinline__ void tree_sum8(float (&v)[NQ][VT], float* red, int p,
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-    for (int e = 0; e < VT; ++e) v[q][e] = v[q][e] + __shfl_xor(v[q][e], 2, 64);  // virtual mask 16
+    for (int e = 0; e < VT; ++e) v[q][e] = v[q][e] + lane_xor2(v[q][e]);  // virtual mask 16 (same pairs as shfl_xor 2)
 #pragma unroll
-    for (int e = 0; e < VT; ++e) v[q][e] = v[q][e] + __shfl_xor(v[q][e], 1, 64);  // virtual mask 8
+    for (int e = 0; e < VT; ++e) v[q][e] = v[q][e] + lane_xor1(v[q][e]);  // virtual mask 8
     const float c0 = v[q][0] + v[q][4], c1 = v[q][1] + v[q][5], c2 = v[q][2] + v[q][6], c3 = v[q][3] + v[q][7];
     const float d0 = c0 + c2, d1 = c1 + c3;
     w[q] = d0 + d1;
@@ -487,11 +492,22 @@ __device__ __forceinline__ void ordered_partials(const float* xs, int p, int nv,
 #pragma unroll
     for (int e = 0; e < VT; ++e) v[q][e] = 0.0f;
   if (VT * p < nv) {
-    for (int i = VT * p; i < hidden; i += nv) {
-      const v4f a = *reinterpret_cast<const v4f*>(xs + i);
-      const v4f b = *reinterpret_cast<const v4f*>(xs + i + 4);
+    // chunks in ascending order (that IS the reference's order); four chunks' LDS reads are issued together
+    for (int i = VT * p; i < hidden; i += 4 * nv) {
+      v4f a[4], b[4];
 #pragma unroll
-      for (int e = 0; e < VT; ++e) f(v, e, e < 4 ? a[e] : b[e - 4]);
+      for (int c = 0; c < 4; ++c) {
+        const int ic = (i + c * nv) < hidden ? i + c * nv : i;
+        a[c] = *reinterpret_cast<const v4f*>(xs + ic);
+        b[c] = *reinterpret_cast<const v4f*>(xs + ic + 4);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if ((i + c * nv) < hidden) {
+#pragma unroll
+          for (int e = 0; e < VT; ++e) f(v, e, e < 4 ? a[c][e] : b[c][e - 4]);
+        }
+      }
     }
   }
 }
@@ -504,6 +520,7 @@ __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, 
   extern __shared__ __attribute__((aligned(16))) float xs[];   // [hidden]
   __shared__ float red[96];
   const int p = threadIdx.x;
+  OMNI_CLK(8);
   const Src src = src0.at_row(blockIdx.x);
   float x[RV][VT];
   float amax = 0.0f;
@@ -515,6 +532,7 @@ __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, 
       src.fetch(i < hidden ? i : 0, raw[it]);
     }
   }
+  OMNI_CLK(9);
 #pragma unroll
   for (int it = 0; it < RV; ++it) {
     const int i = (p + it * RT) * VT;
@@ -537,13 +555,16 @@ __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, 
       *reinterpret_cast<v4f*>(xs + i + 4) = (v4f){x[it][4], x[it][5], x[it][6], x[it][7]};
     }
   }
+  OMNI_CLK(10);
   amax = block_max_rt(amax, red);   // (its barriers also publish xs)
+  OMNI_CLK(11);
   if constexpr (FUSE_SUM) {
     float s[1][VT], tot[1];
     ordered_partials<1>(xs, p, nv, hidden, s, [](float (&v)[1][VT], int e, float val) { v[0][e] = v[0][e] + val; });
     tree_sum8<1>(s, red, p, nv >> 5, tot);
     if (p == 0) sum_out[blockIdx.x] = (half_t)tot[0];
   }
+  OMNI_CLK(12);
   if (p == 0) scale_out[blockIdx.x] = (half_t)(amax / 127.0f);
   const float q = 127.0f / amax;
   int8_t* orow = out + (size_t)blockIdx.x * hidden;
@@ -552,6 +573,7 @@ __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, 
     const int i = (p + it * RT) * VT;
     if (i < hidden) store8_i8(orow + i, x[it], q);
   }
+  OMNI_CLK(13);
 }
 
 // rms_norm_general[_fuse_sum] (+ fused residual sources): NV = roundup32(min(hidden,1024))
@@ -562,6 +584,7 @@ __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict_
   extern __shared__ __attribute__((aligned(16))) float xs[];   // [hidden]
   __shared__ float red[96];
   const int p = threadIdx.x;
+  OMNI_CLK(0);
   const Src src = src0.at_row(blockIdx.x);
   float x[RV][VT];
   typename Src::Raw raw[Src::BATCH ? RV : 1];
@@ -588,13 +611,16 @@ __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict_
       *reinterpret_cast<v4f*>(xs + i + 4) = (v4f){x[it][4], x[it][5], x[it][6], x[it][7]};
     }
   }
+  OMNI_CLK(1);
   __syncthreads();
   float st[2][VT], tv[2];
   ordered_partials<2>(xs, p, nv, hidden, st, [](float (&v)[2][VT], int e, float val) {
     v[0][e] = v[0][e] + val;
     v[1][e] = v[1][e] + val * val;
   });
+  OMNI_CLK(2);
   tree_sum8<2>(st, red, p, nv >> 5, tv);   // first barrier inside: everyone is done reading xs
+  OMNI_CLK(3);
   const float mean = tv[0] / (float)hidden;
   const float rstd = 1.0f / __builtin_sqrtf(tv[1] / (float)hidden + eps);
   float amax_h = (float)(half_t)1e-6f;
@@ -618,7 +644,9 @@ __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict_
       }
     }
   }
+  OMNI_CLK(4);
   const float amax = block_max_rt(amax_h, red);   // barriers publish the fp16-rounded y in xs
+  OMNI_CLK(5);
   if constexpr (FUSE_SUM) {
     float hs[1][VT], tot[1];
     ordered_partials<1>(xs, p, nv, hidden, hs, [](float (&v)[1][VT], int e, float val) {
@@ -627,6 +655,7 @@ __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict_
     tree_sum8<1>(hs, red, p, nv >> 5, tot);
     if (p == 0) sum_out[blockIdx.x] = (half_t)tot[0];
   }
+  OMNI_CLK(6);
   if (p == 0) scale_out[blockIdx.x] = (half_t)(amax / 127.0f);
   const float q = 127.0f / amax;
   int8_t* orow = out + (size_t)blockIdx.x * hidden;
@@ -635,6 +664,7 @@ __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict_
     const int i = (p + it * RT) * VT;
     if (i < hidden) store8_i8(orow + i, x[it], q);
   }
+  OMNI_CLK(7);
 }
 
 // rms_norm (fp16 out): NV = min(hidden,1024)
@@ -924,3 +954,5 @@ extern "C" int omni_attn_merge_quant_fuse_sum(void* out_i8, const void* part_ml_
                  (half_t*)scale_f16, hidden, nv);
   return omni_launch_status();
 }
+
+OMNI_CLK_READER(omni_debug_clocks_elementwise)

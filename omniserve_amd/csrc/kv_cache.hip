@@ -601,6 +601,7 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
   const int sub = blockIdx.y % qg;
   const int hq0 = hk * group + sub * G;
   const int b = blockIdx.z;
+  OMNI_CLK(16);
   const KvLayout lay = p.lay;
   // The kernel is a chain of memory round trips, so the requests are ordered to need only two of them:
   //   trip 1 (independent of the sequence length): length, page-table window, raw q / k / v rows;
@@ -711,6 +712,7 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
       rc[j] = t.x; rs[j] = t.y;
     }
   }
+  OMNI_CLK(17);
   __syncthreads();   // pages[] visible
 
   const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
@@ -775,6 +777,7 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
   }
   if (owns_cur && tid < DH) vcur[tid] = vcur_r;
   __syncthreads();
+  OMNI_CLK(18);
 
   // ---- pass 1: scores = q.K / sqrt(Dh) on MFMA ------------------------------------------------------
   float mloc = -1e30f;   // running max of this lane's head column (valid for l15 < G)
@@ -817,6 +820,7 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
       }
     }
   }
+  OMNI_CLK(19);
   float scur[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) scur[g] = 0.0f;
@@ -873,6 +877,7 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
     lblk[g] = l + pcur[g];
   }
 
+  OMNI_CLK(20);
   // ---- pass 2: O^T = V^T . P^T on MFMA (V through LDS, transposed read) ----------------------------------
   v4f oacc[8];   // block c: rows = column positions c*16 + 4*l4 + r of the V tile, col = head l15
 #pragma unroll
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
       for (int u = 0; u < MF_UT; ++u)
 #pragma unroll
         for (int h = 0; h < 2; ++h) { raw[u][h] = vraw[u][h]; sc[u][h] = vsc[u][h]; ze[u][h] = vze[u][h]; }
-      load_v_batch(tl0 + DEC_WAVES * MF_UT);   // next batch in flight while this one is consumed
+      if (tl0 + DEC_WAVES * MF_UT < ntiles) load_v_batch(tl0 + DEC_WAVES * MF_UT);   // (rare) next batch
 #pragma unroll
       for (int u = 0; u < MF_UT; ++u) {
         const int tbase = (tl0 + u * DEC_WAVES) * 32;
@@ -926,6 +931,7 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
       }
     }
   }
+  OMNI_CLK(21);
   // ---- reduce O across the 4 waves via LDS, un-permute the columns, normalise / emit partials --------------
   if (l15 < G) {
 #pragma unroll
@@ -952,6 +958,7 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
     }
   }
 
+  OMNI_CLK(22);
   // ---- append the current token (quantised) to the cache ------------------------------------------
   if (owns_cur && sub == 0 && wave < 2) {
     const half_t* src = wave == 0 ? kcur : vcur;
@@ -1333,3 +1340,5 @@ extern "C" int omni_kv4_decode_attention_fine_grained(
                      a.part_o, pl.nsplit);
   return omni_launch_status();
 }
+
+OMNI_CLK_READER(omni_debug_clocks_kv)
