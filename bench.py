@@ -35,6 +35,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 INT8_PEAK_TOPS = 5000.0     # dense int8 MFMA
+# (M, N, K, group) -> measured HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), see profiles/r01_d_*
+PMC_TRAFFIC_BYTES = {(16, 28672, 4096, -1): 60415000}
 
 
 def event_time_ms(fn, iters, warm=3):
@@ -69,9 +71,14 @@ def roofline_gate_up(runner):
     # algorithmic bytes per launch: M*K + N*K/2 + 2*M*N + 4*N + 4*M (+ g128 params)
     alg = B * K + lin0.weight_bytes() + 2 * B * N + 4 * N + 4 * B
     achieved = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "w4a8_gemm_kernel (gate_up GEMV M=%d N=%d K=%d, incl. split-K epilogue)" % (B, N, K),
+    # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # runs, FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes): only known for the
+    # default shape; anything else reports null.
+    traffic = PMC_TRAFFIC_BYTES.get((B, N, K, lin0.group))
+    return {"bound": "hbm", "kernel": "w4a8_gemv_kernel<1,CHN,false,4> (gate_up GEMV M=%d N=%d K=%d, one kernel)" % (B, N, K),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": "profiles/r01_d_pmc_gemv_traffic_and_gemm_mfma.md" if traffic else None,
             "bytes_per_launch": alg, "us_per_launch": round(ms * 1e3, 2)}
 
 

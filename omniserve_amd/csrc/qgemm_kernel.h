@@ -43,6 +43,7 @@ struct GemmArgs {
   int M, N, K;
   int64_t out_stride;
   int kslice;             // k per split (multiple of 64)
+  int tiles_m, tiles_n;   // > 0: 1-D grid with the XCD-aware tile order of w4a8_gemm_kernel
 };
 
 // per-byte add mod 256 (CUDA __vadd4)
@@ -65,6 +66,9 @@ __device__ __forceinline__ half_t epilogue(int acc, float sw, float sa, float sz
 
 // One workgroup = WAVES waves; wave w owns output channels [64*(WAVES*bx + w), +64);
 // all waves share the LDS-staged activation tile of MB*16 rows.
+#ifndef OMNI_GEMM_XCD_ORDER
+#define OMNI_GEMM_XCD_ORDER 1
+#endif
 #ifndef OMNI_GEMM_MIN_BLOCKS
 #define OMNI_GEMM_MIN_BLOCKS 2
 #endif
@@ -78,9 +82,24 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int ng = blockIdx.x * WAVES + wave;  // 64-channel group
+  int tile_n = blockIdx.x, tile_m = blockIdx.z;
+  if (p.tiles_n > 0) {
+    // XCD-aware order (1-D grid).  Workgroups are dealt round-robin to the 8 XCDs, each with a private
+    // 4 MiB L2: XCD x takes the x-th contiguous eighth of the tiles, enumerated as 8 x 8 super-blocks, so
+    // the ~64 workgroups an XCD runs at a time share 8 activation row-tiles and 8 weight column-tiles
+    // (every L2 line is fetched once from the fabric and reused 8x) instead of striding over all of M.
+    const int wid = blockIdx.x;
+    const int per_xcd = gridDim.x >> 3;
+    const int t = (wid & 7) * per_xcd + (wid >> 3);
+    const int sbn = (p.tiles_n + 7) >> 3;
+    const int sb = t >> 6, in = t & 63;
+    tile_m = (sb / sbn) * 8 + (in >> 3);
+    tile_n = (sb % sbn) * 8 + (in & 7);
+    if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
+  }
+  const int ng = tile_n * WAVES + wave;  // 64-channel group
   const bool wave_active = (ng * 64) < p.N;
-  const int m0 = blockIdx.z * MT;
+  const int m0 = tile_m * MT;
   const int k_begin = blockIdx.y * p.kslice;
   const int k_end = min(p.K, k_begin + p.kslice);
   const int nsteps = (k_end - k_begin) / KSTEP;
@@ -109,16 +128,33 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   uint4 wq[STEPS][WL];
 
   // ---- activation staging --------------------------------------------------------------
+  // LDS image of a chunk: [k-step s][16-B slot q of the step's B operand][row m][16 B] ("plane" layout):
+  // the 16 lanes of a ds_read_b128 lane group read 16 consecutive rows of one or two planes = 16 distinct
+  // 16-B slots of the 256-B bank row (conflict-free; the row-major [s][m][64 B] image was 2-way).
+  // Thread -> (row m, 16-B piece kk of the chunk row) is chosen so that the 32 lanes of a store group hit
+  // 32 distinct banks: W4 (ds_write_b32 of dword e into plane e): 8 rows x 4 pieces of one k-step;
+  // W8 (ds_write_b128 into plane kk&3): 8 rows per 8-lane group.
+  static_assert(KCHUNK == 256 && (MT % 16) == 0, "piece mapping assumes 16 pieces per chunk row");
   uint4 areg[A_LOADS];
+  auto piece = [&](int j, int& m, int& kk) {
+    const int id = tid + j * NTHREADS;
+    if constexpr (MODE == MODE_W8) {
+      m = (id & 7) | ((id >> 7) << 3);
+      kk = (id >> 3) & 15;
+    } else {
+      m = ((id >> 2) & 7) | ((id >> 7) << 3);
+      kk = (id & 3) | (((id >> 5) & 3) << 2);
+    }
+  };
   auto load_a = [&](int chunk) {
     const int kc = k_begin + chunk * KCHUNK;
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) {
-      const int id = tid + j * NTHREADS;
-      const int m = id / (KCHUNK / 16), kk = id % (KCHUNK / 16);
+      int m, kk;
+      piece(j, m, kk);
       const int k = kc + kk * 16;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (id < MT * KCHUNK / 16 && (m0 + m) < p.M && k < k_end)
+      if (tid + j * NTHREADS < MT * KCHUNK / 16 && (m0 + m) < p.M && k < k_end)
         v = *reinterpret_cast<const uint4*>(p.A + (size_t)(m0 + m) * p.K + k);
       areg[j] = v;
     }
@@ -126,24 +162,21 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   auto store_a = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) {
-      const int id = tid + j * NTHREADS;
-      if (id >= MT * KCHUNK / 16) continue;
-      const int m = id / (KCHUNK / 16), kk = id % (KCHUNK / 16);
+      if (tid + j * NTHREADS >= MT * KCHUNK / 16) continue;
+      int m, kk;
+      piece(j, m, kk);
+      const int ks = kk >> 2;
       if constexpr (MODE == MODE_W8) {
-        // row-major per k-step: [(ks*MT + m)*64 + g*16]
-        const int ks = kk >> 2, g = kk & 3;
-        *reinterpret_cast<uint4*>(&lds[buf][(ks * MT + m) * 64 + g * 16]) = areg[j];
+        *reinterpret_cast<uint4*>(&lds[buf][((ks * 4 + (kk & 3)) * MT + m) * 16]) = areg[j];
       } else {
-        // kk = 16-byte piece: kp = k-pair (64 k), tp = tile parity, d = k5;
-        // piece bytes [e*4+f] scatter to [(kp*MT+m)*64 + pos(e)*16 + tp*8 + d*4 + f], pos(e) = (e+kp)&3:
-        // the rotation spreads the four k-pairs of one ds_write over all 64 banks (without it the
-        // k-pair stride of MT*64 B maps them onto the same bank: a 4-way conflict on every write)
-        const int kp = kk >> 2, tp = (kk >> 1) & 1, d = kk & 1;
-        uint8_t* dst = &lds[buf][(kp * MT + m) * 64 + tp * 8 + d * 4];
-        *reinterpret_cast<uint32_t*>(dst + ((0 + kp) & 3) * 16) = areg[j].x;
-        *reinterpret_cast<uint32_t*>(dst + ((1 + kp) & 3) * 16) = areg[j].y;
-        *reinterpret_cast<uint32_t*>(dst + ((2 + kp) & 3) * 16) = areg[j].z;
-        *reinterpret_cast<uint32_t*>(dst + ((3 + kp) & 3) * 16) = areg[j].w;
+        // kk = 16-byte piece of the row: tp = tile parity, d = k5; its dword e belongs to slot e of the
+        // step's B operand, at byte tp*8 + d*4 of the slot
+        const int tp = (kk >> 1) & 1, d = kk & 1;
+        uint8_t* dst = &lds[buf][(ks * 4 * MT + m) * 16 + tp * 8 + d * 4];
+        *reinterpret_cast<uint32_t*>(dst + 0 * MT * 16) = areg[j].x;
+        *reinterpret_cast<uint32_t*>(dst + 1 * MT * 16) = areg[j].y;
+        *reinterpret_cast<uint32_t*>(dst + 2 * MT * 16) = areg[j].z;
+        *reinterpret_cast<uint32_t*>(dst + 3 * MT * 16) = areg[j].w;
       }
     }
   };
@@ -226,8 +259,7 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          const int pos = (MODE == MODE_W8) ? (lane >> 4) : (((lane >> 4) + s) & 3);
-          const v4i bf = *reinterpret_cast<const v4i*>(abuf + ((s * MT + mb * 16 + (lane & 15)) * 4 + pos) * 16);
+          const v4i bf = *reinterpret_cast<const v4i*>(abuf + ((s * 4 + (lane >> 4)) * MT + mb * 16 + (lane & 15)) * 16);
 #pragma unroll
           for (int ab = 0; ab < 4; ++ab)
             acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf, acc[mb][ab], 0, 0, 0);
@@ -632,9 +664,18 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred = false);
 
 template <int MODE, int MB, int WAVES>
 static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
-  // prefill regime: chunked LDS staging, weights through L2
-  dim3 grid((a.N / 64 + WAVES - 1) / WAVES, 1, (a.M + MB * 16 - 1) / (MB * 16));
-  hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, false>), grid, dim3(64 * WAVES), 0, st, a);
+  // prefill regime: chunked LDS staging, weights through L2, XCD-aware tile order
+  GemmArgs b = a;
+  b.tiles_n = (a.N / 64 + WAVES - 1) / WAVES;
+  b.tiles_m = (a.M + MB * 16 - 1) / (MB * 16);
+#if OMNI_GEMM_XCD_ORDER
+  const int sbs = ((b.tiles_m + 7) / 8) * ((b.tiles_n + 7) / 8);
+  dim3 grid(sbs * 64, 1, 1);
+#else
+  dim3 grid(b.tiles_n, 1, b.tiles_m);
+  b.tiles_n = b.tiles_m = 0;
+#endif
+  hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, false>), grid, dim3(64 * WAVES), 0, st, b);
 }
 
 template <int MODE, int MB, bool TO_SLAB>

@@ -40,7 +40,8 @@ def test_per_chn_decode_shapes(M, N, K):
     _run_chn(M, N, K, seed=M + N + K)
 
 
-@pytest.mark.parametrize("M,N,K", [(129, 256, 256), (300, 320, 192), (1000, 512, 1024), (257, 64, 64)])
+@pytest.mark.parametrize("M,N,K", [(129, 256, 256), (300, 320, 192), (1000, 512, 1024), (257, 64, 64),
+                                   (2100, 2304, 128)])   # last: 17 x 9 tiles = several 8 x 8 super-blocks (XCD order)
 def test_per_chn_prefill_shapes(M, N, K):
     _run_chn(M, N, K, seed=M)
 
