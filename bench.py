@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--no-fused", action="store_true", help="reference call sequence (no fused extension kernels)")
     ap.add_argument("--fused-level", type=int, default=2, help="0 reference sequence, 1 fused add+norm / silu+quant, 2 + deferred split-K epilogue")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / gemm_4096 legs")
+    ap.add_argument("--tp", action="store_true", help="with N > 1: shard ONE model over the N GPUs (Megatron TP, fp16 "
+                    "all-reduce over RCCL after o_proj / down_proj; strong scaling) instead of N replicas")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,8 +168,11 @@ def main():
 
     from omniserve_amd.runtime import DecodeRunner, LlamaConfig
     cfg = LlamaConfig.llama3_8b(args.group_size)
+    tp = args.tp and world > 1
     runner = DecodeRunner(cfg, args.batch, args.context, args.steps + args.warmup + 4, device,
-                          seed=1234 + rank, use_graph=not args.no_graph, fused=0 if args.no_fused else args.fused_level)
+                          seed=1234 + (0 if tp else rank), use_graph=not args.no_graph,
+                          fused=0 if args.no_fused else args.fused_level,
+                          tp_rank=rank if tp else 0, tp_size=world if tp else 1)
     for _ in range(args.warmup):
         runner.step()
     torch.cuda.synchronize()
@@ -188,22 +193,23 @@ def main():
     if not torch.isfinite(runner.x.float()).all():
         raise SystemExit("non-finite activations in the decode step")
 
-    total_tokens = args.batch * args.steps * world
+    total_tokens = args.batch * args.steps * (1 if tp else world)
     result = {
-        "metric": "decode tokens/sec/GPU Llama-3-8B W4A8KV4 bs=16" if world == 1 else
-                  "decode tokens/sec (all GPUs) Llama-3-8B W4A8KV4 bs=16 per GPU",
+        "metric": "decode tokens/sec/GPU Llama-3-8B W4A8KV4 bs=%d" % args.batch if world == 1 else
+                  "decode tokens/sec (all GPUs) Llama-3-8B W4A8KV4 bs=%d per GPU" % args.batch,
         "value": round(total_tokens / elapsed, 1),
         "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if tp else "weak", "vs_baseline": None,
         "dtype": "int8 (W4A8 int32-accumulate GEMM) + fp16 (KV4 attention, fp32 softmax)",
         "data": "synthetic (random packed int4 weights, random KV4 pages, random tokens)",
         "config": {"workload": "Llama-3-8B W4A8KV4 %s decode, bs=%d, context=%d, TP=1 (%s)" % (
                        "per-channel" if args.group_size == -1 else "g%d" % args.group_size, args.batch,
                        args.context, "BASELINE.json configs[1]" if args.group_size == -1 else "configs[2]-like"),
                    "batch_per_gpu": args.batch, "context": args.context, "layers": cfg.layers,
-                   "parallelism": "replicas x%d (no collective)" % world if world > 1 else "single GPU",
+                   "parallelism": ("tp%d (RCCL all-reduce x2 per layer)" % world if tp else
+                                   "replicas x%d (no collective)" % world) if world > 1 else "single GPU",
                    "hip_graph": not args.no_graph, "fused_ext_level": runner.fused,
                    "gemm_weight_bytes_per_step": runner.gemm_weight_bytes_per_step(),
                    "kv_bytes_per_step": runner.kv_bytes_per_step(args.context)},

@@ -55,6 +55,9 @@ class W4A8Linear:
         self.n, self.k, self.group = n, k, group_size
         self.qweight = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, device=device, generator=gen).view(torch.int8)
         self.s1_scales = (torch.rand((n,), device=device, generator=gen) * 0.018 + 0.002).half()
+        if group_size != -1:
+            # level-2 weights span +-120 instead of +-15: keep the synthetic model's activations in fp16 range
+            self.s1_scales = (self.s1_scales.float() / 8.0).half()
         if group_size == -1:
             zeros = torch.randint(0, 16, (n,), device=device, generator=gen).half()
             self.s1_szeros = (zeros * self.s1_scales).half()
@@ -78,34 +81,82 @@ class W4A8Linear:
             b += self.s2_scales.numel() + self.s2_zeros.numel()
         return b
 
+    # ---- tensor-parallel shards of a full layer (omniserve_amd/tp.py has the granularity rules) ------------
+    def select_rows(self, ranges):
+        """Column-parallel shard: output channels [a,b) for (a,b) in ranges (multiples of 64), concatenated."""
+        sh = object.__new__(W4A8Linear)
+        cat = lambda t, dim: torch.cat([t.narrow(dim, a, b - a) for a, b in ranges], dim=dim).contiguous()
+        sh.n, sh.k, sh.group = sum(b - a for a, b in ranges), self.k, self.group
+        sh.qweight = cat(self.qweight, 0)
+        sh.s1_scales = cat(self.s1_scales, 0)
+        if self.group == -1:
+            sh.s1_szeros = cat(self.s1_szeros, 0)
+        else:
+            sh.s2_scales, sh.s2_zeros = cat(self.s2_scales, 1), cat(self.s2_zeros, 1)
+        return sh
+
+    def shard_k(self, rank, world):
+        """Row-parallel shard: the rank's slice of the reduction dimension (whole 128-k blocks)."""
+        from . import tp
+        sh = object.__new__(W4A8Linear)
+        sh.n, sh.k, sh.group = self.n, self.k // world, self.group
+        sh.qweight = tp.shard_qweight_k(self.qweight, rank, world)
+        sh.s1_scales = self.s1_scales
+        if self.group == -1:
+            sh.s1_szeros = self.s1_szeros
+        else:
+            sh.s2_scales = tp.shard_group_params_k(self.s2_scales, rank, world, self.group)
+            sh.s2_zeros = tp.shard_group_params_k(self.s2_zeros, rank, world, self.group)
+        return sh
+
 
 class DecodeRunner:
     """bs sequences with `context` cached tokens each; step() decodes one token per sequence."""
 
     def __init__(self, cfg: LlamaConfig, batch: int, context: int, max_new: int, device, seed=0,
-                 use_graph=True, fused=True):
+                 use_graph=True, fused=True, tp_rank=0, tp_size=1, tp_group=None, shard_full=False):
+        """tp_size > 1: Megatron-style tensor parallelism (omniserve_amd/tp.py): qkv / gate_up column-parallel,
+        o / down row-parallel, attention by kv head, one fp16 sum all-reduce of the [B, hidden] projection after
+        o_proj and after down_proj.  shard_full=True builds the full layers from the seed and keeps this
+        rank's shards (tests: every rank then holds shards of the SAME model); otherwise only the local shapes
+        are drawn (bench: synthetic weights, no point in materialising 70B parameters per rank)."""
         self.cfg, self.B, self.device = cfg, batch, device
+        self.tp_rank, self.tp_size, self.tp_group = int(tp_rank), int(tp_size), tp_group
+        if cfg.heads % self.tp_size or cfg.kv_heads % self.tp_size or cfg.inter % (128 * self.tp_size):
+            raise ValueError("heads / kv_heads / intermediate size not divisible by the TP degree")
+        self.hl, self.kl, self.il = cfg.heads // self.tp_size, cfg.kv_heads // self.tp_size, cfg.inter // self.tp_size
         # fused: 0/False = the reference call sequence; 1 = opt-in fused entry points (residual add +
         # norm + quant, silu*mul + quant); 2/True = additionally defer the split-K epilogue of o_proj /
         # down_proj into the following add+norm kernel.  All bit-identical to the reference sequence
         # (SURVEY.md 8f.1).
         self.fused = 2 if fused is True else int(fused)
-        if cfg.group_size != -1 and self.fused > 1:
-            self.fused = 1   # the deferred epilogue exists for the per-channel GEMM only
+        if (cfg.group_size != -1 or self.tp_size > 1) and self.fused > 1:
+            self.fused = 1   # the deferred epilogue exists for the per-channel GEMM only; TP all-reduces fp16
         c = cfg
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
         self.gen = gen
-        qkv_n = (c.heads + 2 * c.kv_heads) * c.head_dim
+        d = c.head_dim
+        hl, kl, il, r, w = self.hl, self.kl, self.il, self.tp_rank, self.tp_size
+        qkv_n = (hl + 2 * kl) * d
         self.layers = []
         for _ in range(c.layers):
-            self.layers.append(dict(
-                ln1=(1.0 + 0.05 * torch.randn(c.hidden, device=device, generator=gen)).half(),
-                ln2=(1.0 + 0.05 * torch.randn(c.hidden, device=device, generator=gen)).half(),
-                qkv=W4A8Linear(qkv_n, c.hidden, c.group_size, gen, device),
-                o=W4A8Linear(c.hidden, c.heads * c.head_dim, c.group_size, gen, device),
-                gate_up=W4A8Linear(2 * c.inter, c.hidden, c.group_size, gen, device),
-                down=W4A8Linear(c.hidden, c.inter, c.group_size, gen, device)))
+            ln1 = (1.0 + 0.05 * torch.randn(c.hidden, device=device, generator=gen)).half()
+            ln2 = (1.0 + 0.05 * torch.randn(c.hidden, device=device, generator=gen)).half()
+            if w > 1 and shard_full:
+                qkv = W4A8Linear((c.heads + 2 * c.kv_heads) * d, c.hidden, c.group_size, gen, device).select_rows(
+                    [(r * hl * d, (r + 1) * hl * d), (c.heads * d + r * kl * d, c.heads * d + (r + 1) * kl * d),
+                     ((c.heads + c.kv_heads) * d + r * kl * d, (c.heads + c.kv_heads) * d + (r + 1) * kl * d)])
+                o = W4A8Linear(c.hidden, c.heads * d, c.group_size, gen, device).shard_k(r, w)
+                gate_up = W4A8Linear(2 * c.inter, c.hidden, c.group_size, gen, device).select_rows(
+                    [(r * il, (r + 1) * il), (c.inter + r * il, c.inter + (r + 1) * il)])
+                down = W4A8Linear(c.hidden, c.inter, c.group_size, gen, device).shard_k(r, w)
+            else:
+                qkv = W4A8Linear(qkv_n, c.hidden, c.group_size, gen, device)
+                o = W4A8Linear(c.hidden, hl * d, c.group_size, gen, device)
+                gate_up = W4A8Linear(2 * il, c.hidden, c.group_size, gen, device)
+                down = W4A8Linear(c.hidden, il, c.group_size, gen, device)
+            self.layers.append(dict(ln1=ln1, ln2=ln2, qkv=qkv, o=o, gate_up=gate_up, down=down))
         self.final_norm = torch.ones(c.hidden, device=device).half()
         self.embed = (0.02 * torch.randn(c.vocab, c.hidden, device=device, generator=gen)).half()
         self.lm_head = (0.02 * torch.randn(c.vocab, c.hidden, device=device, generator=gen)).half()
@@ -114,11 +165,11 @@ class DecodeRunner:
         self.tpb = 64
         self.max_context = context + max_new + 1
         pages_per_seq = (self.max_context + self.tpb - 1) // self.tpb
-        self.page_bytes = c.kv_heads * self.tpb * (c.head_dim // 2) + 2 * c.kv_heads * self.tpb * 2
+        self.page_bytes = kl * self.tpb * (c.head_dim // 2) + 2 * kl * self.tpb * 2
         n_pages = batch * pages_per_seq
         self.block_tables = []
         self.pools = []
-        data_bytes = c.kv_heads * self.tpb * (c.head_dim // 2)
+        data_bytes = kl * self.tpb * (c.head_dim // 2)
         for _ in range(c.layers):
             pools = []
             tab = torch.empty((batch, 2, pages_per_seq), dtype=torch.int64, device=device)
@@ -126,8 +177,8 @@ class DecodeRunner:
                 pool = torch.empty((n_pages, self.page_bytes), dtype=torch.uint8, device=device)
                 pool[:, :data_bytes] = torch.randint(0, 256, (n_pages, data_bytes), dtype=torch.uint8,
                                                      device=device, generator=gen)
-                tail = pool[:, data_bytes:].view(torch.float16).view(n_pages, 2, c.kv_heads * self.tpb)
-                tail[:, 0] = 0.25 * (0.5 + torch.rand((n_pages, c.kv_heads * self.tpb), device=device, generator=gen))
+                tail = pool[:, data_bytes:].view(torch.float16).view(n_pages, 2, kl * self.tpb)
+                tail[:, 0] = 0.25 * (0.5 + torch.rand((n_pages, kl * self.tpb), device=device, generator=gen))
                 tail[:, 1] = 7.5
                 perm = torch.randperm(n_pages, device=device, generator=gen).view(batch, pages_per_seq)
                 tab[:, kv] = pool.data_ptr() + perm * self.page_bytes
@@ -140,8 +191,8 @@ class DecodeRunner:
         f16, i8 = torch.float16, torch.int8
         self.x = torch.empty((B, c.hidden), dtype=f16, device=device)
         self._q_hidden = torch.empty((B, c.hidden), dtype=i8, device=device)
-        self._q_inter = torch.empty((B, c.inter), dtype=i8, device=device)
-        self._q_attn = torch.empty((B, c.heads * c.head_dim), dtype=i8, device=device)
+        self._q_inter = torch.empty((B, il), dtype=i8, device=device)
+        self._q_attn = torch.empty((B, hl * c.head_dim), dtype=i8, device=device)
         self.act_scale = torch.empty((B,), dtype=f16, device=device)   # written by norm kernels
         self.act_sum = torch.empty((B,), dtype=f16, device=device)
         self.act_scale2 = torch.empty((B,), dtype=f16, device=device)  # written by quant kernels
@@ -149,8 +200,8 @@ class DecodeRunner:
         self.slab = torch.empty((16 << 20,), dtype=torch.uint8, device=device)  # deferred split-K partial sums
         self.qkv_buf = torch.empty((B, qkv_n), dtype=f16, device=device)
         self.proj_buf = torch.empty((B, c.hidden), dtype=f16, device=device)
-        self.gate_up_buf = torch.empty((B, 2 * c.inter), dtype=f16, device=device)
-        self.mlp_act = torch.empty((B, c.inter), dtype=f16, device=device)
+        self.gate_up_buf = torch.empty((B, 2 * il), dtype=f16, device=device)
+        self.mlp_act = torch.empty((B, il), dtype=f16, device=device)
         self.normed = torch.empty((B, c.hidden), dtype=f16, device=device)
         self.lengths = torch.full((B,), context, dtype=torch.int32, device=device)
         self.tokens = torch.randint(0, c.vocab, (B,), device=device, generator=gen)
@@ -188,7 +239,7 @@ class DecodeRunner:
         self.lengths.add_(1)
         torch.index_select(self.embed, 0, self.tokens, out=self.x)
         B = self.B
-        hq, hk, d = c.heads, c.kv_heads, c.head_dim
+        hq, hk, d = self.hl, self.kl, c.head_dim     # this rank's heads
         sA, mA = self.act_scale2, self.act_sum2   # scales / sums produced by quant-type kernels
         sB, mB = self.act_scale, self.act_sum     # ... by norm kernels
         pending = None                             # (sk, linear) of a down_proj whose epilogue is deferred
@@ -222,6 +273,7 @@ class DecodeRunner:
                                                                L["o"].s1_szeros, mA, L["ln2"], mB, sB, c.eps)
             else:
                 L["o"].forward(self._q_attn, sA, mA, self.proj_buf)
+                self._all_reduce(self.proj_buf)
                 if self.fused:
                     fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln2"], mB, sB, c.eps)
                 else:
@@ -237,11 +289,17 @@ class DecodeRunner:
                 pending = (fused_ext.gemm_partial_per_chn(qa_i, L["down"].qweight, self.slab), L["down"])
             else:
                 L["down"].forward(qa_i, sA, mA, self.proj_buf)
+                self._all_reduce(self.proj_buf)
                 if not self.fused or li == nl - 1:
                     self.x.add_(self.proj_buf)
         layernorm_ops.rms_norm(self.normed, self.x, self.final_norm, c.eps, False)
         logits = torch.matmul(self.normed, self.lm_head.t())
         self.tokens.copy_(torch.argmax(logits, dim=-1))
+
+    def _all_reduce(self, buf):
+        if self.tp_size > 1:
+            from . import tp
+            tp.all_reduce_(buf, self.tp_group)
 
     # ---- accounting -----------------------------------------------------------
     def gemm_weight_bytes_per_step(self):
@@ -249,5 +307,5 @@ class DecodeRunner:
 
     def kv_bytes_per_step(self, context):
         c = self.cfg
-        per_tok = 2 * (c.kv_heads * c.head_dim // 2 + c.kv_heads * 4)
+        per_tok = 2 * (self.kl * c.head_dim // 2 + self.kl * 4)
         return per_tok * context * self.B * c.layers

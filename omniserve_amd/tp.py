@@ -58,5 +58,12 @@ def all_reduce_(buf: torch.Tensor, group=None) -> torch.Tensor:
     """In-place fp16 sum all-reduce of a projection output (RCCL on GPU, gloo in the CPU tests)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        if buf.is_cuda and dist.get_backend(group) == "gloo":
+            # test rigs only (several ranks on one GPU): gloo reduces on the host.  fp32 staging: the sum of
+            # `world` fp16 values rounded once, as a 2-rank fp16 ring all-reduce would produce.
+            host = buf.float().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            buf.copy_(host.to(buf.dtype))
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf
