@@ -243,6 +243,7 @@ struct DecodeArgs {
   FgArgs fg;               // fine-grained (retrieval / streaming) extension, used by the FG instantiations
 };
 
+constexpr int DEC_MAX_SPLITS = 1024;   // KV splits per (sequence, head group): contexts up to 1024 x 2048 tokens
 constexpr int DEC_THREADS = 256;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
 constexpr int DEC_UK = 8;  // 16-token groups whose K loads a wave issues back to back (pass 1)
@@ -1051,11 +1052,11 @@ static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int ma
   const int max_s = (max_context + 63) / 64;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
-  if (s > 64) s = 64;
+  if (s > DEC_MAX_SPLITS) s = DEC_MAX_SPLITS;
   int st = ((max_context + s - 1) / s + 15) & ~15;
   // LDS bound on the score buffer; the kernel keeps a window of 40 page pointers per split
   const int st_cap = 38 * tokens_per_block < 2048 ? 38 * tokens_per_block : 2048;
-  while (st > st_cap && s < 64) {
+  while (st > st_cap && s < DEC_MAX_SPLITS) {
     ++s;
     st = ((max_context + s - 1) / s + 15) & ~15;
   }
@@ -1172,8 +1173,12 @@ extern "C" void omni_kv4_decode_set_split_override(int nsplit) {
 extern "C" size_t omni_kv4_decode_workspace_bytes(int batch, int num_heads, int head_dim, int max_context) {
   (void)head_dim;
   if (batch < 1 || num_heads < 1) return 0;
-  // nsplit <= 64 by construction
-  return (size_t)batch * num_heads * 64 * (DH + 2) * sizeof(float);
+  // upper bound of the planner's split count for any tokens_per_block >= 16 (a split holds >= 512 tokens
+  // once the context forces more than 64 splits)
+  long long s = 64;
+  if ((long long)max_context > 64LL * 512) s = ((long long)max_context + 511) / 512 + 1;
+  if (s > DEC_MAX_SPLITS) s = DEC_MAX_SPLITS;
+  return (size_t)batch * num_heads * (size_t)s * (DH + 2) * sizeof(float);
 }
 
 static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride,
@@ -1207,7 +1212,7 @@ static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, co
   a.fg = FgArgs{};
   dim3 grid(pl.nsplit, num_kv_heads * (group / pl.g), batch);
   hipStream_t st = (hipStream_t)stream;
-  if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;  // context beyond 64 splits x 2048 tokens
+  if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;
 #define OMNI_LAUNCH_DEC(G_, D_)                                                                       \
   do {                                                                                                \
     if (pl.mfma) {                                                                                    \

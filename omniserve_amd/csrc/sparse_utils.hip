@@ -63,48 +63,90 @@ struct SelArgs {
   const float* rope; int rope_max_pos;
 };
 
-// one workgroup per (q head, sequence); 16 lanes per sub-chunk (8 dims each)
+// Page selector.  One workgroup per (block of SEL_PB pages, kv head, sequence) scores ALL q heads of the kv
+// head's GQA group from one pass over the page statistics (the reference walks them once per q head).  A team
+// of 16 lanes (= one DPP row; 8 dims per lane, one 16-B load of kmax and of kmin) owns a sub-chunk; a team keeps
+// 8 sub-chunks = 16 loads in flight.  Per-lane sums run over e = 0..7 and the team butterfly over xor 8, 4, 2, 1
+// exactly as KVPageSelectorTemplate.hpp:482-493, so the fp32 sums (and the fp16 scores) are bit-identical.
+constexpr int SEL_PB = 32;     // pages per workgroup
+constexpr int SEL_UN = 8;      // sub-chunks in flight per team
+constexpr int SEL_MAXG = 8;    // q heads per kv head
+
+__device__ __forceinline__ float team_xor4(float v, int lane) {
+  const float up = dpp_mov<0x104>(v);    // row_shl:4 : lane i reads lane i+4
+  const float dn = dpp_mov<0x114>(v);    // row_shr:4 : lane i reads lane i-4
+  return (lane & 4) ? dn : up;
+}
+
+template <int G>
 __global__ __launch_bounds__(256) void kv_page_selector_kernel(SelArgs p) {
-  __shared__ __attribute__((aligned(16))) half_t q_lds[SDH];
-  const int h = blockIdx.x, b = blockIdx.y;
-  const int hk = h / (p.num_heads / p.num_kv_heads);
+  __shared__ __attribute__((aligned(16))) half_t q_lds[G * SDH];
+  __shared__ int64_t page_lds[SEL_PB];
+  const int hk = blockIdx.y, b = blockIdx.z;
   if (p.retrieval_head_flags[hk] == 0) return;   // streaming heads: scores stay zero
   const int rank = p.head_rank_table[hk];
   const int tlen = p.lengths[b] - 1;
-  const int tid = threadIdx.x;
-  if (tid < 64) {  // RoPE(q) at position tlen, rounded to fp16 (as the decode kernel)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int subs = p.tpb / p.sub;
+  const int n_sub = (tlen + p.sub - 1) / p.sub;
+  const int page0 = blockIdx.x * SEL_PB;
+  const int c0 = page0 * subs;
+  if (c0 >= n_sub) return;
+  const int h0 = hk * G;
+  if (tid < SEL_PB) {
+    const int pg = page0 + tid;
+    page_lds[tid] = (pg < p.max_blocks && pg * subs < n_sub) ? p.kv_pointers[(size_t)b * 2 * p.max_blocks + pg] : 0;
+  }
+  for (int idx = tid; idx < G * 64; idx += 256) {   // RoPE(q) at position tlen, rounded to fp16 (as the decode kernel)
+    const int g = idx >> 6, i = idx & 63;
     const int rp = tlen < p.rope_max_pos ? tlen : p.rope_max_pos - 1;
     const float* cs = p.rope + (size_t)rp * SDH;
-    const half_t* src = p.q + (size_t)b * p.q_stride + (size_t)h * SDH;
-    const float c = cs[2 * tid], s = cs[2 * tid + 1];
-    const float a = (float)src[tid], bb = (float)src[tid + 64];
+    const half_t* src = p.q + (size_t)b * p.q_stride + (size_t)(h0 + g) * SDH;
+    const float c = cs[2 * i], s = cs[2 * i + 1];
+    const float a = (float)src[i], bb = (float)src[i + 64];
     const float t0 = c * a, t1 = s * bb, t2 = c * bb, t3 = s * a;
-    q_lds[tid] = (half_t)(t0 - t1);
-    q_lds[tid + 64] = (half_t)(t2 + t3);
+    q_lds[g * SDH + i] = (half_t)(t0 - t1);
+    q_lds[g * SDH + i + 64] = (half_t)(t2 + t3);
   }
   __syncthreads();
-  const int n_sub = (tlen + p.sub - 1) / p.sub;
-  const int subs = p.tpb / p.sub;
-  const int part = tid & 15;                 // 8 dims
-  const v8h q8 = *reinterpret_cast<const v8h*>(q_lds + part * 8);
-  const size_t bytes_per_seq = (size_t)p.num_retrieval_kv_heads * p.tpb * (SDH / 2);
-  for (int c = tid >> 4; c < n_sub; c += 16) {
-    const int page = (c * p.sub) / p.tpb, sc = c % subs;
-    const uint8_t* pg = reinterpret_cast<const uint8_t*>(p.kv_pointers[(size_t)b * 2 * p.max_blocks + page]);
-    const half_t* kmax = reinterpret_cast<const half_t*>(pg + bytes_per_seq) + (size_t)p.tpb * p.num_retrieval_kv_heads * 2;
-    const half_t* kmin = kmax + (size_t)subs * p.num_retrieval_kv_heads * SDH;
-    const size_t o = ((size_t)sc * p.num_retrieval_kv_heads + rank) * SDH + part * 8;
-    const v8h mx = *reinterpret_cast<const v8h*>(kmax + o);
-    const v8h mn = *reinterpret_cast<const v8h*>(kmin + o);
-    float acc = 0.0f;
+  const int part = tid & 15, team = tid >> 4;
+  v8h q8[G];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const half_t a = q8[e] * mx[e], bq = q8[e] * mn[e];   // fp16 products, as the reference (hmul2 / hmax2)
-      acc += (float)(a > bq ? a : bq);
+  for (int g = 0; g < G; ++g) q8[g] = *reinterpret_cast<const v8h*>(q_lds + g * SDH + part * 8);
+  const size_t stats_off = (size_t)p.num_retrieval_kv_heads * p.tpb * (SDH / 2) +
+                           (size_t)p.tpb * p.num_retrieval_kv_heads * 4;                    // bytes: data | scale | zero
+  const size_t min_off = (size_t)subs * p.num_retrieval_kv_heads * SDH;                     // halfs: kmax -> kmin
+  const int n_here = min(SEL_PB * subs, n_sub - c0);
+  for (int i0 = team; i0 < n_here; i0 += 16 * SEL_UN) {
+    v8h mx[SEL_UN], mn[SEL_UN];
+#pragma unroll
+    for (int u = 0; u < SEL_UN; ++u) {   // branch-free: sub-chunks past the end re-read the workgroup's first one
+      const int ci = i0 + 16 * u;
+      const int cc = ci < n_here ? ci : 0;
+      const int pg = cc / subs, sc = cc - pg * subs;
+      const half_t* kmax = reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(page_lds[pg]) + stats_off) +
+                           ((size_t)sc * p.num_retrieval_kv_heads + rank) * SDH + part * 8;
+      mx[u] = *reinterpret_cast<const v8h*>(kmax);
+      mn[u] = *reinterpret_cast<const v8h*>(kmax + min_off);
     }
 #pragma unroll
-    for (int m = 8; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
-    if (part == 0) p.out[((size_t)b * p.num_heads + h) * p.padded + c] = (half_t)acc;
+    for (int u = 0; u < SEL_UN; ++u) {
+      const int ci = i0 + 16 * u;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const half_t a = q8[g][e] * mx[u][e], bq = q8[g][e] * mn[u][e];   // fp16 products (hmul2 / hmax2 upstream)
+          acc += (float)(a > bq ? a : bq);
+        }
+        acc += dpp_mov<0x128>(acc);        // xor 8 (row_ror:8)
+        acc += team_xor4(acc, lane);       // xor 4
+        acc += lane_xor2(acc);
+        acc += lane_xor1(acc);
+        if (part == 0 && ci < n_here) p.out[((size_t)b * p.num_heads + h0 + g) * p.padded + c0 + ci] = (half_t)acc;
+      }
+    }
   }
 }
 
@@ -144,6 +186,17 @@ extern "C" int omni_kv_page_selector(void* out_f16, const void* q_f16, int64_t q
             (const int*)retrieval_head_flags_i32, (const int*)head_rank_table_i32, (const int*)lengths_i32,
             max_blocks, num_heads, num_kv_heads, num_retrieval_kv_heads, tokens_per_block, tokens_per_sub_chunk,
             padded_sub_chunks, (const float*)rope_cos_sin_f32, rope_max_pos};
-  hipLaunchKernelGGL(kv_page_selector_kernel, dim3(num_heads, batch), dim3(256), 0, (hipStream_t)stream, a);
+  const int group = num_heads / num_kv_heads;
+  const int subs = tokens_per_block / tokens_per_sub_chunk;
+  const int pages = (padded_sub_chunks + subs - 1) / subs;
+  if (pages == 0) return OMNI_OK;
+  dim3 grid((pages + SEL_PB - 1) / SEL_PB, num_kv_heads, batch);
+  switch (group) {
+    case 1: hipLaunchKernelGGL(kv_page_selector_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL(kv_page_selector_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 4: hipLaunchKernelGGL(kv_page_selector_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 8: hipLaunchKernelGGL(kv_page_selector_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    default: return OMNI_EINVAL;
+  }
   return omni_launch_status();
 }

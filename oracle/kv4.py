@@ -129,13 +129,22 @@ class PagedKV4:
         self.zeros(page)[head, slot] = ze
 
     def read_tokens(self, table_row, head, n, fp16_math=True):
-        """Dequantized [n, D] float32 for logical tokens 0..n-1 of one sequence."""
-        out = np.empty((n, self.D), F32)
-        for t in range(n):
-            pg, sl = int(table_row[t // self.TPB]), t % self.TPB
-            out[t] = kv4_dequant(self.data(pg)[head, sl], self.scales(pg)[head, sl],
-                                 self.zeros(pg)[head, sl], fp16_math)
-        return out
+        """Dequantized [n, D] float32 for logical tokens 0..n-1 of one sequence (vectorised gather)."""
+        if n <= 0:
+            return np.empty((0, self.D), F32)
+        t = np.arange(n, dtype=np.int64)
+        pg = np.asarray(table_row, np.int64)[t // self.TPB]
+        sl = t % self.TPB
+        flat = self.pool.reshape(-1)
+        row = pg * self.pool.shape[1]
+        d_off = row + (head * self.TPB + sl) * (self.D // 2)
+        packed = flat[d_off[:, None] + np.arange(self.D // 2, dtype=np.int64)[None, :]]
+        s_off = row + self.bytes_per_seq + (head * self.TPB + sl) * 2
+        z_off = s_off + self.H * self.TPB * 2
+        two = np.arange(2, dtype=np.int64)[None, :]
+        sc = np.ascontiguousarray(flat[s_off[:, None] + two]).view(F16)[:, 0]
+        ze = np.ascontiguousarray(flat[z_off[:, None] + two]).view(F16)[:, 0]
+        return kv4_dequant(packed, sc, ze, fp16_math)
 
 
 def prefill_write(qkv_h, seq_lens, k_cache: PagedKV4, v_cache: PagedKV4, k_table, v_table,

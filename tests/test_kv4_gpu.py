@@ -102,3 +102,35 @@ def test_decode_attention_multi_step_crossing_page():
 
 def test_decode_attention_long_context_many_splits():
     _decode_case([1500, 1030], 32, 8, seed=4)
+
+
+def test_decode_attention_very_long_context():
+    """> 64 x 2048 tokens: the KV split count grows past 64 (LServe contexts).  Random page bytes with sane
+    scale / zero tails stand in for a prefill (the oracle reads the same pages)."""
+    import omniserve_backend.fused_attention_pure_dense as fa
+    rng = np.random.default_rng(77)
+    Hq, Hk, T = 4, 1, 140000
+    pages = T // 64 + 2
+    kc, vc = kv4.PagedKV4(pages, Hk, D), kv4.PagedKV4(pages, Hk, D)
+    for c in (kc, vc):
+        c.pool[:] = rng.integers(0, 256, c.pool.shape, dtype=np.uint8)
+        for p in range(pages):
+            c.scales(p)[:] = (0.02 + 0.05 * rng.random((Hk, 64))).astype(np.float16)
+            c.zeros(p)[:] = (6.0 + 3.0 * rng.random((Hk, 64))).astype(np.float16)
+    kidx = rng.permutation(pages).reshape(1, pages)
+    vidx = rng.permutation(pages).reshape(1, pages)
+    gk = GpuPagedKV(kc, vc, kidx, vidx)
+    lens = np.asarray([T + 1], np.int32)
+    q = (0.3 * rng.standard_normal((1, Hq, D))).astype(np.float16)
+    k = rng.standard_normal((1, Hk, D)).astype(np.float16)
+    v = rng.standard_normal((1, Hk, D)).astype(np.float16)
+    want = kv4.decode_attention(q, k, v, lens, kc, vc, kidx, vidx, ROPE_BASE)
+    out = fa.single_query_attention(to_dev(q), to_dev(k), to_dev(v), gk.table, to_dev(lens), None, 1 << 20, 64,
+                                    Hk * D // 2, T + 1, D, ROPE_BASE, True, True, True)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.float32)
+    ref = want.astype(np.float32)
+    tol = 1e-3 * np.abs(ref) + 1e-3 * np.abs(ref).max()
+    assert (np.abs(got - ref) <= tol).all(), "off by %g" % np.abs(got - ref).max()
+    kp, vp = gk.pools()
+    assert np.array_equal(kp, kc.pool) and np.array_equal(vp, vc.pool)

@@ -26,7 +26,8 @@ def _setup(seq_lens, Hin, pooled, seed):
     return k, cu, pool, table, pb
 
 
-@pytest.mark.parametrize("seq_lens,Hin,pooled", [([5], 2, [1]), ([64, 17, 130], 8, [0, 3, 4, 7]), ([200], 4, [0, 1, 2, 3])])
+@pytest.mark.parametrize("seq_lens,Hin,pooled", [([5], 2, [1]), ([64, 17, 130], 8, [0, 3, 4, 7]), ([200], 4, [0, 1, 2, 3]),
+                                                  ([2500, 70], 2, [1])])   # > 32 pages: several selector workgroups per head
 def test_paged_min_max_pool_and_selector(seq_lens, Hin, pooled):
     import omniserve_backend.fused_attention_ctx_pool as cp
     import omniserve_backend.fused_attention_selector as sel
