@@ -8,20 +8,28 @@
 // sequence and q head, GQA by head index division; mask = causal (bottom-right aligned) and, for heads with
 // head_mask_type < 0, additionally (k_pos < sink  OR  q_pos - k_pos < local).
 //
-// Structure (flash-attention, online softmax, matrix cores): a wave owns 16 query rows and walks the
-// keys 32 at a time.  It computes S^T = K Q^T (A = K rows straight from global memory, B = Q held in
-// registers) so that a lane ends up with 8 keys of ONE query row -- exactly the B-operand layout of the
-// second product O^T = V^T P^T, whose A operand (V transposed) comes from an fp16 V tile staged in LDS
-// and read back with ds_read_b64_tr_b16.  No shuffles are needed to turn scores into probabilities'
-// operand layout; row statistics reduce over the 4 lanes that share a query row.
+// Structure (flash-attention, online softmax, matrix cores): a workgroup of 4 waves owns 128 query rows (32 per
+// wave = two 16-row MFMA blocks) of one q head and walks the keys 64 at a time.  The K and V tiles are staged
+// once per workgroup in LDS (double buffered: the next tile travels global -> VGPR during the MFMAs and is
+// written to the other buffer at the end of the iteration, one barrier per tile), so a key row fetched from
+// L2 serves 128 queries.  S^T = K Q^T (A = K rows from LDS, XOR-swizzled 16-B slots: conflict-free
+// ds_read_b128; B = Q held in registers) leaves a lane with 4+4 keys of ONE query row per 32 keys -- exactly
+// the B-operand layout of the second product O^T = V^T P^T, whose A operand (V transposed) is read from the
+// V tile with ds_read_b64_tr_b16.  Probabilities never leave registers; row statistics reduce over the 4 lanes
+// that share a query row.  Tiles that need no masking skip the per-element predicate (workgroup-uniform).
 #include "common.h"
 
 namespace omni {
 
 constexpr int PDH = 128;
-constexpr int PVROW = 272;            // bytes per key row of the V tile in LDS (256 + 16 pad)
-constexpr int PVTILE = 32 * PVROW;
-constexpr int PWAVES = 4;             // 4 waves x 16 query rows = 64 rows per workgroup
+constexpr int PKT = 64;               // keys per tile
+constexpr int PQB = 1;                // 16-row query blocks per wave
+constexpr int PWAVES = 8;             // 8 waves x 16 rows: ~120 VGPRs per wave, 4 waves per SIMD hide the softmax VALU work
+constexpr int PPT = (PKT * 16) / (64 * PWAVES);   // 16-B pieces of a K (or V) tile per thread
+constexpr int PQROWS = 16 * PQB * PWAVES;   // 128 query rows per workgroup
+constexpr int PKROW = 256;            // bytes per key row of the K tile (swizzled slots)
+constexpr int PVROW = 272;            // bytes per key row of the V tile (256 + 16 pad)
+constexpr int PKTILE = PKT * PKROW, PVTILE = PKT * PVROW;
 typedef __fp16 pv4hp __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 struct PrefillArgs {
@@ -32,131 +40,203 @@ struct PrefillArgs {
   const int* streaming_info;                 // [2*Hq] (sink, local) or null
   int num_heads, num_kv_heads;
   int causal;
+  int q_tiles;                               // > 0: 1-D grid, XCD-aware order (see the kernel)
 };
 
-__global__ __launch_bounds__(64 * PWAVES) void prefill_attn_kernel(PrefillArgs p) {
-  __shared__ __attribute__((aligned(16))) uint8_t vtile[PWAVES * PVTILE];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifndef OMNI_PREFILL_MIN_BLOCKS
+#define OMNI_PREFILL_MIN_BLOCKS 2
+#endif
+__global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) void prefill_attn_kernel(PrefillArgs p) {
+  __shared__ __attribute__((aligned(16))) uint8_t ktile[2][PKTILE];
+  __shared__ __attribute__((aligned(16))) uint8_t vtile[2][PVTILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int b = blockIdx.z, h = blockIdx.y, qt = gridDim.x - 1 - blockIdx.x;   // long (late) query tiles are scheduled first
+  if (p.q_tiles > 0) {
+    // 1-D grid: workgroups are dealt round-robin to the 8 XCDs (private L2s).  XCD x takes q heads
+    // [x*Hq/8, (x+1)*Hq/8): all q heads of a kv head -- and every query tile of them -- share one L2, so a
+    // K/V tile is fetched from the fabric once per XCD instead of once per XCD that happens to host a sharer.
+    const int hpx = p.num_heads >> 3;
+    const int wid = blockIdx.x, xcd = wid & 7, slot = wid >> 3;
+    h = xcd * hpx + slot % hpx;
+    const int rest = slot / hpx;
+    qt = p.q_tiles - 1 - rest % p.q_tiles;
+    b = rest / p.q_tiles;
+  }
   const int hk = h / (p.num_heads / p.num_kv_heads);
   const int q_begin = p.cu_q[b], len_q = p.cu_q[b + 1] - q_begin;
   const int k_begin = p.cu_k[b], len_k = p.cu_k[b + 1] - k_begin;
-  const int q0 = blockIdx.x * (16 * PWAVES) + wave * 16;      // first query row of this wave
-  if (blockIdx.x * (16 * PWAVES) >= len_q) return;              // whole workgroup out of range
-  if (q0 >= len_q) return;                                      // waves are independent (private LDS tiles, no barriers)
+  const int q_first = qt * PQROWS;
+  if (q_first >= len_q) return;                                 // whole workgroup out of range
+  const int q_last = min(q_first + PQROWS, len_q) - 1;
+  const int q0 = q_first + wave * (16 * PQB);                   // first query row of this wave
   const int off = len_k - len_q;                                // bottom-right aligned causal mask
   const bool streaming = p.head_mask_type != nullptr && p.head_mask_type[h] < 0;
   const int sink = streaming ? p.streaming_info[2 * h] : 0;
   const int local = streaming ? p.streaming_info[2 * h + 1] : 0;
-  const float scale = 0.08838834764831845f;                     // 1/sqrt(128)
+  const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e)/sqrt(128): scores in the exp2 domain
 
-  const int qrow = q0 + l15;                                    // this lane's query row (column j of S^T)
-  const int qr_c = qrow < len_q ? qrow : (len_q - 1);
-  // B operand of S^T = K Q^T: Q[qrow][32s + 8*l4 + (0..7)]
-  v8h qb[4];
-  {
+  // B operand of S^T = K Q^T: Q[row][32s + 8*l4 + (0..7)] for the wave's two row blocks
+  int qrow[PQB];
+  v8h qb[PQB][4];
+#pragma unroll
+  for (int j = 0; j < PQB; ++j) {
+    qrow[j] = q0 + 16 * j + l15;
+    const int qr_c = qrow[j] < len_q ? qrow[j] : (len_q - 1);
     const half_t* qp = p.q + (size_t)(q_begin + qr_c) * p.q_stride + (size_t)h * PDH + 8 * l4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qb[s] = *reinterpret_cast<const v8h*>(qp + 32 * s);
+    for (int s = 0; s < 4; ++s) qb[j][s] = *reinterpret_cast<const v8h*>(qp + 32 * s);
   }
-  v4f oacc[8];
+  v4f oacc[PQB][8];
+  float m_run[PQB], l_run[PQB];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) oacc[c] = (v4f){0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.0f;
+  for (int j = 0; j < PQB; ++j) {
+    m_run[j] = -1e30f; l_run[j] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) oacc[j][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+  }
 
   // key range this workgroup needs
-  const int q_last = min(blockIdx.x * (16 * PWAVES) + 16 * PWAVES, len_q) - 1;   // last row of the WG
   const int k_hi = p.causal ? min(len_k, q_last + off + 1) : len_k;             // exclusive
-  const int win_lo = streaming ? (int)(blockIdx.x * (16 * PWAVES)) + off - local + 1 : 0;  // first local key of the WG's first row
-  uint8_t* vt = vtile + wave * PVTILE;
-  const int tr_off = (4 * l4 + (l15 >> 2)) * PVROW + (l15 & 3) * 8;
-  const int vtok = lane >> 1, vhalf = lane & 1;                  // V staging: 2 lanes per key row, 128 B each
+  const int win_lo = streaming ? q_first + off - local + 1 : 0;                   // first local key of the first row
+  auto skipped = [&](int kb) { return streaming && kb >= sink && kb + PKT <= win_lo; };   // tile inside the masked band
 
-  for (int kb = 0; kb < k_hi; kb += 32) {
-    if (streaming && kb >= sink && kb + 32 <= win_lo) continue;  // tile entirely in the masked band (uniform)
-    // ---- S^T tile: 2 groups of 16 keys --------------------------------------------------------------
-    v4f st[2];
+  // cooperative tile staging: thread -> 4 (key, 16-B piece) pairs of K and of V
+  uint4 kreg[PPT], vreg[PPT];
+  auto load_tile = [&](int kb) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int key = kb + 16 * u + l15;
+    for (int j = 0; j < PPT; ++j) {
+      const int pid = tid + 64 * PWAVES * j;
+      const int key = kb + (pid >> 4), piece = pid & 15;
       const int kc = key < len_k ? key : (len_k - 1);
-      const half_t* kp = p.k + (size_t)(k_begin + kc) * p.k_stride + (size_t)hk * PDH + 8 * l4;
-      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      kreg[j] = *reinterpret_cast<const uint4*>(p.k + (size_t)(k_begin + kc) * p.k_stride + (size_t)hk * PDH + piece * 8);
+      vreg[j] = *reinterpret_cast<const uint4*>(p.v + (size_t)(k_begin + kc) * p.v_stride + (size_t)hk * PDH + piece * 8);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int pid = tid + 64 * PWAVES * j;
+      const int key = pid >> 4, piece = pid & 15;
+      *reinterpret_cast<uint4*>(&ktile[buf][key * PKROW + ((piece ^ (key & 15)) << 4)]) = kreg[j];
+      *reinterpret_cast<uint4*>(&vtile[buf][key * PVROW + (piece << 4)]) = vreg[j];
+    }
+  };
+  auto next_tile = [&](int kb) {     // first tile >= kb that is not skipped (or >= k_hi)
+    while (kb < k_hi && skipped(kb)) kb += PKT;
+    return kb;
+  };
+
+  const int tr_off = (4 * l4 + (l15 >> 2)) * PVROW + (l15 & 3) * 8;
+  int kb = next_tile(0);
+  if (kb < k_hi) {
+    load_tile(kb);
+    store_tile(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  while (kb < k_hi) {
+    const int kb_next = next_tile(kb + PKT);
+    if (kb_next < k_hi) load_tile(kb_next);                      // in flight during the MFMAs below
+    const uint8_t* kt = ktile[buf];
+    const uint8_t* vt = vtile[buf];
+    // ---- S^T tile: 4 blocks of 16 keys x 2 query blocks ---------------------------------------------------
+    v4f st[PQB][4];
+#pragma unroll
+    for (int j = 0; j < PQB; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) st[j][u] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int key = 16 * u + l15;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const v8h a = *reinterpret_cast<const v8h*>(kp + 32 * s);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qb[s], acc, 0, 0, 0);
+        const v8h a = *reinterpret_cast<const v8h*>(kt + key * PKROW + (((4 * s + l4) ^ l15) << 4));
+#pragma unroll
+        for (int j = 0; j < PQB; ++j) st[j][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qb[j][s], st[j][u], 0, 0, 0);
       }
-      st[u] = acc;   // st[u][r] = K[kb + 16u + 4*l4 + r] . Q[qrow]
     }
-    // ---- stage V tile [32 keys][128 dims] fp16 into LDS (per wave) -----------------------------------
-    {
-      const int key = kb + vtok;
-      const int kc = key < len_k ? key : (len_k - 1);
-      const half_t* vp = p.v + (size_t)(k_begin + kc) * p.v_stride + (size_t)hk * PDH + vhalf * 64;
-      uint8_t* dst = vt + vtok * PVROW + vhalf * 128;
+    // st[j][u][r] = K[kb + 16u + 4*l4 + r] . Q[qrow[j]]
+    // does any (row, key) pair of this workgroup's tile need the mask?  (workgroup-uniform)
+    bool full = (kb + PKT <= len_k) && (q_first + PQROWS <= len_q);
+    if (p.causal) full = full && (kb + PKT - 1 <= q_first + off);
+    if (streaming) full = full && ((kb + PKT <= sink) || (q_last + off - kb < local));
+    // ---- online softmax (per query row = per lane column), probabilities straight into the B operand ----------
+    v8h pb[PQB][2];
 #pragma unroll
-      for (int w = 0; w < 8; ++w)
-        *reinterpret_cast<v8h*>(dst + w * 16) = *reinterpret_cast<const v8h*>(vp + w * 8);
-    }
-    // ---- online softmax for query row `qrow` over this lane's 8 keys ----------------------------------
-    float sv[8];
-    float tmax = -1e30f;
+    for (int j = 0; j < PQB; ++j) {
+      float sv[16];
+      float tmax = -1e30f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kb + 16 * u + 4 * l4 + r;
-        bool ok = key < len_k && qrow < len_q;
-        if (p.causal) ok = ok && key <= qrow + off;
-        if (streaming) ok = ok && (key < sink || (qrow + off) - key < local);
-        const float x = ok ? st[u][r] * scale : -1e30f;
-        sv[u * 4 + r] = x;
-        tmax = __builtin_fmaxf(tmax, x);
+        for (int r = 0; r < 4; ++r) {
+          float x = st[j][u][r] * scale2;
+          if (!full) {
+            const int key = kb + 16 * u + 4 * l4 + r;
+            bool ok = key < len_k && qrow[j] < len_q;
+            if (p.causal) ok = ok && key <= qrow[j] + off;
+            if (streaming) ok = ok && (key < sink || (qrow[j] + off) - key < local);
+            x = ok ? x : -1e30f;
+          }
+          sv[u * 4 + r] = x;
+          tmax = __builtin_fmaxf(tmax, x);
+        }
+      tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = __builtin_fmaxf(m_run[j], tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+      float psum = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pe = (full || sv[e] > -1e29f) ? __builtin_amdgcn_exp2f(sv[e] - m_new) : 0.0f;
+        pb[j][e >> 3][e & 7] = (half_t)pe;   // keys 4*l4+r of blocks (2kk, 2kk+1) -> k-slots of the 32-key step kk
+        psum += pe;
       }
-    tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = __builtin_fmaxf(m_run, tmax);
-    const float alpha = __expf(m_run - m_new);
-    float psum = 0.0f;
-    v8h pb;
+      l_run[j] = l_run[j] * alpha + psum;
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run[j]) != 0) {   // (wave-uniform) rescale only when a row's max moved
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float pe = sv[e] > -1e29f ? __expf(sv[e] - m_new) : 0.0f;
-      const half_t ph = (half_t)pe;
-      pb[e] = ph;
-      psum += (float)ph;
+        for (int c = 0; c < 8; ++c) oacc[j][c] *= alpha;
+      }
+      m_run[j] = m_new;
     }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+    // ---- O^T += V^T P^T ------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int c = 0; c < 8; ++c) oacc[c] *= alpha;
-    // ---- O^T += V^T P^T ------------------------------------------------------------------------------------
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const uint8_t* src = vt + tr_off + c * 32;
-      const pv4hp lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-          (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src));
-      const pv4hp hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-          (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src + 16 * PVROW));
-      const v8h a = {(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
-                     (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
-      oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb, oacc[c], 0, 0, 0);
-    }
+      for (int c = 0; c < 8; ++c) {
+        const uint8_t* src = vt + (32 * kk) * PVROW + tr_off + c * 32;
+        const pv4hp lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src));
+        const pv4hp hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src + 16 * PVROW));
+        const v8h a = {(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
+                       (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+#pragma unroll
+        for (int j = 0; j < PQB; ++j) oacc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[j][kk], oacc[j][c], 0, 0, 0);
+      }
+    // ---- publish the next tile -----------------------------------------------------------------------------------
+    if (kb_next < k_hi) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    kb = kb_next;
   }
   // ---- finish: row sum over the 4 lanes of a query row, normalise, store ------------------------------------
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
-  if (qrow >= len_q) return;
-  const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
-  half_t* op = p.out + ((size_t)(q_begin + qrow) * p.num_heads + h) * PDH + 4 * l4;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
-    const v4h_t o = {(half_t)(oacc[c][0] * inv), (half_t)(oacc[c][1] * inv), (half_t)(oacc[c][2] * inv),
-                     (half_t)(oacc[c][3] * inv)};
-    *reinterpret_cast<v4h_t*>(op + c * 16) = o;
+  for (int j = 0; j < PQB; ++j) {
+    float l = l_run[j];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qrow[j] >= len_q) continue;
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+    half_t* op = p.out + ((size_t)(q_begin + qrow[j]) * p.num_heads + h) * PDH + 4 * l4;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
+      const v4h_t o = {(half_t)(oacc[j][c][0] * inv), (half_t)(oacc[j][c][1] * inv), (half_t)(oacc[j][c][2] * inv),
+                       (half_t)(oacc[j][c][3] * inv)};
+      *reinterpret_cast<v4h_t*>(op + c * 16) = o;
+    }
   }
 }
 
@@ -180,7 +260,13 @@ extern "C" int omni_prefill_attention(void* out_f16, const void* q_f16, const vo
   a.cu_q = (const int*)cu_seqlens_q_i32; a.cu_k = (const int*)cu_seqlens_k_i32;
   a.head_mask_type = (const int*)head_mask_type_i32; a.streaming_info = (const int*)streaming_info_i32;
   a.num_heads = num_heads; a.num_kv_heads = num_kv_heads; a.causal = causal;
-  dim3 grid((max_seqlen_q + 16 * PWAVES - 1) / (16 * PWAVES), num_heads, batch);
+  const int q_tiles = (max_seqlen_q + PQROWS - 1) / PQROWS;
+  dim3 grid(q_tiles, num_heads, batch);
+  a.q_tiles = 0;
+  if (num_heads % 8 == 0 && (long long)q_tiles * num_heads * batch < (1LL << 31)) {
+    a.q_tiles = q_tiles;
+    grid = dim3((unsigned)((long long)q_tiles * num_heads * batch), 1, 1);
+  }
   hipLaunchKernelGGL(prefill_attn_kernel, grid, dim3(64 * PWAVES), 0, (hipStream_t)stream, a);
   return omni_launch_status();
 }

@@ -70,7 +70,6 @@ struct SelArgs {
 // exactly as KVPageSelectorTemplate.hpp:482-493, so the fp32 sums (and the fp16 scores) are bit-identical.
 constexpr int SEL_PB = 32;     // pages per workgroup
 constexpr int SEL_UN = 8;      // sub-chunks in flight per team
-constexpr int SEL_MAXG = 8;    // q heads per kv head
 
 __device__ __forceinline__ float team_xor4(float v, int lane) {
   const float up = dpp_mov<0x104>(v);    // row_shl:4 : lane i reads lane i+4
