@@ -296,6 +296,73 @@ class DecodeRunner:
         logits = torch.matmul(self.normed, self.lm_head.t())
         self.tokens.copy_(torch.argmax(logits, dim=-1))
 
+    # ---- prefill (context stage) ---------------------------------------------------------------------------
+    def prefill(self, prompt_len=None):
+        """One context-stage pass over `prompt_len` tokens per sequence in the order of the reference's decoder
+        layer at prefill shape (llama_w4a8_unpad.py:406-438 with M = B * prompt_len; ctx_update_kv.py:96-135;
+        ctx_attn_func.py:68-73): norm+quant -> qkv GEMM -> RoPE in place + KV4 page write -> varlen causal
+        attention -> quant -> o GEMM -> add -> norm+quant -> gate_up GEMM -> silu*mul -> quant -> down GEMM -> add.
+        Fills the KV pools for positions [0, prompt_len) and leaves the first generated token in self.tokens
+        (self.lengths = prompt_len), i.e. the qserve_benchmark.py protocol's prefill step.  Eager launches."""
+        import omniserve_backend.fused_attention_fine_grained_dense as fgd
+        from .backend.prefill_attn import flash_attn_varlen_func
+        c, B, dev = self.cfg, self.B, self.device
+        L = int(prompt_len if prompt_len is not None else self.lengths[0].item())
+        if L < 1 or L + 1 > self.max_context:
+            raise ValueError("prompt length does not fit the runner's KV pools")
+        T = B * L
+        hq, hk, d = self.hl, self.kl, c.head_dim
+        f16, i8 = torch.float16, torch.int8
+        buf = getattr(self, "_prefill_bufs", None)
+        if buf is None or buf["T"] != T:
+            buf = dict(T=T, x=torch.empty((T, c.hidden), dtype=f16, device=dev),
+                       qh=torch.empty((T, c.hidden), dtype=i8, device=dev),
+                       qi=torch.empty((T, self.il), dtype=i8, device=dev),
+                       qa=torch.empty((T, hq * d), dtype=i8, device=dev),
+                       qkv=torch.empty((T, (hq + 2 * hk) * d), dtype=f16, device=dev),
+                       proj=torch.empty((T, c.hidden), dtype=f16, device=dev),
+                       gu=torch.empty((T, 2 * self.il), dtype=f16, device=dev),
+                       s1=torch.empty((T,), dtype=f16, device=dev), m1=torch.empty((T,), dtype=f16, device=dev),
+                       s2=torch.empty((T,), dtype=f16, device=dev), m2=torch.empty((T,), dtype=f16, device=dev))
+            self._prefill_bufs = buf
+        x, qh, qi, qa, qkv, proj, gu = buf["x"], buf["qh"], buf["qi"], buf["qa"], buf["qkv"], buf["proj"], buf["gu"]
+        sB, mB, sA, mA = buf["s1"], buf["m1"], buf["s2"], buf["m2"]
+        tokens = torch.randint(0, c.vocab, (T,), device=dev, generator=self.gen)
+        torch.index_select(self.embed, 0, tokens, out=x)
+        lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+        cu = torch.arange(0, B + 1, dtype=torch.int32, device=dev) * L
+        pad = fgd.compute_padding_offsets(cu, L, T)
+        flags = torch.ones((hk,), dtype=torch.int32, device=dev)
+        rank = torch.arange(hk, dtype=torch.int32, device=dev)
+        q = qkv[:, : hq * d].view(T, hq, d)
+        k = qkv[:, hq * d:(hq + hk) * d].view(T, hk, d)
+        v = qkv[:, (hq + hk) * d:].view(T, hk, d)
+        for li, Ly in enumerate(self.layers):
+            if li == 0:
+                layernorm_ops.rms_norm_general_fuse_sum(qh, x, Ly["ln1"], mB, sB, c.eps, True)
+            else:
+                fused_ext.add_rms_norm_general_fuse_sum(qh, x, proj, Ly["ln1"], mB, sB, c.eps)
+            Ly["qkv"].forward(qh, sB, mB, qkv)
+            fgd.apply_bias_rope_update_kv_cache(qkv, lens, None, pad, self.block_tables[li], None, flags, rank, hq, hk, L,
+                                                self.tpb, hk * d // 2, 0, 0, 0, 0, 0, hk, 0, d, c.rope_theta, 1.0,
+                                                1 << 20, True, True, True)
+            attn = flash_attn_varlen_func(q, k, v, cu, cu, L, L, causal=True)
+            fused_kernels.invoke_quant_fuse_sum(qa, attn.view(T, hq * d), mA, sA)
+            Ly["o"].forward(qa, sA, mA, proj)
+            self._all_reduce(proj)
+            fused_ext.add_rms_norm_general_fuse_sum(qh, x, proj, Ly["ln2"], mB, sB, c.eps)
+            Ly["gate_up"].forward(qh, sB, mB, gu)
+            fused_ext.silu_mul_quant_fuse_sum(qi, gu, mA, sA)
+            Ly["down"].forward(qi, sA, mA, proj)
+            self._all_reduce(proj)
+        x.add_(proj)
+        last = x.view(B, L, c.hidden)[:, L - 1]
+        self.x.copy_(last)
+        layernorm_ops.rms_norm(self.normed, self.x, self.final_norm, c.eps, False)
+        logits = torch.matmul(self.normed, self.lm_head.t())
+        self.tokens.copy_(torch.argmax(logits, dim=-1))
+        self.lengths.fill_(L)
+
     def _all_reduce(self, buf):
         if self.tp_size > 1:
             from . import tp
