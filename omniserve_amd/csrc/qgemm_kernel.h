@@ -328,7 +328,10 @@ template <int MB, int MODE>
 struct GemvCfg {
   static constexpr int WL = (MODE == MODE_W8) ? 4 : 2;
   static constexpr int RING = (MODE == MODE_W8) ? 4 : (MB <= 2 ? 8 : 4);
-  static constexpr int WAVES = MB == 1 ? 1 : (MB == 2 ? 2 : 4);
+  // M <= 64: single-wave tiles (no barrier; K is split over the workgroup's KW waves instead); M <= 128 keeps four
+  // channel groups per workgroup sharing the staged activations (a 128-row round is 32 KiB of LDS)
+  static constexpr int WAVES = MB == 8 ? 4 : 1;
+  static constexpr int MAX_KW = MB == 1 ? 4 : (MB == 8 ? 1 : 2);   // LDS: KW x 2 buffers x MT x RK <= 64 KiB
 };
 
 //   * KW > 1 (single 64-channel group per workgroup only): KW waves split the workgroup's K-slice,
@@ -339,7 +342,8 @@ template <int MB, int MODE, bool TO_SLAB, int KW = 1>
 __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_gemv_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
   constexpr int WAVES = GemvCfg<MB, MODE>::WAVES;
-  static_assert(KW == 1 || (WAVES == 1 && MB == 1), "in-workgroup K split is for single-wave tiles");
+  static_assert(KW == 1 || WAVES == 1, "in-workgroup K split is for single-wave tiles");
+  static_assert(KW <= GemvCfg<MB, MODE>::MAX_KW, "LDS budget");
   static_assert(KW == 1 || KW == 2 || KW == 4, "KW");
   constexpr int NTHREADS = 64 * WAVES;                   // threads sharing one staged activation tile
   constexpr int WL = GemvCfg<MB, MODE>::WL;
@@ -383,11 +387,12 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_
   // activation staging: piece id -> (row m, 16-byte piece kk of the round).  A single-wave tile (MB = 1,
   // RING = 8) lets every ds_write cover 4 rows x 16 pieces (4 k-steps): with the rotated piece position
   // below that is one lane per LDS bank.
-  constexpr bool QUAD_ROWS = (NTHREADS == 64 && RK / 16 == 32 && MODE != MODE_W8);
+  constexpr bool QUAD_ROWS = (NTHREADS == 64 && (RK / 16) % 16 == 0 && MODE != MODE_W8);
+  constexpr int CPR = RK / 256;                          // 16-piece chunks per activation row of a round
   auto piece = [&](int j, int& m, int& kk) {
     if constexpr (QUAD_ROWS) {
-      m = 4 * (j >> 1) + (tid >> 4);
-      kk = (tid & 15) + 16 * (j & 1);
+      m = 4 * (j / CPR) + (tid >> 4);
+      kk = (tid & 15) + 16 * (j % CPR);
     } else {
       const int id = tid + j * NTHREADS;
       m = id / (RK / 16);
@@ -570,29 +575,33 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_
   if (!wave_active) return;   // (never taken with KW > 1: one group per workgroup)
 
   // ---- combine the K parts (KW > 1) and write back (same mapping as w4a8_gemm_kernel) ----------------
+  // (row blocks are indexed with compile-time constants only: a runtime index into acc[][] would push the
+  //  accumulators to scratch memory)
   if constexpr (KW > 1) {
     // every wave used only its own buffers so far: park the partials there, then meet
+    static_assert(MB * 4 * 64 * 16 <= 2 * MT * RK, "partials must fit the wave's staging buffers");
     v4i* mine = reinterpret_cast<v4i*>(&lds_all[kw][0][0]);
 #pragma unroll
-    for (int ab = 0; ab < 4; ++ab) mine[ab * 64 + lane] = acc[0][ab];
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab) mine[(mb * 4 + ab) * 64 + lane] = acc[mb][ab];
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ABW; ++j) {
-      v4i t = (v4i){0, 0, 0, 0};
-#pragma unroll
-      for (int w = 0; w < KW; ++w) t += reinterpret_cast<const v4i*>(&lds_all[w][0][0])[(ab0 + j) * 64 + lane];
-      acc[0][ab0 + j] = t;
-    }
   }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m = mb * 16 + mcol;
-    if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < ABW; ++j) {
-      const int ab = ab0 + j;
+    for (int ab = 0; ab < 4; ++ab) {
+      if ((ab / ABW) != kw) continue;          // row block finished by another wave of the workgroup
+      const int j = ab % ABW;                   // compile-time slot of the prefetched epilogue operands
+      v4i a4 = acc[mb][ab];
+      if constexpr (KW > 1) {
+        a4 = (v4i){0, 0, 0, 0};
+#pragma unroll
+        for (int w = 0; w < KW; ++w) a4 += reinterpret_cast<const v4i*>(&lds_all[w][0][0])[(mb * 4 + ab) * 64 + lane];
+      }
+      if (m >= p.M) continue;
       const int n = chan(ab);
-      const v4i a4 = acc[mb][ab];
       if constexpr (TO_SLAB) {
         int32_t* dst = p.slab + ((size_t)blockIdx.y * p.M + m) * p.N + n;
         *reinterpret_cast<v4i*>(dst) = a4;
@@ -689,6 +698,12 @@ static void launch_gemv_kernel(const GemmArgs& a, const GemmPlan& pl, hipStream_
     }
     if (pl.kw == 2) {
       hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, TO_SLAB, 2>), grid, dim3(128), 0, st, a);
+      return;
+    }
+  }
+  if constexpr (MB == 2 || MB == 4) {
+    if (pl.kw == 2) {
+      hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 2>), grid, dim3(128), 0, st, a);
       return;
     }
   }

@@ -16,7 +16,7 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred) {
   // bandwidth-bound regime (decode): every CU must stream weights.  One wave owns 64 channels
   // and a K-slice; activations are staged per round of RING steps, so the slice length is free.
   pl.mb = M <= 16 ? 1 : (M <= 32 ? 2 : (M <= 64 ? 4 : 8));
-  pl.waves = pl.mb == 1 ? 1 : (pl.mb == 2 ? 2 : 4);   // fixed per tile height (GemvCfg)
+  pl.waves = pl.mb == 8 ? 4 : 1;   // fixed per tile height (GemvCfg)
   const int ngroups = N / 64;
   const int round_k = (pl.mb <= 2 ? 8 : 4) * 64;     // k per ring round (W8A8 uses 4 x 64 <= this)
   auto ok = [&](int s) { return s >= 1 && (K % s) == 0 && ((K / s) % kalign) == 0; };
@@ -45,10 +45,27 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred) {
     if (g_override_waves == 1 || g_override_waves == 2 || g_override_waves == 4) kw = g_override_waves;
     while (kw > 1 && ((K / sk) % (kw * kalign)) != 0) kw >>= 1;
     pl.kw = kw;
+  } else if (pl.mb <= 4) {
+    // 16 < M <= 64: single-wave tiles of MB*16 rows, two K parts per workgroup; split across workgroups until a
+    // wave streams <= 2048 k (a wave keeps only RING x 2 KiB in flight, so short parts = more bytes in flight)
+    pl.waves = 1;
+    int kw = 2;
+    while (kw > 1 && (K % (kw * kalign)) != 0) kw >>= 1;
+    auto fits = [&](int s) { return ok(s) && ((K / s) % (kw * kalign)) == 0; };
+    int best = 1;
+    for (int s = 1; s <= 64; ++s) {
+      if (!fits(s) || K / (s * kw) < 512) continue;
+      best = s;
+      if (K / (s * kw) <= 2048) break;
+    }
+    sk = best;
+    if (g_override_sk > 0 && ok(g_override_sk)) sk = g_override_sk;
+    if (g_override_waves == 1 || g_override_waves == 2) kw = g_override_waves;
+    while (kw > 1 && ((K / sk) % (kw * kalign)) != 0) kw >>= 1;
+    pl.kw = kw;
   } else {
     auto full_rounds = [&](int s) { return ((K / s) % round_k) == 0; };
-    // split K until ~2 waves per CU stream (a wave keeps 16 KiB in flight); prefer slices made of
-    // whole rounds, and no split at all when the channels alone fill the machine (no slab traffic)
+    // M <= 128: four channel groups per workgroup share the staged activations; split K until ~2 waves per CU
     const int target_waves = 448;
     for (int s = 1; s <= 64 && ngroups * sk < target_waves; ++s) {
       if (!ok(s) || (K / s) < round_k) continue;
