@@ -209,11 +209,7 @@ __global__ __launch_bounds__(256) void silu_and_mul_kernel(half_t* __restrict__ 
     const v8h b = *reinterpret_cast<const v8h*>(in + t * 2 * d + d + c);
     v8h o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xf = (float)a[j];
-      const half_t s = (half_t)(xf / (1.0f + expf(-xf)));
-      o[j] = (half_t)((float)s * (float)b[j]);
-    }
+    for (int j = 0; j < 8; ++j) o[j] = silu_mul_h(a[j], b[j]);
     *reinterpret_cast<v8h*>(out + t * d + c) = o;
   }
 }
@@ -226,9 +222,7 @@ __global__ __launch_bounds__(256) void silu_and_mul_scalar_kernel(half_t* __rest
        idx += (size_t)gridDim.x * blockDim.x) {
     const size_t t = idx / d;
     const int c = (int)(idx % d);
-    const float xf = (float)in[t * 2 * d + c];
-    const half_t s = (half_t)(xf / (1.0f + expf(-xf)));
-    out[t * d + c] = (half_t)((float)s * (float)in[t * 2 * d + d + c]);
+    out[t * d + c] = silu_mul_h(in[t * 2 * d + c], in[t * 2 * d + d + c]);
   }
 }
 
@@ -470,9 +464,11 @@ __device__ __forceinline__ void store8_i8(int8_t* dst, const float (&x)[VT], flo
 // replay the reference's per-virtual-thread accumulation ORDER from LDS (cheap: hidden/NV adds per
 // value) and run the reference reduction tree.  Heavy per-element work (silu, split-K slab sums) is
 // spread over the whole workgroup, the ordered part stays bit-identical to oracle/elementwise.py.
-constexpr int RT = 512;       // threads per row
-constexpr int RV = 4;         // 8-element vectors per thread held in registers: hidden <= 16384
+// Geometry <RT threads per row, RV 8-element vectors per thread>: <512, 4> for decode-size batches (the row is a
+// latency chain: spread it over 8 waves), <128, 4> / <256, 8> when there are many rows (prefill: 4x / 2x more rows
+// resident per CU, the kernel becomes bandwidth-bound instead of chain-bound).  hidden <= RT * RV * 8.
 
+template <int RT>
 __device__ __forceinline__ float block_max_rt(float m, float* red) {
   m = wave_max64(m);
   __syncthreads();
@@ -513,7 +509,7 @@ __device__ __forceinline__ void ordered_partials(const float* xs, int p, int nv,
 }
 
 // quant[_fuse_sum] (NV = min(hidden,1024)) with a pluggable source
-template <bool FUSE_SUM, typename Src>
+template <int RT, int RV, bool FUSE_SUM, typename Src>
 __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, Src src0,
                                                        half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
                                                        int hidden, int nv) {
@@ -556,7 +552,7 @@ __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, 
     }
   }
   OMNI_CLK(10);
-  amax = block_max_rt(amax, red);   // (its barriers also publish xs)
+  amax = block_max_rt<RT>(amax, red);   // (its barriers also publish xs)
   OMNI_CLK(11);
   if constexpr (FUSE_SUM) {
     float s[1][VT], tot[1];
@@ -577,7 +573,7 @@ __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, 
 }
 
 // rms_norm_general[_fuse_sum] (+ fused residual sources): NV = roundup32(min(hidden,1024))
-template <bool FUSE_SUM, typename Src>
+template <int RT, int RV, bool FUSE_SUM, typename Src>
 __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict__ out, Src src0, const half_t* __restrict__ gamma,
                                                               half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
                                                               float eps, int hidden, int nv) {
@@ -645,7 +641,7 @@ __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict_
     }
   }
   OMNI_CLK(4);
-  const float amax = block_max_rt(amax_h, red);   // barriers publish the fp16-rounded y in xs
+  const float amax = block_max_rt<RT>(amax_h, red);   // barriers publish the fp16-rounded y in xs
   OMNI_CLK(5);
   if constexpr (FUSE_SUM) {
     float hs[1][VT], tot[1];
@@ -668,6 +664,7 @@ __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict_
 }
 
 // rms_norm (fp16 out): NV = min(hidden,1024)
+template <int RT, int RV>
 __global__ __launch_bounds__(RT) void rms_norm_v2_kernel(half_t* __restrict__ out, const half_t* __restrict__ in,
                                                           const half_t* __restrict__ weight, float eps, int hidden, int nv) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -716,10 +713,20 @@ __global__ __launch_bounds__(RT) void rms_norm_v2_kernel(half_t* __restrict__ ou
 
 // dispatch helpers ------------------------------------------------------------------------------------
 static inline bool v2_ok(int hidden, int nv) {
-  return hidden % 8 == 0 && nv % 32 == 0 && nv <= 1024 && hidden <= RT * RV * VT && (size_t)hidden * 4 <= 64 * 1024;
+  return hidden % 8 == 0 && nv % 32 == 0 && nv <= 1024 && hidden <= 512 * 4 * VT && (size_t)hidden * 4 <= 64 * 1024;
 }
-#define OMNI_V2_LAUNCH(KERNEL, tokens, hidden, ...) \
-  hipLaunchKernelGGL(KERNEL, dim3(tokens), dim3(RT), (size_t)(hidden) * sizeof(float), (hipStream_t)stream, __VA_ARGS__)
+constexpr int ROWS_MANY = 1024;   // from here on the narrow geometries win (measured at 16384 rows)
+// KERNEL(RT, RV) must expand to a kernel instantiation; `hidden` here is the row length that sizes the f32 LDS copy
+#define OMNI_V2_LAUNCH(KERNEL, tokens, hidden, elems, ...)                                                      \
+  do {                                                                                                          \
+    const size_t lds_ = (size_t)(hidden) * sizeof(float);                                                       \
+    if ((tokens) >= ROWS_MANY && (elems) <= 128 * 4 * VT)                                                       \
+      hipLaunchKernelGGL((KERNEL(128, 4)), dim3(tokens), dim3(128), lds_, (hipStream_t)stream, __VA_ARGS__);    \
+    else if ((tokens) >= ROWS_MANY && (elems) <= 256 * 8 * VT)                                                  \
+      hipLaunchKernelGGL((KERNEL(256, 8)), dim3(tokens), dim3(256), lds_, (hipStream_t)stream, __VA_ARGS__);    \
+    else                                                                                                        \
+      hipLaunchKernelGGL((KERNEL(512, 4)), dim3(tokens), dim3(512), lds_, (hipStream_t)stream, __VA_ARGS__);    \
+  } while (0)
 
 static inline int norm_block(int hidden, bool round32) {
   int b = hidden < NT_MAX ? hidden : NT_MAX;
@@ -738,7 +745,9 @@ extern "C" int omni_quant(void* out_i8, const void* in_f16, void* scale_f16, int
   if (tokens == 0) return OMNI_OK;
   const int nv = norm_block(hidden, false);
   if (v2_ok(hidden, nv)) {
-    OMNI_V2_LAUNCH((quant_v2_kernel<false, SrcPlain>), tokens, 8, (int8_t*)out_i8, SrcPlain{(const half_t*)in_f16, hidden},
+    #undef KQ_
+    #define KQ_(RT_, RV_) quant_v2_kernel<RT_, RV_, false, SrcPlain>
+    OMNI_V2_LAUNCH(KQ_, tokens, 8, hidden, (int8_t*)out_i8, SrcPlain{(const half_t*)in_f16, hidden},
                    (half_t*)nullptr, (half_t*)scale_f16, hidden, nv);
     return omni_launch_status();
   }
@@ -755,7 +764,9 @@ extern "C" int omni_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f
   if (tokens == 0) return OMNI_OK;
   const int nv = norm_block(hidden, false);
   if (v2_ok(hidden, nv)) {
-    OMNI_V2_LAUNCH((quant_v2_kernel<true, SrcPlain>), tokens, hidden, (int8_t*)out_i8, SrcPlain{(const half_t*)in_f16, hidden},
+    #undef KQ_
+    #define KQ_(RT_, RV_) quant_v2_kernel<RT_, RV_, true, SrcPlain>
+    OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8, SrcPlain{(const half_t*)in_f16, hidden},
                    (half_t*)sum_f16, (half_t*)scale_f16, hidden, nv);
     return omni_launch_status();
   }
@@ -773,7 +784,9 @@ extern "C" int omni_rms_norm(void* out_f16, const void* in_f16, const void* weig
   {
     const int nv = norm_block(hidden, false);
     if (v2_ok(hidden, nv)) {
-      OMNI_V2_LAUNCH(rms_norm_v2_kernel, tokens, hidden, (half_t*)out_f16, (const half_t*)in_f16,
+      #undef KQ_
+      #define KQ_(RT_, RV_) rms_norm_v2_kernel<RT_, RV_>
+      OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (half_t*)out_f16, (const half_t*)in_f16,
                      (const half_t*)weight_f16, eps, hidden, nv);
       return omni_launch_status();
     }
@@ -793,7 +806,9 @@ extern "C" int omni_rms_norm_general(void* out_i8, const void* in_f16, const voi
   {
     const int nv = norm_block(hidden, true);
     if (v2_ok(hidden, nv)) {
-      OMNI_V2_LAUNCH((general_norm_v2_kernel<false, SrcPlain>), tokens, hidden, (int8_t*)out_i8,
+      #undef KQ_
+      #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, false, SrcPlain>
+      OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8,
                      SrcPlain{(const half_t*)in_f16, hidden}, (const half_t*)weight_f16, (half_t*)nullptr,
                      (half_t*)scale_f16, eps, hidden, nv);
       return omni_launch_status();
@@ -816,7 +831,9 @@ extern "C" int omni_rms_norm_general_fuse_sum(void* out_i8, const void* in_f16,
   {
     const int nv = norm_block(hidden, true);
     if (v2_ok(hidden, nv)) {
-      OMNI_V2_LAUNCH((general_norm_v2_kernel<true, SrcPlain>), tokens, hidden, (int8_t*)out_i8,
+      #undef KQ_
+      #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, true, SrcPlain>
+      OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8,
                      SrcPlain{(const half_t*)in_f16, hidden}, (const half_t*)weight_f16, (half_t*)sum_f16,
                      (half_t*)scale_f16, eps, hidden, nv);
       return omni_launch_status();
@@ -891,7 +908,9 @@ extern "C" int omni_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f
   {
     const int nv = norm_block(hidden, true);
     if (v2_ok(hidden, nv)) {
-      OMNI_V2_LAUNCH((general_norm_v2_kernel<true, SrcAdd>), tokens, hidden, (int8_t*)out_i8,
+      #undef KQ_
+      #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, true, SrcAdd>
+      OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8,
                      SrcAdd{(half_t*)residual_f16, (const half_t*)delta_f16, hidden}, (const half_t*)weight_f16,
                      (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
       return omni_launch_status();
@@ -911,7 +930,9 @@ extern "C" int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, vo
   {
     const int nv = norm_block(d, false);
     if (v2_ok(d, nv)) {
-      OMNI_V2_LAUNCH((quant_v2_kernel<true, SrcSilu>), tokens, d, (int8_t*)out_i8, SrcSilu{(const half_t*)in_f16, d},
+      #undef KQ_
+      #define KQ_(RT_, RV_) quant_v2_kernel<RT_, RV_, true, SrcSilu>
+      OMNI_V2_LAUNCH(KQ_, tokens, d, d, (int8_t*)out_i8, SrcSilu{(const half_t*)in_f16, d},
                      (half_t*)sum_f16, (half_t*)scale_f16, d, nv);
       return omni_launch_status();
     }
@@ -935,7 +956,9 @@ extern "C" int omni_splitk_add_rms_norm_general_fuse_sum(void* out_i8, void* res
   SrcSlabAddChn src{(half_t*)residual_f16, (const int32_t*)slab_i32, (size_t)tokens * hidden, sk, hidden,
                     (const half_t*)wscales_f16, (const half_t*)w_szs_f16, (const half_t*)ascales_in_f16,
                     (const half_t*)a_ssums_in_f16, 0.f, 0.f};
-  OMNI_V2_LAUNCH((general_norm_v2_kernel<true, SrcSlabAddChn>), tokens, hidden, (int8_t*)out_i8, src,
+  #undef KQ_
+  #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, true, SrcSlabAddChn>
+  OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8, src,
                  (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
   return omni_launch_status();
 }
@@ -950,7 +973,9 @@ extern "C" int omni_attn_merge_quant_fuse_sum(void* out_i8, const void* part_ml_
   if (!v2_ok(hidden, nv)) return OMNI_EINVAL;
   if (batch == 0) return OMNI_OK;
   SrcAttnMerge src{(const float*)part_ml_f32, (const float*)part_o_f32, nsplit, num_heads, 0};
-  OMNI_V2_LAUNCH((quant_v2_kernel<true, SrcAttnMerge>), batch, hidden, (int8_t*)out_i8, src, (half_t*)sum_f16,
+  #undef KQ_
+  #define KQ_(RT_, RV_) quant_v2_kernel<RT_, RV_, true, SrcAttnMerge>
+  OMNI_V2_LAUNCH(KQ_, batch, hidden, hidden, (int8_t*)out_i8, src, (half_t*)sum_f16,
                  (half_t*)scale_f16, hidden, nv);
   return omni_launch_status();
 }

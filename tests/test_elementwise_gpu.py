@@ -14,7 +14,8 @@ def _x(tokens, hidden, seed, scale=1.0):
     return (rng.standard_normal((tokens, hidden)) * scale).astype(np.float16)
 
 
-@pytest.mark.parametrize("tokens,hidden", [(1, 128), (16, 4096), (37, 14336), (5, 1024), (3, 28672), (0, 4096)])
+@pytest.mark.parametrize("tokens,hidden", [(1, 128), (16, 4096), (37, 14336), (5, 1024), (3, 28672), (0, 4096),
+                                           (1100, 4096), (1030, 14336)])   # many rows: 128 / 256 threads per row
 @pytest.mark.parametrize("fuse", [False, True])
 def test_quant(tokens, hidden, fuse):
     import omniserve_backend.fused_kernels as fk
@@ -36,7 +37,7 @@ def test_quant(tokens, hidden, fuse):
         assert_f16_equal(ssum, sm, "sum")
 
 
-@pytest.mark.parametrize("tokens,hidden", [(1, 128), (16, 4096), (33, 8192), (7, 5120), (4, 96)])
+@pytest.mark.parametrize("tokens,hidden", [(1, 128), (16, 4096), (33, 8192), (7, 5120), (4, 96), (1100, 4096), (1030, 8192)])
 @pytest.mark.parametrize("fuse", [False, True])
 def test_rms_norm_general(tokens, hidden, fuse):
     import omniserve_backend.layernorm_ops as ln
@@ -57,7 +58,7 @@ def test_rms_norm_general(tokens, hidden, fuse):
         assert_f16_equal(ssum, sm, "sum")
 
 
-@pytest.mark.parametrize("tokens,hidden", [(1, 128), (16, 4096), (9, 8192)])
+@pytest.mark.parametrize("tokens,hidden", [(1, 128), (16, 4096), (9, 8192), (1100, 4096)])
 def test_rms_norm(tokens, hidden):
     import omniserve_backend.layernorm_ops as ln
     x = _x(tokens, hidden, tokens, 2.0)
@@ -82,7 +83,7 @@ def test_silu_and_mul(tokens, d):
     assert (np.asarray(out.cpu().numpy()).view(np.uint16) != want.view(np.uint16)).mean() < 1e-3
 
 
-@pytest.mark.parametrize("tokens,hidden", [(16, 4096), (5, 8192), (3, 128)])
+@pytest.mark.parametrize("tokens,hidden", [(16, 4096), (5, 8192), (3, 128), (1100, 4096)])
 def test_fused_add_norm_matches_the_two_reference_calls(tokens, hidden):
     import omniserve_backend.layernorm_ops as ln
     from omniserve_amd.backend import fused_ext
@@ -103,7 +104,7 @@ def test_fused_add_norm_matches_the_two_reference_calls(tokens, hidden):
     assert_f16_equal(ssum, sm, "sum")
 
 
-@pytest.mark.parametrize("tokens,d", [(16, 14336), (3, 28672), (5, 128)])
+@pytest.mark.parametrize("tokens,d", [(16, 14336), (3, 28672), (5, 128), (1030, 14336)])
 def test_fused_silu_mul_quant_matches_the_two_kernels(tokens, d):
     """Compared against the HIP silu_and_mul + quant pair (both go through the same device expf)."""
     import omniserve_backend.activation_ops as act
