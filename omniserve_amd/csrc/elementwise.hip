@@ -715,7 +715,10 @@ __global__ __launch_bounds__(RT) void rms_norm_v2_kernel(half_t* __restrict__ ou
 static inline bool v2_ok(int hidden, int nv) {
   return hidden % 8 == 0 && nv % 32 == 0 && nv <= 1024 && hidden <= 512 * 4 * VT && (size_t)hidden * 4 <= 64 * 1024;
 }
-constexpr int ROWS_MANY = 1024;   // from here on the narrow geometries win (measured at 16384 rows)
+#ifndef OMNI_ROWS_MANY
+#define OMNI_ROWS_MANY 1024
+#endif
+constexpr int ROWS_MANY = OMNI_ROWS_MANY;   // from here on the narrow geometries win (measured at 16384 rows)
 // KERNEL(RT, RV) must expand to a kernel instantiation; `hidden` here is the row length that sizes the f32 LDS copy
 #define OMNI_V2_LAUNCH(KERNEL, tokens, hidden, elems, ...)                                                      \
   do {                                                                                                          \
