@@ -24,3 +24,5 @@ extern "C" int omni_w4a8_per_chn_gemm_partial(const void* in_feats, const void* 
   a.M = M; a.N = N; a.K = K; a.out_stride = N;
   return launch_gemm_partial<MODE_CHN>(a, slab_i32, slab_bytes, sk_out, (hipStream_t)stream);
 }
+
+OMNI_CLK_READER(omni_debug_clocks_gemm_chn)

@@ -28,6 +28,7 @@ constexpr int KCHUNK = 256;  // k staged in LDS per barrier
 constexpr int STEPS = KCHUNK / KSTEP;
 
 enum { MODE_CHN = 0, MODE_GRP = 1, MODE_W8 = 2 };
+template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 struct GemmArgs {
   const int8_t* A;        // [M,K]
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   }
   const int ng = tile_n * WAVES + wave;  // 64-channel group
   const bool wave_active = (ng * 64) < p.N;
+  const int ngc = wave_active ? ng : (p.N / 64 - 1);   // inactive waves stream the last valid group again and drop it
   const int m0 = tile_m * MT;
   const int k_begin = blockIdx.y * p.kslice;
   const int k_end = min(p.K, k_begin + p.kslice);
@@ -110,9 +112,9 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   const int lx = (lane >> 3) & 1, lc = lane & 7, le = lane >> 4;
   const uint8_t* wbase;
   if constexpr (MODE == MODE_W8) {
-    wbase = p.W + (size_t)(ng * 64 + (lane & 15)) * p.K + (lane >> 4) * 16;
+    wbase = p.W + (size_t)(ngc * 64 + (lane & 15)) * p.K + (lane >> 4) * 16;
   } else {
-    wbase = p.W + ((size_t)(2 * ng + lx) * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
+    wbase = p.W + ((size_t)(2 * ngc + lx) * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
   }
   auto load_w = [&](int k, int j) -> uint4 {
     // W4: j = tile parity inside the 64-k step.  W8: j = 16-row block (0..3).
@@ -146,17 +148,24 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
       kk = (id & 3) | (((id >> 5) & 3) << 2);
     }
   };
-  auto load_a = [&](int chunk) {
+  auto load_a = [&](int chunk, bool plain) {
     const int kc = k_begin + chunk * KCHUNK;
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) {
       int m, kk;
       piece(j, m, kk);
       const int k = kc + kk * 16;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (tid + j * NTHREADS < MT * KCHUNK / 16 && (m0 + m) < p.M && k < k_end)
-        v = *reinterpret_cast<const uint4*>(p.A + (size_t)(m0 + m) * p.K + k);
-      areg[j] = v;
+      if (plain) {   // whole tile in range (workgroup-uniform, hoisted out of the steady loop): nothing to predicate
+        areg[j] = *reinterpret_cast<const uint4*>(p.A + (size_t)(m0 + m) * p.K + k);
+        continue;
+      }
+      // branch-free (a branch around a load turns every later wait into vmcnt(0)): out-of-range pieces read a
+      // valid address and are zeroed by a select
+      const bool ok = tid + j * NTHREADS < MT * KCHUNK / 16 && (m0 + m) < p.M && k < k_end;
+      const int mr = (m0 + m) < p.M ? (m0 + m) : (p.M - 1);
+      const int kr = k < k_end ? k : k_begin;
+      const uint4 v = *reinterpret_cast<const uint4*>(p.A + (size_t)mr * p.K + kr);
+      areg[j] = ok ? v : make_uint4(0, 0, 0, 0);
     }
   };
   auto store_a = [&](int buf) {
@@ -188,44 +197,62 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
     for (int ab = 0; ab < 4; ++ab) acc[mb][ab] = (v4i){0, 0, 0, 0};
 
   // ---- prologue --------------------------------------------------------------------------
-  if (wave_active) {
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s)
-      if (s < nsteps) {
+  for (int s = 0; s < STEPS; ++s) {
+    const int ks = s < nsteps ? s : 0;      // (short slices) re-read step 0, never consumed
 #pragma unroll
-        for (int j = 0; j < WL; ++j) wq[s][j] = load_w(k_begin + s * KSTEP, j);
-      }
+    for (int j = 0; j < WL; ++j) wq[s][j] = load_w(k_begin + ks * KSTEP, j);
   }
-  load_a(0);
+  load_a(0, false);
   store_a(0);
 
   // per-group second-level params for the current chunk (2 groups of 128 per chunk)
   uint32_t gs[2] = {0, 0}, gz[2] = {0, 0};
-
-  for (int c = 0; c < nchunks; ++c) {
-    const int kc = k_begin + c * KCHUNK;
-    const int steps_here = min(STEPS, nsteps - c * STEPS);
-    const bool has_next = (c + 1) < nchunks;
-    if (has_next) load_a(c + 1);
-    if constexpr (MODE == MODE_GRP) {
-      if (wave_active) {
-        const size_t col = (size_t)(2 * ng + lx) * 32 + lc * 4;
+  if constexpr (MODE == MODE_GRP) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int g = (kc + h * 128) / 128;
-          if (kc + h * 128 < k_end) {
-            gs[h] = *reinterpret_cast<const uint32_t*>(p.s2s + (size_t)g * p.N + col);
-            gz[h] = *reinterpret_cast<const uint32_t*>(p.s2z + (size_t)g * p.N + col);
-          }
-        }
+    for (int h = 0; h < 2; ++h) {
+      const int kg = (k_begin + h * 128 < k_end) ? k_begin + h * 128 : k_begin;
+      gs[h] = *reinterpret_cast<const uint32_t*>(p.s2s + (size_t)(kg / 128) * p.N + ((size_t)(2 * ngc + lx) * 32 + lc * 4));
+      gz[h] = *reinterpret_cast<const uint32_t*>(p.s2z + (size_t)(kg / 128) * p.N + ((size_t)(2 * ngc + lx) * 32 + lc * 4));
+    }
+  }
+
+#ifdef OMNI_DEBUG_CLOCKS
+  unsigned long long dbg_barrier = 0, dbg_vmwait = 0;
+  const unsigned long long dbg_start = wall_clock64();
+#endif
+  // One K chunk.  STEADY = this chunk and the next are whole: no control flow at all, so the waits the compiler
+  // inserts are counted (vmcnt(N)) and the weight refills / next activation tile stay in flight across the MFMAs.
+  // The generic form (last chunks, ragged K) keeps the conditions.
+  const size_t gcol = (size_t)(2 * ngc + lx) * 32 + lc * 4;
+  auto run_chunk = [&](int c, auto steady_tag) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
+    const int kc = k_begin + c * KCHUNK;
+    const int steps_here = STEADY ? STEPS : min(STEPS, nsteps - c * STEPS);
+    const bool has_next = STEADY ? true : (c + 1) < nchunks;
+    if (has_next) load_a(c + 1, STEADY);
+    uint32_t gsn[2] = {0, 0}, gzn[2] = {0, 0};   // second-level params of the NEXT chunk (consumed a chunk later)
+    if constexpr (MODE == MODE_GRP) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kn = kc + KCHUNK + h * 128;
+        const int kg = (STEADY || kn < k_end) ? kn : k_begin;
+        gsn[h] = *reinterpret_cast<const uint32_t*>(p.s2s + (size_t)(kg / 128) * p.N + gcol);
+        gzn[h] = *reinterpret_cast<const uint32_t*>(p.s2z + (size_t)(kg / 128) * p.N + gcol);
       }
     }
+#ifdef OMNI_DEBUG_CLOCKS
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
     __syncthreads();  // chunk c of A is visible in lds[c&1]
+#ifdef OMNI_DEBUG_CLOCKS
+    dbg_barrier += wall_clock64() - dbg_t0;
+#endif
     const uint8_t* abuf = lds[c & 1];
 
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      if (s < steps_here && wave_active) {
+      if (STEADY || s < steps_here) {
         v4i wa[4];
         if constexpr (MODE == MODE_W8) {
 #pragma unroll
@@ -253,9 +280,12 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
             }
         }
         // refill this step's weight registers for the next chunk
-        if (has_next && (c + 1) * STEPS + s < nsteps) {
+        if (STEADY || (has_next && (c + 1) * STEPS + s < nsteps)) {
 #pragma unroll
           for (int j = 0; j < WL; ++j) wq[s][j] = load_w(kc + KCHUNK + s * KSTEP, j);
+          // keep the refill HERE (a whole chunk of MFMAs ahead of its use): the scheduler otherwise sinks all
+          // four steps' loads to the end of the chunk, right in front of the wait that needs them
+          if constexpr (STEADY) __builtin_amdgcn_sched_barrier(0x78F);   // everything but VMEM may still move across
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
@@ -266,9 +296,33 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
         }
       }
     }
+#ifdef OMNI_DEBUG_CLOCKS
+    const unsigned long long dbg_t1 = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (debug build) isolate the wait for the staged loads
+    dbg_vmwait += wall_clock64() - dbg_t1;
+#endif
     if (has_next) store_a((c + 1) & 1);
+    if constexpr (MODE == MODE_GRP) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { gs[h] = gsn[h]; gz[h] = gzn[h]; }
+    }
+  };
+  const int nfull = nsteps / STEPS;     // whole chunks
+  int c = 0;
+  // (per-group mode keeps the generic loop: its dequant temporaries + the pinned refills exceed 256 VGPRs and spill)
+  if constexpr (MODE != MODE_GRP) {
+    if (m0 + MT <= p.M && MT * KCHUNK / 16 == A_LOADS * NTHREADS)   // all activation rows of the tile exist
+      for (; c + 1 < nfull; ++c) run_chunk(c, BoolTag<true>{});
   }
+  for (; c < nchunks; ++c) run_chunk(c, BoolTag<false>{});
 
+#ifdef OMNI_DEBUG_CLOCKS
+  if (blockIdx.x == 0 && (tid & 63) == 0) {   // per wave of workgroup 0: total / barrier / vmcnt wait (10 ns ticks)
+    omni_dbg_clk[wave * 4 + 0] = wall_clock64() - dbg_start;
+    omni_dbg_clk[wave * 4 + 1] = dbg_barrier;
+    omni_dbg_clk[wave * 4 + 2] = dbg_vmwait;
+  }
+#endif
   if (!wave_active) return;
 
   // ---- write back ------------------------------------------------------------------------
