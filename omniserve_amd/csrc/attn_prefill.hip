@@ -46,7 +46,8 @@ struct PrefillArgs {
 #ifndef OMNI_PREFILL_MIN_BLOCKS
 #define OMNI_PREFILL_MIN_BLOCKS 2
 #endif
-__global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) void prefill_attn_kernel(PrefillArgs p) {
+__global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void prefill_attn_kernel(PrefillArgs p) {
   __shared__ __attribute__((aligned(16))) uint8_t ktile[2][PKTILE];
   __shared__ __attribute__((aligned(16))) uint8_t vtile[2][PVTILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -101,27 +102,30 @@ __global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) void prefill_
   const int win_lo = streaming ? q_first + off - local + 1 : 0;                   // first local key of the first row
   auto skipped = [&](int kb) { return streaming && kb >= sink && kb + PKT <= win_lo; };   // tile inside the masked band
 
-  // cooperative tile staging: thread -> 4 (key, 16-B piece) pairs of K and of V
-  uint4 kreg[PPT], vreg[PPT];
-  auto load_tile = [&](int kb) {
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int pid = tid + 64 * PWAVES * j;
-      const int key = kb + (pid >> 4), piece = pid & 15;
-      const int kc = key < len_k ? key : (len_k - 1);
-      kreg[j] = *reinterpret_cast<const uint4*>(p.k + (size_t)(k_begin + kc) * p.k_stride + (size_t)hk * PDH + piece * 8);
-      vreg[j] = *reinterpret_cast<const uint4*>(p.v + (size_t)(k_begin + kc) * p.v_stride + (size_t)hk * PDH + piece * 8);
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int pid = tid + 64 * PWAVES * j;
-      const int key = pid >> 4, piece = pid & 15;
-      *reinterpret_cast<uint4*>(&ktile[buf][key * PKROW + ((piece ^ (key & 15)) << 4)]) = kreg[j];
-      *reinterpret_cast<uint4*>(&vtile[buf][key * PVROW + (piece << 4)]) = vreg[j];
-    }
-  };
+  // cooperative tile staging: thread -> PPT (key, 16-B piece) pairs of K and of V.  The staging registers are
+  // plain named values (not arrays captured by a lambda): as arrays they ended up in scratch memory, which put a
+  // full wait right behind every prefetch load.
+  static_assert(PPT == 2, "staging below is written for two pieces per thread");
+  const int skey0 = tid >> 4, spiece = tid & 15;            // piece 0: keys 0..31, piece 1: keys 32..63
+  const int skey1 = skey0 + 32;
+  uint4 kreg0, kreg1, vreg0, vreg1;
+#define PREFILL_LOAD_TILE(kb_)                                                                                    \
+  do {                                                                                                            \
+    const int ka_ = (kb_) + skey0 < len_k ? (kb_) + skey0 : (len_k - 1);                                          \
+    const int kb2_ = (kb_) + skey1 < len_k ? (kb_) + skey1 : (len_k - 1);                                         \
+    const size_t oa_ = (size_t)(k_begin + ka_), ob_ = (size_t)(k_begin + kb2_);                                   \
+    kreg0 = *reinterpret_cast<const uint4*>(p.k + oa_ * p.k_stride + (size_t)hk * PDH + spiece * 8);               \
+    vreg0 = *reinterpret_cast<const uint4*>(p.v + oa_ * p.v_stride + (size_t)hk * PDH + spiece * 8);               \
+    kreg1 = *reinterpret_cast<const uint4*>(p.k + ob_ * p.k_stride + (size_t)hk * PDH + spiece * 8);               \
+    vreg1 = *reinterpret_cast<const uint4*>(p.v + ob_ * p.v_stride + (size_t)hk * PDH + spiece * 8);               \
+  } while (0)
+#define PREFILL_STORE_TILE(buf_)                                                                                  \
+  do {                                                                                                            \
+    *reinterpret_cast<uint4*>(&ktile[buf_][skey0 * PKROW + ((spiece ^ (skey0 & 15)) << 4)]) = kreg0;               \
+    *reinterpret_cast<uint4*>(&vtile[buf_][skey0 * PVROW + (spiece << 4)]) = vreg0;                                \
+    *reinterpret_cast<uint4*>(&ktile[buf_][skey1 * PKROW + ((spiece ^ (skey1 & 15)) << 4)]) = kreg1;               \
+    *reinterpret_cast<uint4*>(&vtile[buf_][skey1 * PVROW + (spiece << 4)]) = vreg1;                                \
+  } while (0)
   auto next_tile = [&](int kb) {     // first tile >= kb that is not skipped (or >= k_hi)
     while (kb < k_hi && skipped(kb)) kb += PKT;
     return kb;
@@ -130,14 +134,15 @@ __global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) void prefill_
   const int tr_off = (4 * l4 + (l15 >> 2)) * PVROW + (l15 & 3) * 8;
   int kb = next_tile(0);
   if (kb < k_hi) {
-    load_tile(kb);
-    store_tile(0);
+    PREFILL_LOAD_TILE(kb);
+    PREFILL_STORE_TILE(0);
   }
   __syncthreads();
   int buf = 0;
   while (kb < k_hi) {
     const int kb_next = next_tile(kb + PKT);
-    if (kb_next < k_hi) load_tile(kb_next);                      // in flight during the MFMAs below
+    // next tile in flight during the MFMAs below (past the end: the last tile again, branch-free, never stored)
+    PREFILL_LOAD_TILE(kb_next < k_hi ? kb_next : kb);
     const uint8_t* kt = ktile[buf];
     const uint8_t* vt = vtile[buf];
     // ---- S^T tile: 4 blocks of 16 keys x 2 query blocks ---------------------------------------------------
@@ -165,8 +170,7 @@ __global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) void prefill_
     v8h pb[PQB][2];
 #pragma unroll
     for (int j = 0; j < PQB; ++j) {
-      float sv[16];
-      float tmax = -1e30f;
+      float tmax = -1e30f;       // scaled (and masked) scores overwrite st[j] in place: no second 16-register copy
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) void prefill_
             if (streaming) ok = ok && (key < sink || (qrow[j] + off) - key < local);
             x = ok ? x : -1e30f;
           }
-          sv[u * 4 + r] = x;
+          st[j][u][r] = x;
           tmax = __builtin_fmaxf(tmax, x);
         }
       tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 16, 64));
@@ -189,7 +193,8 @@ __global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) void prefill_
       float psum = 0.0f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pe = (full || sv[e] > -1e29f) ? __builtin_amdgcn_exp2f(sv[e] - m_new) : 0.0f;
+        const float x = st[j][e >> 2][e & 3];
+        const float pe = (full || x > -1e29f) ? __builtin_amdgcn_exp2f(x - m_new) : 0.0f;
         pb[j][e >> 3][e & 7] = (half_t)pe;   // keys 4*l4+r of blocks (2kk, 2kk+1) -> k-slots of the 32-key step kk
         psum += pe;
       }
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) void prefill_
         for (int j = 0; j < PQB; ++j) oacc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[j][kk], oacc[j][c], 0, 0, 0);
       }
     // ---- publish the next tile -----------------------------------------------------------------------------------
-    if (kb_next < k_hi) store_tile(buf ^ 1);
+    if (kb_next < k_hi) PREFILL_STORE_TILE(buf ^ 1);
     __syncthreads();
     buf ^= 1;
     kb = kb_next;
@@ -239,6 +244,9 @@ __global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) void prefill_
     }
   }
 }
+
+#undef PREFILL_LOAD_TILE
+#undef PREFILL_STORE_TILE
 
 }  // namespace omni
 
