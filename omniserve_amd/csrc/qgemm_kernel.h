@@ -176,7 +176,9 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
       piece(j, m, kk);
       const int ks = kk >> 2;
       if constexpr (MODE == MODE_W8) {
-        *reinterpret_cast<uint4*>(&lds[buf][((ks * 4 + (kk & 3)) * MT + m) * 16]) = areg[j];
+        // (component-wise copy: assigning the whole uint4 keeps `areg` in scratch memory)
+        *reinterpret_cast<uint4*>(&lds[buf][((ks * 4 + (kk & 3)) * MT + m) * 16]) =
+            make_uint4(areg[j].x, areg[j].y, areg[j].z, areg[j].w);
       } else {
         // kk = 16-byte piece of the row: tp = tile parity, d = k5; its dword e belongs to slot e of the
         // step's B operand, at byte tp*8 + d*4 of the slot
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
           for (int j = 0; j < WL; ++j) wq[s][j] = load_w(kc + KCHUNK + s * KSTEP, j);
           // keep the refill HERE (a whole chunk of MFMAs ahead of its use): the scheduler otherwise sinks all
           // four steps' loads to the end of the chunk, right in front of the wait that needs them
-          if constexpr (STEADY) __builtin_amdgcn_sched_barrier(0x78F);   // everything but VMEM may still move across
+          if constexpr (STEADY && MODE != MODE_W8) __builtin_amdgcn_sched_barrier(0x78F);   // everything but VMEM may still move across
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
@@ -469,7 +471,8 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_
       int m, kk;
       piece(j, m, kk);
       if constexpr (MODE == MODE_W8) {
-        *reinterpret_cast<uint4*>(&lds[buf][((kk >> 2) * MT + m) * 64 + (kk & 3) * 16]) = areg[j];
+        *reinterpret_cast<uint4*>(&lds[buf][((kk >> 2) * MT + m) * 64 + (kk & 3) * 16]) =
+            make_uint4(areg[j].x, areg[j].y, areg[j].z, areg[j].w);   // component-wise: keeps areg in VGPRs
       } else {
         // dword e of the piece goes to 16-B slot (e + kp) & 3 of row (kp, m): see w4a8_gemm_kernel
         const int kp = kk >> 2, tp = (kk >> 1) & 1, d = kk & 1;
