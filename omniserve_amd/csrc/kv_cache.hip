@@ -653,6 +653,7 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
       if (pg < p.max_blocks) my_page = tab[pg];   // entries past the sequence's pages are never dereferenced
     }
   }
+  const int64_t dummy_ptr = ktab[0];   // the sequence's first page: always allocated (an empty split reads it, unused)
   constexpr int QIT = ((G + 1) * 64 + DEC_THREADS - 1) / DEC_THREADS;
   half_t qa[QIT], qbv[QIT];
 #pragma unroll
@@ -716,6 +717,8 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
   OMNI_CLK(17);
   __syncthreads();   // pages[] visible
 
+  const bool has_tokens = nt > 0;
+  const uint8_t* dummy_page = reinterpret_cast<const uint8_t*>(dummy_ptr);
   const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
   const size_t vhead_off = (size_t)hrank * lay.tpb * ROW_BYTES + vpiece * 16;
   uint4 vraw[MF_UT][2];
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
         const int tok = ti < nt ? t0 + ti : t0;
         int pidx, slot;
         locate(tok, pidx, slot);
-        const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[40 + pidx]);
+        const uint8_t* pg = has_tokens ? reinterpret_cast<const uint8_t*>(pages[40 + (has_tokens ? pidx : 0)]) : dummy_page;
         vraw[u][h] = *reinterpret_cast<const uint4*>(pg + vhead_off + (size_t)slot * ROW_BYTES);
         const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
         vsc[u][h] = tail[0];
@@ -746,17 +749,17 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
       const int tok = ti < nt ? t0 + ti : t0;
       int pidx, slot;
       locate(tok, pidx, slot);
-      const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[pidx]);
+      const uint8_t* pg = has_tokens ? reinterpret_cast<const uint8_t*>(pages[has_tokens ? pidx : 0]) : dummy_page;
       kraw[u] = *reinterpret_cast<const uint4*>(pg + khead_off + (size_t)slot * ROW_BYTES);
       const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
       ksc[u] = tail[0];
       kze[u] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
     }
   };
-  if (nt > 0) {   // (workgroup-uniform) an empty split has no valid page to touch
-    load_k_batch(wave);
-    load_v_batch(wave);
-  }
+  // no branch around these loads (a branch would turn the wait for K into a wait for K AND V): an empty split
+  // reads the sequence's first page instead (discarded)
+  load_k_batch(wave);
+  load_v_batch(wave);
 
   // RoPE(q) (and k of the current token) into LDS while the cache bytes are in flight
 #pragma unroll
