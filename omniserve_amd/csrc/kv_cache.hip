@@ -1014,6 +1014,414 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
   }
 }
 
+// Single-sweep (flash) variant of the kernel above -- the default.
+// FG: LServe fine-grained mode.  The split runs over a head's list of *attended* cached tokens
+// ("virtual" tokens): all of them for a retrieval head, the tokens of the selected pages with
+// fg.dyn (one list per q head, hence G = 1), min(sink+local-1, tlen) tokens read through the page
+// ring for a streaming head (decoderMaskedMultiheadAttentionTemplate.hpp:1475-1537 of
+// fused_attention_fine_grained/dense_attention, :1566-1641 of sparse_attention).
+#ifndef OMNI_FLASH_MIN_BLOCKS
+#define OMNI_FLASH_MIN_BLOCKS 2
+#endif
+template <int G, bool DIRECT, bool FG = false>
+__global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode_flash_kernel(DecodeArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  half_t* q_lds = reinterpret_cast<half_t*>(smem);            // [G][128] dequant order
+  half_t* kcur = q_lds + G * DH;                              // [128] natural order (post RoPE)
+  half_t* kcur_p = kcur + DH;                                 // [128] dequant order
+  half_t* vcur = kcur_p + DH;                                 // [128]
+  float* red = reinterpret_cast<float*>(vcur + DH);           // [64]
+  int64_t* pages = reinterpret_cast<int64_t*>(red + 64);      // [2][40]
+  float* xbuf = reinterpret_cast<float*>(pages + 80);         // [4 waves][G][128]
+  float* mlbuf = xbuf + DEC_WAVES * G * DH;                   // [4 waves][G][2]  (max, sum) of each wave
+  uint8_t* vtile = reinterpret_cast<uint8_t*>(mlbuf + DEC_WAVES * G * 2);   // [4 waves][32][VROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x;
+  const int group = p.num_heads / p.num_kv_heads;
+  const int qg = group / G;
+  const int hk = blockIdx.y / qg;
+  const int sub = blockIdx.y % qg;
+  const int hq0 = hk * group + sub * G;
+  const int b = blockIdx.z;
+  OMNI_CLK(16);
+  const KvLayout lay = p.lay;
+  // The kernel is a chain of memory round trips, so the requests are ordered to need only two of them:
+  //   trip 1 (independent of the sequence length): length, page-table window, raw q / k / v rows;
+  //   trip 2: RoPE coefficients of position tlen, and every K and V byte of the split.
+  // The split geometry is fixed on the host (split s = virtual tokens [s*split_tokens, +split_tokens)),
+  // so the page window does not wait for the length.
+  // head class: pool geometry and page table of this kv head
+  int hrank = hk, hpool = lay.num_kv_heads, tab_blocks = p.max_blocks;
+  bool streaming = false;
+  const int64_t* ktab = p.kv_pointers + (size_t)b * 2 * p.max_blocks;
+  const int* dyn = nullptr;
+  if constexpr (FG) {
+    hrank = p.fg.rank[hk];
+    streaming = p.fg.flags[hk] == 0;
+    hpool = streaming ? p.fg.num_strm : p.fg.num_retr;
+    if (streaming) {
+      tab_blocks = p.fg.strm_blocks;
+      ktab = p.fg.strm_pointers + (size_t)b * 2 * tab_blocks;
+    } else if (p.fg.dyn) {
+      dyn = p.fg.dyn + ((size_t)b * p.num_heads + hq0) * p.fg.num_dyn;
+    }
+  }
+  const int64_t* vtab = ktab + tab_blocks;
+  const int pool_bytes_per_seq = hpool * lay.tpb * ROW_BYTES;
+  const float inv_sqrt_dh = 0.08838834764831845f;
+  const int vt0 = split * p.split_tokens;
+  const int page0 = (FG && streaming) ? 0 : (vt0 >> lay.tpb_log2);
+  const bool owns_cur = split == p.nsplit - 1;
+
+  // ---- trip 1 -----------------------------------------------------------------------------------------
+  int64_t my_page = 0;
+  if (tid < 80) {
+    const int pi = tid < 40 ? tid : tid - 40;
+    const int64_t* tab = tid < 40 ? ktab : vtab;
+    const int pg = page0 + pi;
+    if constexpr (FG) {
+      if (streaming) {               // the whole ring (<= 40 pages, checked on the host)
+        if (pg < tab_blocks) my_page = tab[pg];
+      } else if (dyn) {              // selected pages, in selection order
+        if (pg < p.fg.num_dyn) {
+          const int sel = dyn[pg];
+          if (sel >= 0 && sel < tab_blocks) my_page = tab[sel];
+        }
+      } else if (pg < tab_blocks) {
+        my_page = tab[pg];
+      }
+    } else {
+      if (pg < p.max_blocks) my_page = tab[pg];   // entries past the sequence's pages are never dereferenced
+    }
+  }
+  const int64_t dummy_ptr = ktab[0];   // the sequence's first page: always allocated (an empty split reads it, unused)
+  constexpr int QIT = ((G + 1) * 64 + DEC_THREADS - 1) / DEC_THREADS;
+  half_t qa[QIT], qbv[QIT];
+#pragma unroll
+  for (int j = 0; j < QIT; ++j) {
+    const int idx = tid + j * DEC_THREADS;
+    const int h = idx >> 6, i = idx & 63;
+    const half_t* src = h < G ? p.q + (size_t)b * p.q_stride + (size_t)(hq0 + h) * DH
+                              : p.k + (size_t)b * p.kv_stride + (size_t)hk * DH;   // h > G (idle slots): k again
+    qa[j] = src[i];
+    qbv[j] = src[i + 64];
+  }
+  half_t vcur_r = (half_t)0.0f;
+  if (tid < DH) vcur_r = p.v[(size_t)b * p.kv_stride + (size_t)hk * DH + tid];
+
+  const int tlen = p.lengths[b] - 1;
+  int nvirt = tlen, gap = 0;   // attended cached tokens; streaming: virtual i >= sink is token i + gap
+  if constexpr (FG) {
+    if (streaming) {
+      nvirt = min(p.fg.sink + p.fg.local - 1, tlen);
+      gap = tlen - nvirt;
+    } else if (dyn) {
+      nvirt = tlen > 0 ? (p.fg.num_dyn - 1) * lay.tpb + ((tlen - 1) & (lay.tpb - 1)) + 1 : 0;
+    }
+  }
+  const int t0 = min(nvirt, vt0);
+  const int t1 = min(nvirt, vt0 + p.split_tokens);
+  const int nt = t1 - t0;
+  if (tid < 80) pages[tid] = my_page;
+
+  // virtual token -> (index into pages[], slot in the page)
+  auto locate = [&](int vt, int& pidx, int& slot) {
+    if (FG && streaming) {
+      const int lt = vt < p.fg.sink ? vt : vt + gap;
+      pidx = ring_block(lt >> lay.tpb_log2, p.fg.sink_blocks, p.fg.local_blocks);
+      slot = lt & (lay.tpb - 1);
+    } else {
+      pidx = (vt >> lay.tpb_log2) - page0;
+      slot = vt & (lay.tpb - 1);
+    }
+  };
+
+  const int ntiles = (nt + 31) >> 5;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int jh = l15 < G ? l15 : 0;                               // this lane's q-head column (clamped)
+  const int tail_off = pool_bytes_per_seq + hrank * lay.tpb * 2;
+  const int zero_off = hpool * lay.tpb * 2;
+
+  // ---- trip 2: RoPE coefficients + the first K and V batches (normally: all of the split) -------------------
+  float rc[QIT], rs[QIT];
+  {
+    const int rp = tlen < p.rope_max_pos ? tlen : p.rope_max_pos - 1;
+    const float* cs = p.rope + (size_t)rp * DH;
+#pragma unroll
+    for (int j = 0; j < QIT; ++j) {
+      const int i = (tid + j * DEC_THREADS) & 63;
+      const float2 t = *reinterpret_cast<const float2*>(cs + 2 * i);
+      rc[j] = t.x; rs[j] = t.y;
+    }
+  }
+  OMNI_CLK(17);
+  __syncthreads();   // pages[] visible
+
+  const bool has_tokens = nt > 0;
+  const uint8_t* dummy_page = reinterpret_cast<const uint8_t*>(dummy_ptr);
+  const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
+  const size_t vhead_off = (size_t)hrank * lay.tpb * ROW_BYTES + vpiece * 16;
+  const size_t khead_off = (size_t)hrank * lay.tpb * ROW_BYTES + l4 * 16;  // K: lane = (token l15, 16-B piece l4)
+  // One sweep over the split (flash-decoding inside the workgroup): wave w owns the 32-token tiles w, w+4, ... and
+  // for each runs Q.K^T -> online softmax in registers -> P.V; a batch of FB tiles' K AND V bytes is in flight
+  // while the previous batch is consumed.  No workgroup barrier until the four waves' (max, sum, O) are combined.
+  constexpr int FB = 2;
+  uint4 kraw[FB][2], vraw[FB][2];
+  half_t ksc[FB][2], kze[FB][2], vsc[FB][2], vze[FB][2];
+  auto load_batch = [&](int i0) {   // branch-free: out-of-range tokens re-read token t0 (or the dummy page)
+#pragma unroll
+    for (int u = 0; u < FB; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int tile = wave + DEC_WAVES * (i0 + u);
+        {
+          const int ti = tile * 32 + h * 16 + l15;
+          const int tok = ti < nt ? t0 + ti : t0;
+          int pidx, slot;
+          locate(tok, pidx, slot);
+          const uint8_t* pg = has_tokens ? reinterpret_cast<const uint8_t*>(pages[has_tokens ? pidx : 0]) : dummy_page;
+          kraw[u][h] = *reinterpret_cast<const uint4*>(pg + khead_off + (size_t)slot * ROW_BYTES);
+          const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
+          ksc[u][h] = tail[0];
+          kze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
+        }
+        {
+          const int ti = tile * 32 + h * 16 + vtok;
+          const int tok = ti < nt ? t0 + ti : t0;
+          int pidx, slot;
+          locate(tok, pidx, slot);
+          const uint8_t* pg = has_tokens ? reinterpret_cast<const uint8_t*>(pages[40 + (has_tokens ? pidx : 0)]) : dummy_page;
+          vraw[u][h] = *reinterpret_cast<const uint4*>(pg + vhead_off + (size_t)slot * ROW_BYTES);
+          const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
+          vsc[u][h] = tail[0];
+          vze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
+        }
+      }
+  };
+  load_batch(0);
+
+  // RoPE(q) (and k of the current token) into LDS while the cache bytes are in flight
+#pragma unroll
+  for (int j = 0; j < QIT; ++j) {
+    const int idx = tid + j * DEC_THREADS;
+    const int h = idx >> 6, i = idx & 63;
+    if (h > G || (h == G && !owns_cur)) continue;
+    const float c = rc[j], sn = rs[j];
+    const float a = (float)qa[j], bb = (float)qbv[j];
+    const float t0f = c * a, t1f = sn * bb, t2f = c * bb, t3f = sn * a;
+    const half_t r0 = (half_t)(t0f - t1f), r1 = (half_t)(t2f + t3f);
+    if (h < G) {
+      q_lds[h * DH + perm_pos(i)] = r0;
+      q_lds[h * DH + perm_pos(i + 64)] = r1;
+    } else {
+      kcur[i] = r0; kcur[i + 64] = r1;
+      kcur_p[perm_pos(i)] = r0; kcur_p[perm_pos(i + 64)] = r1;
+    }
+  }
+  if (owns_cur && tid < DH) vcur[tid] = vcur_r;
+  __syncthreads();
+
+  float scur[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) scur[g] = 0.0f;
+  if (owns_cur) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float a = (float)q_lds[g * DH + lane] * (float)kcur_p[lane] +
+                (float)q_lds[g * DH + 64 + lane] * (float)kcur_p[64 + lane];
+      a = wave_sum64(a);
+      scur[g] = a * inv_sqrt_dh;
+    }
+  }
+
+  v8h qb[4];  // B operand of S^T = K.q^T: q[head jh][32*l4 + 8s + (0..7 in dequant order)]
+#pragma unroll
+  for (int sidx = 0; sidx < 4; ++sidx) qb[sidx] = *reinterpret_cast<const v8h*>(q_lds + jh * DH + 32 * l4 + 8 * sidx);
+  v4f oacc[8];   // block c: rows = column positions c*16 + 4*l4 + r of the V tile, col = head l15
+#pragma unroll
+  for (int c = 0; c < 8; ++c) oacc[c] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.0f;   // this lane's head column: running max, partial sum over its own tokens
+  uint8_t* vt = vtile + wave * VTILE;
+  const int tr_off = (4 * l4 + (l15 >> 2)) * VROW + (l15 & 3) * 8;
+  const int my_tiles = ntiles > wave ? (ntiles - wave + DEC_WAVES - 1) / DEC_WAVES : 0;
+  for (int i0 = 0; i0 < my_tiles; i0 += FB) {
+    uint4 kr[FB][2], vr[FB][2];
+    half_t ks[FB][2], kz[FB][2], vs[FB][2], vz[FB][2];
+#pragma unroll
+    for (int u = 0; u < FB; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        kr[u][h] = kraw[u][h]; ks[u][h] = ksc[u][h]; kz[u][h] = kze[u][h];
+        vr[u][h] = vraw[u][h]; vs[u][h] = vsc[u][h]; vz[u][h] = vze[u][h];
+      }
+    if (i0 + FB < my_tiles) load_batch(i0 + FB);   // next batch in flight while this one is consumed
+#pragma unroll
+    for (int u = 0; u < FB; ++u) {
+      const int tbase = (wave + DEC_WAVES * (i0 + u)) * 32;
+      if (tbase >= nt) continue;  // wave-uniform
+      // ---- scores of 32 tokens: two 16-token groups ----
+      float x[8];
+      float tmax = -1e30f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const half_t ch = (half_t)(-(float)ks[u][h] * (float)kz[u][h]);
+        v2h kd[16];
+        kv4_dequant16(kr[u][h], (v2h){ks[u][h], ks[u][h]}, (v2h){ch, ch}, kd);
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+          const v8h a = {kd[4 * sidx][0], kd[4 * sidx][1], kd[4 * sidx + 1][0], kd[4 * sidx + 1][1],
+                         kd[4 * sidx + 2][0], kd[4 * sidx + 2][1], kd[4 * sidx + 3][0], kd[4 * sidx + 3][1]};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qb[sidx], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // acc[r] = q[head l15] . K[token tbase + 16h + 4*l4 + r]
+          const int ti = tbase + 16 * h + 4 * l4 + r;
+          x[4 * h + r] = ti < nt ? acc[r] * inv_sqrt_dh : -1e30f;
+          tmax = __builtin_fmaxf(tmax, x[4 * h + r]);
+        }
+      }
+      tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = __builtin_fmaxf(m_run, tmax);
+      const float alpha = __expf(m_run - m_new);
+      float psum = 0.0f;
+      v8h pb;   // k-slots of the P.V step: tokens 4*l4+r of group 0, then of group 1 (as the V^T operand below)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const half_t ph = x[e] > -1e29f ? (half_t)__expf(x[e] - m_new) : (half_t)0.0f;
+        pb[e] = ph;
+        psum += (float)ph;
+      }
+      l_run = l_run * alpha + psum;
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) oacc[c] *= alpha;
+      }
+      m_run = m_new;
+      // ---- O^T += V^T . P^T : dequantised V tile through LDS, transposed reads ----
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const half_t ch = (half_t)(-(float)vs[u][h] * (float)vz[u][h]);
+        v2h vd[16];
+        kv4_dequant16(vr[u][h], (v2h){vs[u][h], vs[u][h]}, (v2h){ch, ch}, vd);
+        uint8_t* dst = vt + (h * 16 + vtok) * VROW + vpiece * 64;   // 32 values in dequant order
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const v8h t = {vd[4 * w][0], vd[4 * w][1], vd[4 * w + 1][0], vd[4 * w + 1][1],
+                         vd[4 * w + 2][0], vd[4 * w + 2][1], vd[4 * w + 3][0], vd[4 * w + 3][1]};
+          *reinterpret_cast<v8h*>(dst + w * 16) = t;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint8_t* src = vt + tr_off + c * 32;
+        const v4hp lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) v4hp*)(__attribute__((address_space(3))) void*)(src));
+        const v4hp hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) v4hp*)(__attribute__((address_space(3))) void*)(src + 16 * VROW));
+        const v8h a = {(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
+                       (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb, oacc[c], 0, 0, 0);
+      }
+    }
+  }
+  // ---- combine the four waves' (max, sum, O); add the current token; normalise / emit partials ----------------
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (l15 < G) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      *reinterpret_cast<v4f*>(xbuf + ((size_t)wave * G + l15) * DH + c * 16 + 4 * l4) = oacc[c];
+    if (l4 == 0) {
+      mlbuf[(wave * G + l15) * 2 + 0] = m_run;
+      mlbuf[(wave * G + l15) * 2 + 1] = l_run;
+    }
+  }
+  __syncthreads();
+  for (int oi = tid; oi < G * DH; oi += DEC_THREADS) {
+    const int g = oi >> 7, qpos = oi & 127;
+    const int d = unperm_pos(qpos);
+    float M = owns_cur ? scur[g] : -1e30f;
+#pragma unroll
+    for (int w = 0; w < DEC_WAVES; ++w) M = __builtin_fmaxf(M, mlbuf[(w * G + g) * 2]);
+    float acc = 0.0f, L = 0.0f;
+#pragma unroll
+    for (int w = 0; w < DEC_WAVES; ++w) {
+      const float wgt = __expf(mlbuf[(w * G + g) * 2] - M);
+      acc += wgt * xbuf[((size_t)w * G + g) * DH + qpos];
+      L += wgt * mlbuf[(w * G + g) * 2 + 1];
+    }
+    if (owns_cur) {
+      const float pc = __expf(scur[g] - M);
+      acc += pc * (float)vcur[d];
+      L += pc;
+    }
+    if constexpr (DIRECT) {
+      p.out[((size_t)b * p.num_heads + hq0 + g) * DH + d] = (half_t)(acc * (1.0f / (L + 1e-6f)));
+    } else {
+      const size_t pi = ((size_t)b * p.num_heads + hq0 + g) * p.nsplit + split;
+      p.part_o[pi * DH + d] = acc;
+      if (qpos == 0) {
+        p.part_ml[pi * 2 + 0] = M;
+        p.part_ml[pi * 2 + 1] = L;
+      }
+    }
+  }
+
+  OMNI_CLK(22);
+  // ---- append the current token (quantised) to the cache ------------------------------------------
+  if (owns_cur && sub == 0 && wave < 2) {
+    const half_t* src = wave == 0 ? kcur : vcur;
+    const int64_t* tab = wave == 0 ? ktab : vtab;
+    const float x0 = (float)src[lane], x1 = (float)src[64 + lane];
+    const float mx = wave_max64(__builtin_fmaxf(x0, x1));
+    const float mn = -wave_max64(-__builtin_fminf(x0, x1));
+    const float range = mx - mn;
+    const half_t scale_h = (half_t)(range / 15.0f);
+    const float nm = -15.0f * mn;
+    const half_t zero_h = (half_t)(nm / range);
+    const float inv = 1.0f / (float)scale_h, z = (float)zero_h;
+    int blk = tlen >> lay.tpb_log2;
+    if (FG && streaming) blk = ring_block(blk, p.fg.sink_blocks, p.fg.local_blocks);
+    // the page pointer normally sits in the LDS window already (no dependent load at the kernel's end)
+    const int wi = blk - page0;
+    const bool in_window = !(FG && dyn != nullptr) && wi >= 0 && wi < 40;
+    uint8_t* pg = reinterpret_cast<uint8_t*>(in_window ? pages[(wave == 0 ? 0 : 40) + wi] : tab[blk]);
+    const int slot = tlen & (lay.tpb - 1);
+    uint8_t* dst = pg + ((size_t)hrank * lay.tpb + slot) * ROW_BYTES;
+    const uint32_t c0 = kv4_code(x0, inv, z), c1 = kv4_code(x1, inv, z);
+    const uint32_t n0 = __shfl_down(c0, 1, 64), n1 = __shfl_down(c1, 1, 64);
+    if ((lane & 1) == 0) {
+      dst[lane >> 1] = (uint8_t)(c0 | (n0 << 4));
+      dst[32 + (lane >> 1)] = (uint8_t)(c1 | (n1 << 4));
+    }
+    if (lane == 0) {
+      half_t* scp = reinterpret_cast<half_t*>(pg + pool_bytes_per_seq) + hrank * lay.tpb + slot;
+      scp[0] = scale_h;
+      scp[hpool * lay.tpb] = zero_h;
+    }
+    if constexpr (FG) {
+      // K pages with min/max statistics: fold the new key into its sub-chunk's indicators
+      // (sparse_attention/decoderMaskedMultiheadAttentionTemplate.hpp:1414-1428)
+      if (wave == 0 && !streaming && p.fg.sub_chunk > 0) {
+        const int subs = lay.tpb / p.fg.sub_chunk;
+        half_t* kmax = reinterpret_cast<half_t*>(pg + pool_bytes_per_seq) + 2 * hpool * lay.tpb +
+                       ((size_t)(slot / p.fg.sub_chunk) * hpool + hrank) * DH;
+        half_t* kmin = kmax + (size_t)subs * hpool * DH;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int d = lane + 64 * h;
+          const half_t kv = src[d], omx = kmax[d], omn = kmin[d];
+          kmax[d] = (half_t)__builtin_fmaxf((float)omx, (float)kv);
+          kmin[d] = (half_t)__builtin_fminf((float)omn, (float)kv);
+        }
+      }
+    }
+  }
+}
+
 // merge the per-split partials: out = sum_s e^{m_s-M} O_s / (sum_s e^{m_s-M} l_s + 1e-6)
 __global__ __launch_bounds__(128) void kv4_decode_merge_kernel(half_t* __restrict__ out,
                                                                 const float* __restrict__ part_ml,
@@ -1034,11 +1442,11 @@ __global__ __launch_bounds__(128) void kv4_decode_merge_kernel(half_t* __restric
 struct DecodePlan {
   int nsplit, split_tokens, g;
   size_t lds_bytes;
-  bool mfma;
+  int kernel;   // 0 = single-sweep flash kernel (default), 1 = two-pass MFMA kernel, 2 = VALU kernel
 };
 
 static int g_override_nsplit = 0;
-static int g_use_valu_kernel = 0;   // tuning / A-B hook: 1 = the VALU kernel (kv4_decode_kernel)
+static int g_kernel_choice = 0;     // tuning / A-B hook, see omni_kv4_decode_set_split_override
 
 static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int max_context, int tokens_per_block,
                               bool per_q_head = false, bool per_q_head_or_fg = false) {
@@ -1066,8 +1474,11 @@ static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int ma
   if (st > st_cap) st = st_cap;   // caller rejects: max_context > 64 * st_cap
   pl.nsplit = s;
   pl.split_tokens = st;
-  pl.mfma = per_q_head_or_fg || !g_use_valu_kernel;
-  if (pl.mfma)
+  pl.kernel = per_q_head_or_fg ? 0 : g_kernel_choice;
+  if (pl.kernel == 0)
+    pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * pl.g * DH * 4 +
+                   (size_t)DEC_WAVES * pl.g * 2 * 4 + (size_t)DEC_WAVES * VTILE;
+  else if (pl.kernel == 1)
     pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * pl.g * DH * 4 +
                    (size_t)DEC_WAVES * VTILE + (size_t)pl.g * (st + 32) * 6;
   else
@@ -1167,9 +1578,11 @@ extern "C" int omni_kv4_prefill_write_fine_grained(
 }
 
 extern "C" void omni_kv4_decode_set_split_override(int nsplit) {
-  // nsplit >= 0: force the KV split count (0 = heuristic); nsplit = -1 / -2: select the VALU / MFMA kernel
-  if (nsplit == -1) omni::g_use_valu_kernel = 1;
-  else if (nsplit == -2) omni::g_use_valu_kernel = 0;
+  // nsplit >= 0: force the KV split count (0 = heuristic); -1 / -2 / -3: select the VALU / single-sweep (default) /
+  // two-pass MFMA kernel
+  if (nsplit == -1) omni::g_kernel_choice = 2;
+  else if (nsplit == -2) omni::g_kernel_choice = 0;
+  else if (nsplit == -3) omni::g_kernel_choice = 1;
   else omni::g_override_nsplit = nsplit;
 }
 
@@ -1218,7 +1631,9 @@ static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, co
   if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;
 #define OMNI_LAUNCH_DEC(G_, D_)                                                                       \
   do {                                                                                                \
-    if (pl.mfma) {                                                                                    \
+    if (pl.kernel == 0) {                                                                             \
+      hipLaunchKernelGGL((kv4_decode_flash_kernel<G_, D_>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); \
+    } else if (pl.kernel == 1) {                                                                      \
       if (pl.lds_bytes > 64 * 1024)                                                                   \
         (void)hipFuncSetAttribute((const void*)kv4_decode_mfma_kernel<G_, D_>,                        \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);    \
@@ -1333,10 +1748,7 @@ extern "C" int omni_kv4_decode_attention_fine_grained(
   hipStream_t st = (hipStream_t)stream;
 #define OMNI_LAUNCH_FG(G_)                                                                              \
   do {                                                                                                  \
-    if (pl.lds_bytes > 64 * 1024)                                                                       \
-      (void)hipFuncSetAttribute((const void*)kv4_decode_mfma_kernel<G_, false, true>,                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);         \
-    hipLaunchKernelGGL((kv4_decode_mfma_kernel<G_, false, true>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); \
+    hipLaunchKernelGGL((kv4_decode_flash_kernel<G_, false, true>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); \
   } while (0)
   switch (pl.g) {
     case 1: OMNI_LAUNCH_FG(1); break;
