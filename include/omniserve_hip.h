@@ -224,11 +224,13 @@ int omni_prefill_attention(void* out_f16, const void* q_f16, const void* k_f16, 
 /* Replaces omniserve_backend.fused_attention_ctx_pool.paged_min_max_pool
  *   (sparse_utils/ContextPool/context_pool_kernel.cu:145-213): per sequence, pooled head r
  *   (input head pooling_heads_idx[r]) and sub-chunk of `pooling_size` tokens, the elementwise max / min of
- *   the post-RoPE keys k fp16 [L, Hin, 128] are written into the K page tails. */
+ *   the post-RoPE keys k fp16 [L, Hin, 128] are written into the K page tails.  kv_row_bytes = bytes of one
+ *   token row of one head in the page (64: KV4, 128: per-tensor KV8) = the reference's
+ *   size_per_retrieval_token / num_pool_heads; it locates the statistics behind data + 4 B/token-head tail. */
 int omni_kv_min_max_pool(const void* k_f16, const void* kv_pointers_i64, const void* cu_seqlens_i32,
                          const void* pooling_heads_idx_i32, int batch, int max_blocks, int num_input_heads,
-                         int num_pool_heads, int head_dim, int max_seqlen, int pooling_size, int page_size,
-                         void* stream);
+                         int num_pool_heads, int head_dim, int kv_row_bytes, int max_seqlen, int pooling_size,
+                         int page_size, void* stream);
 
 /* Replaces omniserve_backend.fused_attention_selector.single_query_page_selector
  *   (sparse_utils/KVPageSelector/fused_kv_page_selector.cpp:262-334): for retrieval heads,
@@ -237,7 +239,7 @@ int omni_kv_min_max_pool(const void* k_f16, const void* kv_pointers_i64, const v
 int omni_kv_page_selector(void* out_f16, const void* q_f16, int64_t q_stride, const void* kv_pointers_i64,
                           const void* retrieval_head_flags_i32, const void* head_rank_table_i32,
                           const void* lengths_i32, int batch, int max_blocks, int num_heads, int num_kv_heads,
-                          int num_retrieval_kv_heads, int head_dim, int tokens_per_block,
+                          int num_retrieval_kv_heads, int head_dim, int kv_row_bytes, int tokens_per_block,
                           int tokens_per_sub_chunk, int padded_sub_chunks, const void* rope_cos_sin_f32,
                           int rope_max_pos, void* stream);
 
@@ -270,6 +272,44 @@ int omni_kv4_prefill_write_fine_grained(
  *   attend min(sink+local-1, len-1) cached tokens through the ring.  Workspace as omni_kv4_decode_attention. */
 int omni_kv4_decode_attention_fine_grained(
     void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride, int64_t kv_stride,
+    const void* retrieval_kv_pointers_i64, const void* streaming_kv_pointers_i64,
+    const void* retrieval_head_flags_i32, const void* head_rank_table_i32, const void* lengths_i32,
+    const void* dynamic_sparse_page_idx_i32, int num_dynamic_pages, int tokens_per_sub_chunk, int batch,
+    int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads, int num_retrieval_kv_heads,
+    int num_streaming_kv_heads, int head_dim, int tokens_per_block, int sink_tokens, int local_tokens,
+    int sink_blocks, int local_blocks, int max_context, const void* rope_cos_sin_f32, int rope_max_pos,
+    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-tensor KV8 (LServe's published `w8a8kv8 per_tensor` configuration) ------
+ * K or V page of a pool with H heads: int8 data [H][tpb][128] | fp16 scale slot [H][tpb] | fp16 zero slot [H][tpb]
+ *   (| K statistics as above).  Static scales, no zero points (omniserve/engine/arg_utils.py:500-503):
+ *   code = cvt.rni.sat.s8(kv_scale_orig_quant[i] * x), value = fp16(kv_scale_quant_orig[i] * code), i = 0 (K), 1 (V)
+ *   (common/decoderMaskedMultiheadAttentionUtils.h:2041-2048,2086-2093).  Both scale arrays are DEVICE fp32 [2],
+ *   as the reference's Python wrappers pass them (decoding_attention.py:202-210, ctx_update_kv.py:59-67).
+ *
+ * omni_kv8_prefill_write_per_tensor replaces
+ *   omniserve_backend.fused_attention_per_tensor_dense.apply_bias_rope_update_kv_cache
+ *   (fused_attention_per_tensor/per_tensor_common/update_kv_cache.h:16-44; the writer also leaves each row's own
+ *   fp16(absmax/127) in the scale slot, applyBiasRopeUpdateKVCache.h:387-414). */
+int omni_kv8_prefill_write_per_tensor(
+    void* qkv_f16, const void* kv_scale_orig_quant_f32, const void* seq_lens_i32, const void* padding_offsets_i32,
+    const void* retrieval_kv_pointers_i64, const void* streaming_kv_pointers_i64,
+    const void* retrieval_head_flags_i32, const void* head_rank_table_i32, int tokens, int batch,
+    int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads, int num_retrieval_kv_heads,
+    int num_streaming_kv_heads, int head_dim, int max_seq_len, int tokens_per_block, int sink_tokens,
+    int local_tokens, int sink_blocks, int local_blocks, const void* rope_cos_sin_f32, int rope_max_pos,
+    int max_position_embeddings, void* stream);
+
+/* omni_kv8_decode_attention_per_tensor replaces
+ *   omniserve_backend.fused_attention_per_tensor_dense.single_query_attention
+ *     (fused_attention_per_tensor/dense_attention/fused_attention.h:18-46) and, with a page list,
+ *   omniserve_backend.fused_attention_per_tensor_sparse.single_query_attention
+ *     (sparse_attention/fused_attention.h:18-50).  Semantics of omni_kv4_decode_attention_fine_grained on
+ *   KV8 pages; the appended token is stored with kv_scale_orig_quant and no tail is written
+ *   (dense_attention/decoderMaskedMultiheadAttentionTemplate.hpp:1377,2162). */
+int omni_kv8_decode_attention_per_tensor(
+    void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride, int64_t kv_stride,
+    const void* kv_scale_quant_orig_f32, const void* kv_scale_orig_quant_f32,
     const void* retrieval_kv_pointers_i64, const void* streaming_kv_pointers_i64,
     const void* retrieval_head_flags_i32, const void* head_rank_table_i32, const void* lengths_i32,
     const void* dynamic_sparse_page_idx_i32, int num_dynamic_pages, int tokens_per_sub_chunk, int batch,

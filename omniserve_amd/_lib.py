@@ -41,13 +41,15 @@ PROTOTYPES = {
     "omni_kv4_prefill_write": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _i, _i, _vp]),
     "omni_kv4_decode_set_split_override": (None, [_i]),
     "omni_kv4_decode_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "omni_kv_min_max_pool": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
-    "omni_kv_page_selector": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp, _i, _vp]),
+    "omni_kv_min_max_pool": (_i, [_vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
+    "omni_kv_page_selector": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp] + [_i] * 10 + [_vp, _i, _vp]),
     "omni_prefill_attention": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp] + [_i] * 6 + [_vp, _vp, _vp]),
     "omni_kv4_decode_attention_partial": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp] + [_i] * 7 + [_vp, _i, _vp, _sz, _c.POINTER(_i), _vp]),
     "omni_attn_merge_quant_fuse_sum": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "omni_kv4_prefill_write_fine_grained": (_i, [_vp] * 7 + [_i] * 15 + [_vp, _i, _i, _vp]),
     "omni_kv4_decode_attention_fine_grained": (_i, [_vp, _vp, _vp, _vp, _i64, _i64] + [_vp] * 6 + [_i] * 16 + [_vp, _i, _vp, _sz, _vp]),
+    "omni_kv8_prefill_write_per_tensor": (_i, [_vp] * 8 + [_i] * 15 + [_vp, _i, _i, _vp]),
+    "omni_kv8_decode_attention_per_tensor": (_i, [_vp, _vp, _vp, _vp, _i64, _i64] + [_vp] * 8 + [_i] * 16 + [_vp, _i, _vp, _sz, _vp]),
     "omni_kv4_decode_attention": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp] + [_i] * 7 + [_vp, _i, _vp, _sz, _vp]),
 }
 

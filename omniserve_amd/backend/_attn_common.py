@@ -15,6 +15,23 @@ def _check_cfg(rotary_embedding_dim, neox_rotary_style, int4_kv_cache, kv_cache_
         raise NotImplementedError("head_dim = rotary_dim = 128 only")
 
 
+def _check_cfg_kv8(rotary_embedding_dim, neox_rotary_style, int4_kv_cache, kv_cache_with_zeros, head_dim):
+    """per_tensor family: int8 pages with static scales and no zero points (arg_utils.py:492-503)."""
+    if int4_kv_cache or kv_cache_with_zeros:
+        raise NotImplementedError("per_tensor: only the KV8 format without zero points is implemented")
+    if not neox_rotary_style:
+        raise NotImplementedError("only neox-style RoPE is implemented")
+    if head_dim != 128 or rotary_embedding_dim != head_dim:
+        raise NotImplementedError("head_dim = rotary_dim = 128 only")
+
+
+def _kv_scale(t, what, name):
+    if t is None or t.dtype != torch.float32 or t.numel() < 2 or not t.is_contiguous():
+        raise RuntimeError("%s: %s must be a contiguous fp32 tensor with 2 elements (K, V)" % (what, name))
+    _lib.require_cuda(t)
+    return t
+
+
 def compute_padding_offsets(cu_seqlens, max_seqlen, tot_num_tokens):
     """-> int32 [tot_num_tokens], out[tok] = b*max_seqlen - cu_seqlens[b]
     (common/input_metadata_helper.cu:38-50; callee allocates)."""
@@ -93,13 +110,21 @@ def prefill_write_fine_grained(qkv, seq_lens, padding_offset, retrieval_kv_point
                                tokens_per_block, size_per_retrieval_token, size_per_streaming_token, sink_token_num,
                                local_token_num, sink_block_num, local_block_num, num_retrieval_kv_heads,
                                num_streaming_kv_heads, rotary_embedding_dim, rotary_embedding_base, rope_scale,
-                               rotary_embedding_max_positions, neox, int4, zeros, what):
+                               rotary_embedding_max_positions, neox, int4, zeros, what, kv_scale_orig_quant=None,
+                               per_tensor=False):
+    """per_tensor=True: the KV8 family (kv_scale_orig_quant fp32 [2] on the device)."""
     _lib.require_cuda(qkv, seq_lens, padding_offset, retrieval_head_flags, head_rank_table)
     head_dim = qkv.shape[-1] // (head_num + 2 * kv_head_num)
-    _check_cfg(rotary_embedding_dim, neox, int4, zeros, head_dim)
-    if size_per_retrieval_token != num_retrieval_kv_heads * head_dim // 2 or \
-            size_per_streaming_token != num_streaming_kv_heads * head_dim // 2:
-        raise RuntimeError("%s: size_per_*_token must be heads_in_pool*Dh/2" % what)
+    if per_tensor:
+        _check_cfg_kv8(rotary_embedding_dim, neox, int4, zeros, head_dim)
+        kv_scale_orig_quant = _kv_scale(kv_scale_orig_quant, what, "kv_scale_orig_quant")
+        row = head_dim
+    else:
+        _check_cfg(rotary_embedding_dim, neox, int4, zeros, head_dim)
+        row = head_dim // 2
+    if size_per_retrieval_token != num_retrieval_kv_heads * row or \
+            size_per_streaming_token != num_streaming_kv_heads * row:
+        raise RuntimeError("%s: size_per_*_token must be heads_in_pool*%d" % (what, row))
     if not qkv.is_contiguous() or qkv.dtype != torch.float16:
         raise RuntimeError("%s: qkv must be contiguous fp16" % what)
     if retrieval_head_flags.dtype != torch.int32 or head_rank_table.dtype != torch.int32:
@@ -107,6 +132,16 @@ def prefill_write_fine_grained(qkv, seq_lens, padding_offset, retrieval_kv_point
     rp, rb, sp, sb = _fg_tables(retrieval_kv_pointers, streaming_kv_pointers, num_retrieval_kv_heads,
                                 num_streaming_kv_heads, what)
     table = rope_table(int(seq_len), head_dim, float(rotary_embedding_base), float(rope_scale), qkv.device)
+    if per_tensor:
+        rc = _lib.lib().omni_kv8_prefill_write_per_tensor(
+            qkv.data_ptr(), kv_scale_orig_quant.data_ptr(), seq_lens.data_ptr(), padding_offset.data_ptr(), rp, sp,
+            retrieval_head_flags.data_ptr(), head_rank_table.data_ptr(), qkv.shape[0], seq_lens.shape[0], rb, sb,
+            head_num, kv_head_num, int(num_retrieval_kv_heads), int(num_streaming_kv_heads), head_dim, int(seq_len),
+            int(tokens_per_block), int(sink_token_num), int(local_token_num), int(sink_block_num),
+            int(local_block_num), table.data_ptr(), table.shape[0], int(rotary_embedding_max_positions),
+            _lib.current_stream())
+        _lib.check(rc, what)
+        return
     rc = _lib.lib().omni_kv4_prefill_write_fine_grained(
         qkv.data_ptr(), seq_lens.data_ptr(), padding_offset.data_ptr(), rp, sp, retrieval_head_flags.data_ptr(),
         head_rank_table.data_ptr(), qkv.shape[0], seq_lens.shape[0], rb, sb, head_num, kv_head_num,
@@ -121,14 +156,23 @@ def decode_attention_fine_grained(q, k, v, retrieval_kv_pointers, streaming_kv_p
                                   size_per_retrieval_token, size_per_streaming_token, sink_token_num, local_token_num,
                                   sink_block_num, local_block_num, num_retrieval_kv_heads, num_streaming_kv_heads,
                                   timestep, rotary_embedding_dim, rotary_base, rope_scale, neox, int4, zeros,
-                                  tokens_per_sub_chunk, what):
+                                  tokens_per_sub_chunk, what, kv_scale_quant_orig=None, kv_scale_orig_quant=None,
+                                  per_tensor=False):
+    """per_tensor=True: the KV8 family (both scale tensors fp32 [2] on the device)."""
     _lib.require_cuda(q, k, v, lengths, retrieval_head_flags, head_rank_table)
     B, Hq, D = q.shape
     Hkv = k.shape[1]
-    _check_cfg(rotary_embedding_dim, neox, int4, zeros, D)
-    if size_per_retrieval_token != num_retrieval_kv_heads * D // 2 or \
-            size_per_streaming_token != num_streaming_kv_heads * D // 2:
-        raise RuntimeError("%s: size_per_*_token must be heads_in_pool*Dh/2" % what)
+    if per_tensor:
+        _check_cfg_kv8(rotary_embedding_dim, neox, int4, zeros, D)
+        kv_scale_quant_orig = _kv_scale(kv_scale_quant_orig, what, "kv_scale_quant_orig")
+        kv_scale_orig_quant = _kv_scale(kv_scale_orig_quant, what, "kv_scale_orig_quant")
+        row = D
+    else:
+        _check_cfg(rotary_embedding_dim, neox, int4, zeros, D)
+        row = D // 2
+    if size_per_retrieval_token != num_retrieval_kv_heads * row or \
+            size_per_streaming_token != num_streaming_kv_heads * row:
+        raise RuntimeError("%s: size_per_*_token must be heads_in_pool*%d" % (what, row))
     if q.dtype != torch.float16 or q.stride(2) != 1 or q.stride(1) != D:
         raise RuntimeError("%s: q must be fp16 [B,H,D] with contiguous heads" % what)
     if k.stride(2) != 1 or k.stride(1) != D or v.stride(2) != 1 or v.stride(1) != D:
@@ -151,6 +195,17 @@ def decode_attention_fine_grained(q, k, v, retrieval_kv_pointers, streaming_kv_p
     need = _lib.lib().omni_kv4_decode_workspace_bytes(B, Hq, D, max_ctx)
     ws = _lib.workspace(need, q.device, "attn")
     out = torch.empty((B, Hq, D), dtype=q.dtype, device=q.device)
+    if per_tensor:
+        rc = _lib.lib().omni_kv8_decode_attention_per_tensor(
+            out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0),
+            kv_scale_quant_orig.data_ptr(), kv_scale_orig_quant.data_ptr(), rp, sp,
+            retrieval_head_flags.data_ptr(), head_rank_table.data_ptr(), lengths.data_ptr(), dyn_ptr, ndyn,
+            int(tokens_per_sub_chunk), B, rb, sb, Hq, Hkv, int(num_retrieval_kv_heads), int(num_streaming_kv_heads),
+            D, int(tokens_per_block), int(sink_token_num), int(local_token_num), int(sink_block_num),
+            int(local_block_num), max_ctx, table.data_ptr(), table.shape[0], ws.data_ptr(), ws.numel(),
+            _lib.current_stream())
+        _lib.check(rc, what)
+        return out
     rc = _lib.lib().omni_kv4_decode_attention_fine_grained(
         out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), rp, sp,
         retrieval_head_flags.data_ptr(), head_rank_table.data_ptr(), lengths.data_ptr(), dyn_ptr, ndyn,

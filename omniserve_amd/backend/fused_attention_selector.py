@@ -15,9 +15,16 @@ def single_query_page_selector(q, k, v, retrieval_kv_pointers, streaming_kv_poin
                                multiblock_switch):
     """-> fp16 [B, Hq, padded_sub_chunks] page scores (zeros for streaming heads); callee allocates."""
     _lib.require_cuda(q, retrieval_kv_pointers, retrieval_head_flags, head_rank_table, length_per_sample_)
-    if not (int4_kv_cache and kv_cache_with_zeros and neox_rotary_style):
-        raise NotImplementedError("only KV4 + zeros with neox RoPE is implemented")
+    if not (kv_cache_with_zeros and neox_rotary_style):
+        # callers always pass kv_cache_with_zeros=True (decoding_attention.py:126): the statistics sit behind a
+        # 4 B/token-head tail in every page format
+        raise NotImplementedError("only the 4 B/token-head tail layout with neox RoPE is implemented")
     B, Hq, D = q.shape
+    if num_retrieval_kv_heads < 1 or size_per_retrieval_token % num_retrieval_kv_heads != 0 or \
+            size_per_retrieval_token // num_retrieval_kv_heads != (D // 2 if int4_kv_cache else D):
+        raise RuntimeError("fused_attention_selector.single_query_page_selector: size_per_retrieval_token does not "
+                           "match num_retrieval_kv_heads * head_dim%s" % ("/2" if int4_kv_cache else ""))
+    row_bytes = size_per_retrieval_token // num_retrieval_kv_heads
     Hkv = k.shape[1]
     n_sub = (int(timestep) + tokens_per_sub_chunk - 1) // tokens_per_sub_chunk
     group = tokens_per_block // tokens_per_sub_chunk
@@ -28,7 +35,7 @@ def single_query_page_selector(q, k, v, retrieval_kv_pointers, streaming_kv_poin
     rc = _lib.lib().omni_kv_page_selector(out.data_ptr(), q.data_ptr(), q.stride(0), retrieval_kv_pointers.data_ptr(),
                                           retrieval_head_flags.data_ptr(), head_rank_table.data_ptr(),
                                           length_per_sample_.data_ptr(), B, retrieval_kv_pointers.shape[-1], Hq, Hkv,
-                                          int(num_retrieval_kv_heads), D, int(tokens_per_block),
+                                          int(num_retrieval_kv_heads), D, row_bytes, int(tokens_per_block),
                                           int(tokens_per_sub_chunk), padded, table.data_ptr(), table.shape[0],
                                           _lib.current_stream())
     _lib.check(rc, "fused_attention_selector.single_query_page_selector")

@@ -81,10 +81,15 @@ __device__ __forceinline__ uint32_t kv4_code(float x, float inv_scale, float zer
 // (the two halves of 4 neox RoPE pairs).  A workgroup of 256 threads handles 16 head slots;
 // slots per token = Hq (q heads: RoPE in place) + Hkv (k: RoPE in place + quantise; v: quantise).
 // ------------------------------------------------------------------------------------------
+// KV8: the per-tensor int8 format of fused_attention_per_tensor (static scales kv_oq[0] for K, kv_oq[1] for V:
+// per_tensor_common/applyBiasRopeUpdateKVCache.h:329-338,508-511); a token row of one head is Dh bytes.
+template <bool KV8>
 __global__ __launch_bounds__(256) void kv4_prefill_write_kernel(
     half_t* __restrict__ qkv, const int* __restrict__ seq_lens, const int* __restrict__ padding_offsets,
     const int64_t* __restrict__ kv_pointers, int tokens, int max_blocks, int num_heads, int num_kv_heads,
-    int max_seq_len, KvLayout lay, const float* __restrict__ rope, int rope_max_pos, int cyclic_len, FgArgs fg) {
+    int max_seq_len, KvLayout lay, const float* __restrict__ rope, int rope_max_pos, int cyclic_len, FgArgs fg,
+    const float* __restrict__ kv_oq) {
+  constexpr int RB = KV8 ? DH : ROW_BYTES;
   const int slots_per_token = num_heads + num_kv_heads;
   const long long slot_id = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l = threadIdx.x & 15;
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void kv4_prefill_write_kernel(
     if (lower < 0) lower = 0;
     if (pos < lower) return;
   }
-  const int pool_bytes_per_seq = hpool * lay.tpb * ROW_BYTES;
+  const int pool_bytes_per_seq = hpool * lay.tpb * RB;
   const half_t* v = row + (size_t)(num_heads + num_kv_heads + hk) * DH;
   const v4h vlo = *reinterpret_cast<const v4h*>(v + 4 * l);
   const v4h vhi = *reinterpret_cast<const v4h*>(v + 64 + 4 * l);
@@ -156,6 +161,29 @@ __global__ __launch_bounds__(256) void kv4_prefill_write_kernel(
   for (int which = 0; which < 2; ++which) {
     const v4h a = which == 0 ? rlo : vlo;
     const v4h bq = which == 0 ? rhi : vhi;
+    if constexpr (KV8) {
+      const float oq = kv_oq[which];
+      float amax = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf((float)a[j]), __builtin_fabsf((float)bq[j])));
+#pragma unroll
+      for (int m = 8; m > 0; m >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, m, 64));
+      uint8_t* base = reinterpret_cast<uint8_t*>(tab[which * tab_blocks + page]);
+      uint8_t* dst = base + ((size_t)hrank * lay.tpb + slot) * RB;
+      uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w0 |= ((uint32_t)rni_sat_s8(oq * (float)a[j]) & 0xFFu) << (8 * j);
+        w1 |= ((uint32_t)rni_sat_s8(oq * (float)bq[j]) & 0xFFu) << (8 * j);
+      }
+      *reinterpret_cast<uint32_t*>(dst + 4 * l) = w0;
+      *reinterpret_cast<uint32_t*>(dst + 64 + 4 * l) = w1;
+      // the row's own h(absmax/127) still goes to the scale slot of the tail (:387-414); nothing reads it
+      if (l == 0)
+        (reinterpret_cast<half_t*>(base + pool_bytes_per_seq) + hrank * lay.tpb + slot)[0] = (half_t)(amax / 127.0f);
+      continue;
+    }
     float mx = (float)a[0], mn = (float)a[0];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -220,6 +248,20 @@ __device__ __forceinline__ void kv4_dequant16(const uint4 raw, v2h scale2, v2h c
   }
 }
 
+// KV8 (per-tensor int8): out[i] = {h(s*f32(b_2i)), h(s*f32(b_2i+1))} for the 16 bytes of `raw`, natural order
+// (common/decoderMaskedMultiheadAttentionUtils.h:2086-2093: f32 multiply, then one rounding to fp16)
+__device__ __forceinline__ void kv8_dequant16(const uint4 raw, float s, v2h out[8]) {
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int x = (int)w[i];
+    const float f0 = (float)((x << 24) >> 24) * s, f1 = (float)((x << 16) >> 24) * s;
+    const float f2 = (float)((x << 8) >> 24) * s, f3 = (float)(x >> 24) * s;
+    out[2 * i] = (v2h){(half_t)f0, (half_t)f1};
+    out[2 * i + 1] = (v2h){(half_t)f2, (half_t)f3};
+  }
+}
+
 __device__ __forceinline__ float dot2_acc(v2h a, v2h b, float acc) {
   return __builtin_amdgcn_fdot2(a, b, acc, false);
 }
@@ -241,6 +283,8 @@ struct DecodeArgs {
   float* part_ml;          // [B,Hq,S,2]
   float* part_o;           // [B,Hq,S,128]
   FgArgs fg;               // fine-grained (retrieval / streaming) extension, used by the FG instantiations
+  const float* kv_qo;      // KV8 instantiations: device fp32 [2] kv_scale_quant_orig (K, V) ...
+  const float* kv_oq;      // ... and kv_scale_orig_quant
 };
 
 constexpr int DEC_MAX_SPLITS = 1024;   // KV splits per (sequence, head group): contexts up to 1024 x 2048 tokens
@@ -1023,7 +1067,9 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
 #ifndef OMNI_FLASH_MIN_BLOCKS
 #define OMNI_FLASH_MIN_BLOCKS 2
 #endif
-template <int G, bool DIRECT, bool FG = false>
+// KV8: per-tensor int8 pages (fused_attention_per_tensor): rows of Dh bytes, dequant h(kv_qo * f32(int8)) with the static
+// scales kv_qo[0] (K) / kv_qo[1] (V), natural element order (q is not reordered), append with kv_oq, no tail write.
+template <int G, bool DIRECT, bool FG = false, bool KV8 = false>
 __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode_flash_kernel(DecodeArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   half_t* q_lds = reinterpret_cast<half_t*>(smem);            // [G][128] dequant order
@@ -1046,6 +1092,10 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   const int b = blockIdx.z;
   OMNI_CLK(16);
   const KvLayout lay = p.lay;
+  constexpr int RB = KV8 ? DH : ROW_BYTES;   // bytes of one token row of one head
+  constexpr int NQ = KV8 ? 2 : 1;            // 16-B pieces per lane and 32 values
+  float k_qo = 1.0f, v_qo = 1.0f;
+  if constexpr (KV8) { k_qo = p.kv_qo[0]; v_qo = p.kv_qo[1]; }
   // The kernel is a chain of memory round trips, so the requests are ordered to need only two of them:
   //   trip 1 (independent of the sequence length): length, page-table window, raw q / k / v rows;
   //   trip 2: RoPE coefficients of position tlen, and every K and V byte of the split.
@@ -1068,7 +1118,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
     }
   }
   const int64_t* vtab = ktab + tab_blocks;
-  const int pool_bytes_per_seq = hpool * lay.tpb * ROW_BYTES;
+  const int pool_bytes_per_seq = hpool * lay.tpb * RB;
   const float inv_sqrt_dh = 0.08838834764831845f;
   const int vt0 = split * p.split_tokens;
   const int page0 = (FG && streaming) ? 0 : (vt0 >> lay.tpb_log2);
@@ -1161,14 +1211,14 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   const bool has_tokens = nt > 0;
   const uint8_t* dummy_page = reinterpret_cast<const uint8_t*>(dummy_ptr);
   const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
-  const size_t vhead_off = (size_t)hrank * lay.tpb * ROW_BYTES + vpiece * 16;
-  const size_t khead_off = (size_t)hrank * lay.tpb * ROW_BYTES + l4 * 16;  // K: lane = (token l15, 16-B piece l4)
+  const size_t vhead_off = (size_t)hrank * lay.tpb * RB + vpiece * 16 * NQ;
+  const size_t khead_off = (size_t)hrank * lay.tpb * RB + l4 * 16 * NQ;  // K: lane = (token l15, 32-value piece l4)
   // One sweep over the split (flash-decoding inside the workgroup): wave w owns the 32-token tiles w, w+4, ... and
   // for each runs Q.K^T -> online softmax in registers -> P.V; a batch of FB tiles' K AND V bytes is in flight
   // while the previous batch is consumed.  No workgroup barrier until the four waves' (max, sum, O) are combined.
   constexpr int FB = 2;
-  uint4 kraw[FB][2], vraw[FB][2];
-  half_t ksc[FB][2], kze[FB][2], vsc[FB][2], vze[FB][2];
+  uint4 kraw[FB][2][NQ], vraw[FB][2][NQ];
+  half_t ksc[FB][2], kze[FB][2], vsc[FB][2], vze[FB][2];   // KV4 only
   auto load_batch = [&](int i0) {   // branch-free: out-of-range tokens re-read token t0 (or the dummy page)
 #pragma unroll
     for (int u = 0; u < FB; ++u)
@@ -1181,10 +1231,14 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
           int pidx, slot;
           locate(tok, pidx, slot);
           const uint8_t* pg = has_tokens ? reinterpret_cast<const uint8_t*>(pages[has_tokens ? pidx : 0]) : dummy_page;
-          kraw[u][h] = *reinterpret_cast<const uint4*>(pg + khead_off + (size_t)slot * ROW_BYTES);
-          const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
-          ksc[u][h] = tail[0];
-          kze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
+#pragma unroll
+          for (int n = 0; n < NQ; ++n)
+            kraw[u][h][n] = *reinterpret_cast<const uint4*>(pg + khead_off + (size_t)slot * RB + 16 * n);
+          if constexpr (!KV8) {
+            const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
+            ksc[u][h] = tail[0];
+            kze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
+          }
         }
         {
           const int ti = tile * 32 + h * 16 + vtok;
@@ -1192,10 +1246,14 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
           int pidx, slot;
           locate(tok, pidx, slot);
           const uint8_t* pg = has_tokens ? reinterpret_cast<const uint8_t*>(pages[40 + (has_tokens ? pidx : 0)]) : dummy_page;
-          vraw[u][h] = *reinterpret_cast<const uint4*>(pg + vhead_off + (size_t)slot * ROW_BYTES);
-          const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
-          vsc[u][h] = tail[0];
-          vze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
+#pragma unroll
+          for (int n = 0; n < NQ; ++n)
+            vraw[u][h][n] = *reinterpret_cast<const uint4*>(pg + vhead_off + (size_t)slot * RB + 16 * n);
+          if constexpr (!KV8) {
+            const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
+            vsc[u][h] = tail[0];
+            vze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
+          }
         }
       }
   };
@@ -1211,12 +1269,13 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
     const float a = (float)qa[j], bb = (float)qbv[j];
     const float t0f = c * a, t1f = sn * bb, t2f = c * bb, t3f = sn * a;
     const half_t r0 = (half_t)(t0f - t1f), r1 = (half_t)(t2f + t3f);
+    const int p0 = KV8 ? i : perm_pos(i), p1 = KV8 ? i + 64 : perm_pos(i + 64);
     if (h < G) {
-      q_lds[h * DH + perm_pos(i)] = r0;
-      q_lds[h * DH + perm_pos(i + 64)] = r1;
+      q_lds[h * DH + p0] = r0;
+      q_lds[h * DH + p1] = r1;
     } else {
       kcur[i] = r0; kcur[i + 64] = r1;
-      kcur_p[perm_pos(i)] = r0; kcur_p[perm_pos(i + 64)] = r1;
+      kcur_p[p0] = r0; kcur_p[p1] = r1;
     }
   }
   if (owns_cur && tid < DH) vcur[tid] = vcur_r;
@@ -1246,14 +1305,18 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   const int tr_off = (4 * l4 + (l15 >> 2)) * VROW + (l15 & 3) * 8;
   const int my_tiles = ntiles > wave ? (ntiles - wave + DEC_WAVES - 1) / DEC_WAVES : 0;
   for (int i0 = 0; i0 < my_tiles; i0 += FB) {
-    uint4 kr[FB][2], vr[FB][2];
+    uint4 kr[FB][2][NQ], vr[FB][2][NQ];
     half_t ks[FB][2], kz[FB][2], vs[FB][2], vz[FB][2];
 #pragma unroll
     for (int u = 0; u < FB; ++u)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        kr[u][h] = kraw[u][h]; ks[u][h] = ksc[u][h]; kz[u][h] = kze[u][h];
-        vr[u][h] = vraw[u][h]; vs[u][h] = vsc[u][h]; vz[u][h] = vze[u][h];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) { kr[u][h][n] = kraw[u][h][n]; vr[u][h][n] = vraw[u][h][n]; }
+        if constexpr (!KV8) {
+          ks[u][h] = ksc[u][h]; kz[u][h] = kze[u][h];
+          vs[u][h] = vsc[u][h]; vz[u][h] = vze[u][h];
+        }
       }
     if (i0 + FB < my_tiles) load_batch(i0 + FB);   // next batch in flight while this one is consumed
 #pragma unroll
@@ -1265,9 +1328,14 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       float tmax = -1e30f;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const half_t ch = (half_t)(-(float)ks[u][h] * (float)kz[u][h]);
         v2h kd[16];
-        kv4_dequant16(kr[u][h], (v2h){ks[u][h], ks[u][h]}, (v2h){ch, ch}, kd);
+        if constexpr (KV8) {
+          kv8_dequant16(kr[u][h][0], k_qo, kd);
+          kv8_dequant16(kr[u][h][NQ - 1], k_qo, kd + 8);
+        } else {
+          const half_t ch = (half_t)(-(float)ks[u][h] * (float)kz[u][h]);
+          kv4_dequant16(kr[u][h][0], (v2h){ks[u][h], ks[u][h]}, (v2h){ch, ch}, kd);
+        }
         v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sidx = 0; sidx < 4; ++sidx) {
@@ -1303,9 +1371,14 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       // ---- O^T += V^T . P^T : dequantised V tile through LDS, transposed reads ----
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const half_t ch = (half_t)(-(float)vs[u][h] * (float)vz[u][h]);
         v2h vd[16];
-        kv4_dequant16(vr[u][h], (v2h){vs[u][h], vs[u][h]}, (v2h){ch, ch}, vd);
+        if constexpr (KV8) {
+          kv8_dequant16(vr[u][h][0], v_qo, vd);
+          kv8_dequant16(vr[u][h][NQ - 1], v_qo, vd + 8);
+        } else {
+          const half_t ch = (half_t)(-(float)vs[u][h] * (float)vz[u][h]);
+          kv4_dequant16(vr[u][h][0], (v2h){vs[u][h], vs[u][h]}, (v2h){ch, ch}, vd);
+        }
         uint8_t* dst = vt + (h * 16 + vtok) * VROW + vpiece * 64;   // 32 values in dequant order
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -1342,7 +1415,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   __syncthreads();
   for (int oi = tid; oi < G * DH; oi += DEC_THREADS) {
     const int g = oi >> 7, qpos = oi & 127;
-    const int d = unperm_pos(qpos);
+    const int d = KV8 ? qpos : unperm_pos(qpos);
     float M = owns_cur ? scur[g] : -1e30f;
 #pragma unroll
     for (int w = 0; w < DEC_WAVES; ++w) M = __builtin_fmaxf(M, mlbuf[(w * G + g) * 2]);
@@ -1376,6 +1449,34 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
     const half_t* src = wave == 0 ? kcur : vcur;
     const int64_t* tab = wave == 0 ? ktab : vtab;
     const float x0 = (float)src[lane], x1 = (float)src[64 + lane];
+    if constexpr (KV8) {   // static scale, no tail write (dense Template.hpp:1377,2162; the tail code there is commented out)
+      const float oq = p.kv_oq[wave];
+      int blk8 = tlen >> lay.tpb_log2;
+      if (FG && streaming) blk8 = ring_block(blk8, p.fg.sink_blocks, p.fg.local_blocks);
+      const int wi8 = blk8 - page0;
+      const bool in_window8 = !(FG && dyn != nullptr) && wi8 >= 0 && wi8 < 40;
+      uint8_t* pg8 = reinterpret_cast<uint8_t*>(in_window8 ? pages[(wave == 0 ? 0 : 40) + wi8] : tab[blk8]);
+      const int slot8 = tlen & (lay.tpb - 1);
+      uint8_t* dst8 = pg8 + ((size_t)hrank * lay.tpb + slot8) * RB;
+      dst8[lane] = (uint8_t)rni_sat_s8(oq * x0);
+      dst8[64 + lane] = (uint8_t)rni_sat_s8(oq * x1);
+      if constexpr (FG) {
+        if (wave == 0 && !streaming && p.fg.sub_chunk > 0) {
+          const int subs = lay.tpb / p.fg.sub_chunk;
+          half_t* kmax = reinterpret_cast<half_t*>(pg8 + pool_bytes_per_seq) + 2 * hpool * lay.tpb +
+                         ((size_t)(slot8 / p.fg.sub_chunk) * hpool + hrank) * DH;
+          half_t* kmin = kmax + (size_t)subs * hpool * DH;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int d = lane + 64 * h;
+            const half_t kv = src[d], omx = kmax[d], omn = kmin[d];
+            kmax[d] = (half_t)__builtin_fmaxf((float)omx, (float)kv);
+            kmin[d] = (half_t)__builtin_fminf((float)omn, (float)kv);
+          }
+        }
+      }
+      return;
+    }
     const float mx = wave_max64(__builtin_fmaxf(x0, x1));
     const float mn = -wave_max64(-__builtin_fminf(x0, x1));
     const float range = mx - mn;
@@ -1390,7 +1491,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
     const bool in_window = !(FG && dyn != nullptr) && wi >= 0 && wi < 40;
     uint8_t* pg = reinterpret_cast<uint8_t*>(in_window ? pages[(wave == 0 ? 0 : 40) + wi] : tab[blk]);
     const int slot = tlen & (lay.tpb - 1);
-    uint8_t* dst = pg + ((size_t)hrank * lay.tpb + slot) * ROW_BYTES;
+    uint8_t* dst = pg + ((size_t)hrank * lay.tpb + slot) * RB;
     const uint32_t c0 = kv4_code(x0, inv, z), c1 = kv4_code(x1, inv, z);
     const uint32_t n0 = __shfl_down(c0, 1, 64), n1 = __shfl_down(c1, 1, 64);
     if ((lane & 1) == 0) {
@@ -1515,11 +1616,12 @@ extern "C" int omni_kv4_prefill_write(void* qkv_f16, const void* seq_lens_i32,
   if (tokens == 0) return OMNI_OK;
   const long long slots = (long long)tokens * (num_heads + num_kv_heads);
   const unsigned blocks = (unsigned)((slots + 15) / 16);
-  hipLaunchKernelGGL(kv4_prefill_write_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(kv4_prefill_write_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                      (half_t*)qkv_f16, (const int*)seq_lens_i32, (const int*)padding_offsets_i32,
                      (const int64_t*)kv_pointers_i64, tokens, max_blocks, num_heads, num_kv_heads,
                      max_seq_len, make_layout(tokens_per_block, num_kv_heads),
-                     (const float*)rope_cos_sin_f32, rope_max_pos, max_position_embeddings, FgArgs{});
+                     (const float*)rope_cos_sin_f32, rope_max_pos, max_position_embeddings, FgArgs{},
+                     (const float*)nullptr);
   return omni_launch_status();
 }
 
@@ -1548,13 +1650,13 @@ static int fill_fg(FgArgs* fg, const void* streaming_kv_pointers_i64, const void
   return OMNI_OK;
 }
 
-extern "C" int omni_kv4_prefill_write_fine_grained(
+static int prefill_write_fg_common(
     void* qkv_f16, const void* seq_lens_i32, const void* padding_offsets_i32, const void* retrieval_kv_pointers_i64,
     const void* streaming_kv_pointers_i64, const void* retrieval_head_flags_i32, const void* head_rank_table_i32,
     int tokens, int batch, int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads,
     int num_retrieval_kv_heads, int num_streaming_kv_heads, int head_dim, int max_seq_len, int tokens_per_block,
     int sink_tokens, int local_tokens, int sink_blocks, int local_blocks, const void* rope_cos_sin_f32,
-    int rope_max_pos, int max_position_embeddings, void* stream) {
+    int rope_max_pos, int max_position_embeddings, void* stream, const float* kv_oq) {
   if (!qkv_f16 || !seq_lens_i32 || !padding_offsets_i32 || !rope_cos_sin_f32) return OMNI_EINVAL;
   if (head_dim != DH || tokens < 0 || batch < 1 || num_heads < 1 || num_kv_heads < 1 ||
       num_heads % num_kv_heads != 0 || tokens_per_block < 16 ||
@@ -1569,12 +1671,55 @@ extern "C" int omni_kv4_prefill_write_fine_grained(
   if (tokens == 0) return OMNI_OK;
   const long long slots = (long long)tokens * (num_heads + num_kv_heads);
   const unsigned blocks = (unsigned)((slots + 15) / 16);
-  hipLaunchKernelGGL(kv4_prefill_write_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                     (half_t*)qkv_f16, (const int*)seq_lens_i32, (const int*)padding_offsets_i32,
-                     (const int64_t*)retrieval_kv_pointers_i64, tokens, retrieval_blocks, num_heads, num_kv_heads,
-                     max_seq_len, make_layout(tokens_per_block, num_kv_heads),
-                     (const float*)rope_cos_sin_f32, rope_max_pos, max_position_embeddings, fg);
+  if (kv_oq)
+    hipLaunchKernelGGL(kv4_prefill_write_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (half_t*)qkv_f16, (const int*)seq_lens_i32, (const int*)padding_offsets_i32,
+                       (const int64_t*)retrieval_kv_pointers_i64, tokens, retrieval_blocks, num_heads, num_kv_heads,
+                       max_seq_len, make_layout(tokens_per_block, num_kv_heads),
+                       (const float*)rope_cos_sin_f32, rope_max_pos, max_position_embeddings, fg, kv_oq);
+  else
+    hipLaunchKernelGGL(kv4_prefill_write_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (half_t*)qkv_f16, (const int*)seq_lens_i32, (const int*)padding_offsets_i32,
+                       (const int64_t*)retrieval_kv_pointers_i64, tokens, retrieval_blocks, num_heads, num_kv_heads,
+                       max_seq_len, make_layout(tokens_per_block, num_kv_heads),
+                       (const float*)rope_cos_sin_f32, rope_max_pos, max_position_embeddings, fg, kv_oq);
   return omni_launch_status();
+}
+
+extern "C" int omni_kv4_prefill_write_fine_grained(
+    void* qkv_f16, const void* seq_lens_i32, const void* padding_offsets_i32, const void* retrieval_kv_pointers_i64,
+    const void* streaming_kv_pointers_i64, const void* retrieval_head_flags_i32, const void* head_rank_table_i32,
+    int tokens, int batch, int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads,
+    int num_retrieval_kv_heads, int num_streaming_kv_heads, int head_dim, int max_seq_len, int tokens_per_block,
+    int sink_tokens, int local_tokens, int sink_blocks, int local_blocks, const void* rope_cos_sin_f32,
+    int rope_max_pos, int max_position_embeddings, void* stream) {
+  return prefill_write_fg_common(qkv_f16, seq_lens_i32, padding_offsets_i32, retrieval_kv_pointers_i64,
+                                 streaming_kv_pointers_i64, retrieval_head_flags_i32, head_rank_table_i32, tokens,
+                                 batch, retrieval_blocks, streaming_blocks, num_heads, num_kv_heads,
+                                 num_retrieval_kv_heads, num_streaming_kv_heads, head_dim, max_seq_len,
+                                 tokens_per_block, sink_tokens, local_tokens, sink_blocks, local_blocks,
+                                 rope_cos_sin_f32, rope_max_pos, max_position_embeddings, stream, nullptr);
+}
+
+// Per-tensor KV8 (LServe's published w8a8kv8 configuration): same head classes and page tables, int8 pages with the
+// static scales kv_scale_orig_quant_f32 = device fp32 [2] (K, V).  Replaces
+// fused_attention_per_tensor_dense.apply_bias_rope_update_kv_cache (per_tensor_common/update_kv_cache.h:16-44).
+extern "C" int omni_kv8_prefill_write_per_tensor(
+    void* qkv_f16, const void* kv_scale_orig_quant_f32, const void* seq_lens_i32, const void* padding_offsets_i32,
+    const void* retrieval_kv_pointers_i64, const void* streaming_kv_pointers_i64,
+    const void* retrieval_head_flags_i32, const void* head_rank_table_i32, int tokens, int batch,
+    int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads, int num_retrieval_kv_heads,
+    int num_streaming_kv_heads, int head_dim, int max_seq_len, int tokens_per_block, int sink_tokens,
+    int local_tokens, int sink_blocks, int local_blocks, const void* rope_cos_sin_f32, int rope_max_pos,
+    int max_position_embeddings, void* stream) {
+  if (!kv_scale_orig_quant_f32) return OMNI_EINVAL;
+  return prefill_write_fg_common(qkv_f16, seq_lens_i32, padding_offsets_i32, retrieval_kv_pointers_i64,
+                                 streaming_kv_pointers_i64, retrieval_head_flags_i32, head_rank_table_i32, tokens,
+                                 batch, retrieval_blocks, streaming_blocks, num_heads, num_kv_heads,
+                                 num_retrieval_kv_heads, num_streaming_kv_heads, head_dim, max_seq_len,
+                                 tokens_per_block, sink_tokens, local_tokens, sink_blocks, local_blocks,
+                                 rope_cos_sin_f32, rope_max_pos, max_position_embeddings, stream,
+                                 (const float*)kv_scale_orig_quant_f32);
 }
 
 extern "C" void omni_kv4_decode_set_split_override(int nsplit) {
@@ -1626,6 +1771,7 @@ static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, co
   a.part_ml = (float*)workspace;
   a.part_o = a.part_ml + (size_t)batch * num_heads * pl.nsplit * 2;
   a.fg = FgArgs{};
+  a.kv_qo = nullptr; a.kv_oq = nullptr;
   dim3 grid(pl.nsplit, num_kv_heads * (group / pl.g), batch);
   hipStream_t st = (hipStream_t)stream;
   if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;
@@ -1697,7 +1843,7 @@ extern "C" int omni_kv4_decode_attention_partial(const void* q_f16, const void* 
 // LServe fine-grained decode attention: retrieval heads (optionally restricted to the pages in
 // dynamic_sparse_page_idx [B,Hq,num_dynamic_pages]) + streaming heads; replaces
 // fused_attention_fine_grained_{dense,sparse}.single_query_attention (KV4 with zeros).
-extern "C" int omni_kv4_decode_attention_fine_grained(
+static int decode_fg_common(
     void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride, int64_t kv_stride,
     const void* retrieval_kv_pointers_i64, const void* streaming_kv_pointers_i64,
     const void* retrieval_head_flags_i32, const void* head_rank_table_i32, const void* lengths_i32,
@@ -1705,7 +1851,7 @@ extern "C" int omni_kv4_decode_attention_fine_grained(
     int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads, int num_retrieval_kv_heads,
     int num_streaming_kv_heads, int head_dim, int tokens_per_block, int sink_tokens, int local_tokens,
     int sink_blocks, int local_blocks, int max_context, const void* rope_cos_sin_f32, int rope_max_pos,
-    void* workspace, size_t workspace_bytes, void* stream) {
+    void* workspace, size_t workspace_bytes, void* stream, const float* kv_qo, const float* kv_oq) {
   if (!out_f16 || !q_f16 || !k_f16 || !v_f16 || !lengths_i32 || !rope_cos_sin_f32 || !workspace) return OMNI_EINVAL;
   if (head_dim != DH || batch < 1 || num_heads < 1 || num_kv_heads < 1 || num_heads % num_kv_heads != 0 ||
       tokens_per_block < 16 || (tokens_per_block & (tokens_per_block - 1)) != 0 || max_context < 1 ||
@@ -1746,9 +1892,13 @@ extern "C" int omni_kv4_decode_attention_fine_grained(
   a.part_o = a.part_ml + (size_t)batch * num_heads * pl.nsplit * 2;
   dim3 grid(pl.nsplit, num_kv_heads * (group / pl.g), batch);
   hipStream_t st = (hipStream_t)stream;
+  a.kv_qo = kv_qo; a.kv_oq = kv_oq;
 #define OMNI_LAUNCH_FG(G_)                                                                              \
   do {                                                                                                  \
-    hipLaunchKernelGGL((kv4_decode_flash_kernel<G_, false, true>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); \
+    if (kv_qo)                                                                                          \
+      hipLaunchKernelGGL((kv4_decode_flash_kernel<G_, false, true, true>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); \
+    else                                                                                                \
+      hipLaunchKernelGGL((kv4_decode_flash_kernel<G_, false, true>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); \
   } while (0)
   switch (pl.g) {
     case 1: OMNI_LAUNCH_FG(1); break;
@@ -1762,3 +1912,44 @@ extern "C" int omni_kv4_decode_attention_fine_grained(
 }
 
 OMNI_CLK_READER(omni_debug_clocks_kv)
+
+extern "C" int omni_kv4_decode_attention_fine_grained(
+    void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride, int64_t kv_stride,
+    const void* retrieval_kv_pointers_i64, const void* streaming_kv_pointers_i64,
+    const void* retrieval_head_flags_i32, const void* head_rank_table_i32, const void* lengths_i32,
+    const void* dynamic_sparse_page_idx_i32, int num_dynamic_pages, int tokens_per_sub_chunk, int batch,
+    int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads, int num_retrieval_kv_heads,
+    int num_streaming_kv_heads, int head_dim, int tokens_per_block, int sink_tokens, int local_tokens,
+    int sink_blocks, int local_blocks, int max_context, const void* rope_cos_sin_f32, int rope_max_pos,
+    void* workspace, size_t workspace_bytes, void* stream) {
+  return decode_fg_common(out_f16, q_f16, k_f16, v_f16, q_stride, kv_stride, retrieval_kv_pointers_i64,
+                          streaming_kv_pointers_i64, retrieval_head_flags_i32, head_rank_table_i32, lengths_i32,
+                          dynamic_sparse_page_idx_i32, num_dynamic_pages, tokens_per_sub_chunk, batch,
+                          retrieval_blocks, streaming_blocks, num_heads, num_kv_heads, num_retrieval_kv_heads,
+                          num_streaming_kv_heads, head_dim, tokens_per_block, sink_tokens, local_tokens, sink_blocks,
+                          local_blocks, max_context, rope_cos_sin_f32, rope_max_pos, workspace, workspace_bytes,
+                          stream, nullptr, nullptr);
+}
+
+// Per-tensor KV8 decode attention: replaces fused_attention_per_tensor_{dense,sparse}.single_query_attention
+// (fused_attention_per_tensor/dense_attention/fused_attention.h:18-46, sparse_attention/fused_attention.h:18-50).
+// kv_scale_quant_orig_f32 / kv_scale_orig_quant_f32: device fp32 [2] (K, V), as the reference's wrappers pass them.
+extern "C" int omni_kv8_decode_attention_per_tensor(
+    void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride, int64_t kv_stride,
+    const void* kv_scale_quant_orig_f32, const void* kv_scale_orig_quant_f32,
+    const void* retrieval_kv_pointers_i64, const void* streaming_kv_pointers_i64,
+    const void* retrieval_head_flags_i32, const void* head_rank_table_i32, const void* lengths_i32,
+    const void* dynamic_sparse_page_idx_i32, int num_dynamic_pages, int tokens_per_sub_chunk, int batch,
+    int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads, int num_retrieval_kv_heads,
+    int num_streaming_kv_heads, int head_dim, int tokens_per_block, int sink_tokens, int local_tokens,
+    int sink_blocks, int local_blocks, int max_context, const void* rope_cos_sin_f32, int rope_max_pos,
+    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!kv_scale_quant_orig_f32 || !kv_scale_orig_quant_f32) return OMNI_EINVAL;
+  return decode_fg_common(out_f16, q_f16, k_f16, v_f16, q_stride, kv_stride, retrieval_kv_pointers_i64,
+                          streaming_kv_pointers_i64, retrieval_head_flags_i32, head_rank_table_i32, lengths_i32,
+                          dynamic_sparse_page_idx_i32, num_dynamic_pages, tokens_per_sub_chunk, batch,
+                          retrieval_blocks, streaming_blocks, num_heads, num_kv_heads, num_retrieval_kv_heads,
+                          num_streaming_kv_heads, head_dim, tokens_per_block, sink_tokens, local_tokens, sink_blocks,
+                          local_blocks, max_context, rope_cos_sin_f32, rope_max_pos, workspace, workspace_bytes,
+                          stream, (const float*)kv_scale_quant_orig_f32, (const float*)kv_scale_orig_quant_f32);
+}

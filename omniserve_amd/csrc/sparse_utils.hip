@@ -21,6 +21,7 @@ struct PoolArgs {
   const int* cu_seqlens;      // [B+1]
   const int* pooling_heads_idx;  // [pool_h] -> input head
   int max_blocks, num_input_heads, pool_h, pooling_size, page_size;
+  int row_bytes;              // bytes of one token row of one head in the page: Dh/2 (KV4) or Dh (KV8)
 };
 
 // one workgroup per (page, sequence, pooled head); thread = one head dim, two halves of the page's sub-chunks
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void kv_min_max_pool_kernel(PoolArgs p) {
   const int hin = p.pooling_heads_idx[r];
   const int subs = p.page_size / p.pooling_size;
   uint8_t* pg = reinterpret_cast<uint8_t*>(p.kv_pointers[(size_t)b * 2 * p.max_blocks + page]);
-  const size_t bytes_per_seq = (size_t)p.pool_h * p.page_size * (SDH / 2);
+  const size_t bytes_per_seq = (size_t)p.pool_h * p.page_size * p.row_bytes;
   half_t* kmax = reinterpret_cast<half_t*>(pg + bytes_per_seq) + (size_t)p.page_size * p.pool_h * 2;
   half_t* kmin = kmax + (size_t)subs * p.pool_h * SDH;
   for (int sc = half_id; sc < subs; sc += 2) {
@@ -61,6 +62,7 @@ struct SelArgs {
   const int* retrieval_head_flags; const int* head_rank_table; const int* lengths;
   int max_blocks, num_heads, num_kv_heads, num_retrieval_kv_heads, tpb, sub, padded;
   const float* rope; int rope_max_pos;
+  int row_bytes;              // Dh/2 (KV4 pages) or Dh (KV8 pages)
 };
 
 // Page selector.  One workgroup per (block of SEL_PB pages, kv head, sequence) scores ALL q heads of the kv
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void kv_page_selector_kernel(SelArgs p) {
   v8h q8[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) q8[g] = *reinterpret_cast<const v8h*>(q_lds + g * SDH + part * 8);
-  const size_t stats_off = (size_t)p.num_retrieval_kv_heads * p.tpb * (SDH / 2) +
+  const size_t stats_off = (size_t)p.num_retrieval_kv_heads * p.tpb * p.row_bytes +
                            (size_t)p.tpb * p.num_retrieval_kv_heads * 4;                    // bytes: data | scale | zero
   const size_t min_off = (size_t)subs * p.num_retrieval_kv_heads * SDH;                     // halfs: kmax -> kmin
   const int n_here = min(SEL_PB * subs, n_sub - c0);
@@ -155,15 +157,16 @@ using namespace omni;
 
 extern "C" int omni_kv_min_max_pool(const void* k_f16, const void* kv_pointers_i64, const void* cu_seqlens_i32,
                                     const void* pooling_heads_idx_i32, int batch, int max_blocks, int num_input_heads,
-                                    int num_pool_heads, int head_dim, int max_seqlen, int pooling_size, int page_size,
-                                    void* stream) {
+                                    int num_pool_heads, int head_dim, int kv_row_bytes, int max_seqlen, int pooling_size,
+                                    int page_size, void* stream) {
   if (!k_f16 || !kv_pointers_i64 || !cu_seqlens_i32 || !pooling_heads_idx_i32) return OMNI_EINVAL;
   if (head_dim != SDH || batch < 1 || num_pool_heads < 0 || pooling_size < 1 || page_size % pooling_size != 0 ||
-      max_seqlen < 0)
+      max_seqlen < 0 || (kv_row_bytes != SDH / 2 && kv_row_bytes != SDH))
     return OMNI_EINVAL;
   if (num_pool_heads == 0 || max_seqlen == 0) return OMNI_OK;
   PoolArgs a{(const half_t*)k_f16, (const int64_t*)kv_pointers_i64, (const int*)cu_seqlens_i32,
-             (const int*)pooling_heads_idx_i32, max_blocks, num_input_heads, num_pool_heads, pooling_size, page_size};
+             (const int*)pooling_heads_idx_i32, max_blocks, num_input_heads, num_pool_heads, pooling_size, page_size,
+             kv_row_bytes};
   dim3 grid((max_seqlen + page_size - 1) / page_size, batch, num_pool_heads);
   hipLaunchKernelGGL(kv_min_max_pool_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   return omni_launch_status();
@@ -172,19 +175,20 @@ extern "C" int omni_kv_min_max_pool(const void* k_f16, const void* kv_pointers_i
 extern "C" int omni_kv_page_selector(void* out_f16, const void* q_f16, int64_t q_stride, const void* kv_pointers_i64,
                                      const void* retrieval_head_flags_i32, const void* head_rank_table_i32,
                                      const void* lengths_i32, int batch, int max_blocks, int num_heads, int num_kv_heads,
-                                     int num_retrieval_kv_heads, int head_dim, int tokens_per_block,
+                                     int num_retrieval_kv_heads, int head_dim, int kv_row_bytes, int tokens_per_block,
                                      int tokens_per_sub_chunk, int padded_sub_chunks, const void* rope_cos_sin_f32,
                                      int rope_max_pos, void* stream) {
   if (!out_f16 || !q_f16 || !kv_pointers_i64 || !retrieval_head_flags_i32 || !head_rank_table_i32 || !lengths_i32 ||
       !rope_cos_sin_f32)
     return OMNI_EINVAL;
   if (head_dim != SDH || batch < 1 || num_heads < 1 || num_kv_heads < 1 || num_heads % num_kv_heads != 0 ||
-      tokens_per_sub_chunk < 1 || tokens_per_block % tokens_per_sub_chunk != 0 || padded_sub_chunks < 0)
+      tokens_per_sub_chunk < 1 || tokens_per_block % tokens_per_sub_chunk != 0 || padded_sub_chunks < 0 ||
+      (kv_row_bytes != SDH / 2 && kv_row_bytes != SDH))
     return OMNI_EINVAL;
   SelArgs a{(half_t*)out_f16, (const half_t*)q_f16, q_stride, (const int64_t*)kv_pointers_i64,
             (const int*)retrieval_head_flags_i32, (const int*)head_rank_table_i32, (const int*)lengths_i32,
             max_blocks, num_heads, num_kv_heads, num_retrieval_kv_heads, tokens_per_block, tokens_per_sub_chunk,
-            padded_sub_chunks, (const float*)rope_cos_sin_f32, rope_max_pos};
+            padded_sub_chunks, (const float*)rope_cos_sin_f32, rope_max_pos, kv_row_bytes};
   const int group = num_heads / num_kv_heads;
   const int subs = tokens_per_block / tokens_per_sub_chunk;
   const int pages = (padded_sub_chunks + subs - 1) / subs;

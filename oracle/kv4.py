@@ -105,6 +105,7 @@ class PagedKV4:
 
     def __init__(self, num_pages, num_kv_heads, head_dim, tokens_per_block=64, fill=0, stats_sub_chunk=0):
         self.H, self.D, self.TPB = num_kv_heads, head_dim, tokens_per_block
+        self.row_bytes = head_dim // 2
         self.bytes_per_seq = num_kv_heads * tokens_per_block * (head_dim // 2)
         self.page_bytes = page_bytes(num_kv_heads, head_dim, tokens_per_block)
         if stats_sub_chunk:   # K page with min/max statistics appended (cache_engine.py:75-88)
@@ -122,11 +123,14 @@ class PagedKV4:
         o = self.bytes_per_seq + self.H * self.TPB * 2
         return self.pool[page, o: o + self.H * self.TPB * 2].view(F16).reshape(self.H, self.TPB)
 
-    def write_token(self, page, slot, head, x_h):
+    def write_token(self, page, slot, head, x_h, decode=False):
         sc, ze = kv4_quant_params(x_h)
         self.data(page)[head, slot] = kv4_quantize(x_h, sc, ze)
         self.scales(page)[head, slot] = sc
         self.zeros(page)[head, slot] = ze
+
+    def read_row(self, page, head, slot):
+        return kv4_dequant(self.data(page)[head, slot], self.scales(page)[head, slot], self.zeros(page)[head, slot])
 
     def read_tokens(self, table_row, head, n, fp16_math=True):
         """Dequantized [n, D] float32 for logical tokens 0..n-1 of one sequence (vectorised gather)."""
@@ -228,15 +232,18 @@ def decode_attention(q_h, k_h, v_h, lengths, k_cache: PagedKV4, v_cache: PagedKV
 
 
 # ---- LServe dynamic sparsity (sparse_utils/ContextPool, sparse_utils/KVPageSelector) --------------------
-def stats_page_bytes(num_heads_in_pool, head_dim, tokens_per_block, sub_chunk):
-    """K page with min/max statistics (cache_engine.py:75-88)."""
-    return page_bytes(num_heads_in_pool, head_dim, tokens_per_block) + \
+def stats_page_bytes(num_heads_in_pool, head_dim, tokens_per_block, sub_chunk, row_bytes=None):
+    """K page with min/max statistics (cache_engine.py:75-88).  row_bytes = bytes of one token row of one head
+    (Dh/2 for KV4, the default; Dh for KV8): the statistics sit behind data + the 4 B/token-head tail."""
+    rb = head_dim // 2 if row_bytes is None else row_bytes
+    return num_heads_in_pool * tokens_per_block * (rb + 4) + \
         2 * (tokens_per_block // sub_chunk) * num_heads_in_pool * head_dim * 2
 
 
-def pool_views(pool_row, num_heads_in_pool, head_dim, tokens_per_block, sub_chunk):
+def pool_views(pool_row, num_heads_in_pool, head_dim, tokens_per_block, sub_chunk, row_bytes=None):
     """(kmax, kmin) fp16 views [subs][H][D] of one K page (uint8 row)."""
-    base = page_bytes(num_heads_in_pool, head_dim, tokens_per_block)
+    rb = head_dim // 2 if row_bytes is None else row_bytes
+    base = num_heads_in_pool * tokens_per_block * (rb + 4)
     subs = tokens_per_block // sub_chunk
     n = subs * num_heads_in_pool * head_dim
     kmax = pool_row[base: base + 2 * n].view(F16).reshape(subs, num_heads_in_pool, head_dim)
@@ -244,7 +251,8 @@ def pool_views(pool_row, num_heads_in_pool, head_dim, tokens_per_block, sub_chun
     return kmax, kmin
 
 
-def paged_min_max_pool(k_h, cu_seqlens, pooling_heads_idx, pool, k_table, tokens_per_block, sub_chunk):
+def paged_min_max_pool(k_h, cu_seqlens, pooling_heads_idx, pool, k_table, tokens_per_block, sub_chunk,
+                       row_bytes=None):
     """context_pool_kernel.cu:33-71: per (sequence, pooled head, sub-chunk) elementwise max/min of the keys
     (tokens past the end repeat the last one; a sub-chunk is stored only if its first token exists).
     pool: uint8 [pages, stats_page_bytes]; k_table [B][pages] page indices."""
@@ -260,14 +268,14 @@ def paged_min_max_pool(k_h, cu_seqlens, pooling_heads_idx, pool, k_table, tokens
                 toks = np.minimum(np.arange(t0, t0 + sub_chunk), L - 1)
                 blk = k_h[s0 + toks, int(hin)]
                 page = int(k_table[b][t0 // tokens_per_block])
-                kmax, kmin = pool_views(pool[page], H, D, tokens_per_block, sub_chunk)
+                kmax, kmin = pool_views(pool[page], H, D, tokens_per_block, sub_chunk, row_bytes)
                 sc = (t0 % tokens_per_block) // sub_chunk
                 kmax[sc, r] = blk.max(axis=0)
                 kmin[sc, r] = blk.min(axis=0)
 
 
 def page_selector(q_h, lengths, retrieval_head_flags, head_rank_table, pool, k_table, num_kv_heads,
-                  num_retrieval_kv_heads, tokens_per_block, sub_chunk, rope_base, rope_scale=1.0):
+                  num_retrieval_kv_heads, tokens_per_block, sub_chunk, rope_base, rope_scale=1.0, row_bytes=None):
     """KVPageSelectorTemplate.hpp:482-493: score[b,h,c] = sum_d max(h(q_d*kmax_d), h(q_d*kmin_d)) with fp16
     products; q rotated at position lengths[b]-1.  Streaming heads stay zero.  Returns fp16 [B,Hq,padded]."""
     q_h = np.asarray(q_h, F16)
@@ -288,7 +296,7 @@ def page_selector(q_h, lengths, retrieval_head_flags, head_rank_table, pool, k_t
             rank = int(head_rank_table[hk])
             for c in range((tlen + sub_chunk - 1) // sub_chunk):
                 page = int(k_table[b][(c * sub_chunk) // tokens_per_block])
-                kmax, kmin = pool_views(pool[page], num_retrieval_kv_heads, D, tokens_per_block, sub_chunk)
+                kmax, kmin = pool_views(pool[page], num_retrieval_kv_heads, D, tokens_per_block, sub_chunk, row_bytes)
                 a = (qr[h] * kmax[c % grp, rank]).astype(F16)
                 bb = (qr[h] * kmin[c % grp, rank]).astype(F16)
                 out[b, h, c] = np.maximum(a, bb).astype(np.float64).sum()
@@ -307,7 +315,8 @@ def ring_block(blk: int, sink_blocks: int, local_blocks: int) -> int:
 
 
 class FineGrainedKV:
-    """The two page pools of one layer: retrieval (K pages optionally with min/max statistics) and streaming
+    """The two page pools of one layer (PagedKV4 pools, or oracle.kv8.PagedKV8 pools for the per_tensor KV8
+    family -- same head classes, rings and page selection): retrieval (K pages optionally with min/max statistics) and streaming
     (ring of sink_blocks + local_blocks pages per sequence).  Tables hold page indices [B][blocks]."""
 
     def __init__(self, retr_k, retr_v, retr_k_table, retr_v_table, strm_k, strm_v, strm_k_table, strm_v_table,
@@ -328,12 +337,12 @@ class FineGrainedKV:
         return (self.strm_k, self.strm_v, int(self.strm_k_table[b][blk]), int(self.strm_v_table[b][blk]),
                 t % self.strm_k.TPB)
 
-    def write(self, b, hk, t, k_row, v_row, update_stats=False):
+    def write(self, b, hk, t, k_row, v_row, update_stats=False, decode=False):
         kc, vc, kp, vp, slot = self.locate(b, hk, t)
-        kc.write_token(kp, slot, self.rank[hk], k_row)
-        vc.write_token(vp, slot, self.rank[hk], v_row)
+        kc.write_token(kp, slot, self.rank[hk], k_row, decode=decode)
+        vc.write_token(vp, slot, self.rank[hk], v_row, decode=decode)
         if update_stats and self.flags[hk] and self.sub_chunk:
-            kmax, kmin = pool_views(kc.pool[kp], kc.H, kc.D, kc.TPB, self.sub_chunk)
+            kmax, kmin = pool_views(kc.pool[kp], kc.H, kc.D, kc.TPB, self.sub_chunk, kc.row_bytes)
             sc = slot // self.sub_chunk
             kf = np.asarray(k_row, F16)
             kmax[sc, self.rank[hk]] = np.fmax(kmax[sc, self.rank[hk]], kf)
@@ -347,8 +356,8 @@ class FineGrainedKV:
         r = self.rank[hk]
         for i, t in enumerate(toks):
             kc, vc, kp, vp, slot = self.locate(b, hk, int(t))
-            K[i] = kv4_dequant(kc.data(kp)[r, slot], kc.scales(kp)[r, slot], kc.zeros(kp)[r, slot])
-            V[i] = kv4_dequant(vc.data(vp)[r, slot], vc.scales(vp)[r, slot], vc.zeros(vp)[r, slot])
+            K[i] = kc.read_row(kp, r, slot)
+            V[i] = vc.read_row(vp, r, slot)
         return K, V
 
 
@@ -421,5 +430,5 @@ def decode_attention_fine_grained(q_h, k_h, v_h, lengths, fg: FineGrainedKV, rop
                 p = e / (e.sum() + 1e-6)
                 vals = np.concatenate([Vc.astype(np.float64), vr[hk][None, :].astype(np.float64)], axis=0)
                 out[b, hq] = (p[:, None] * vals).sum(axis=0).astype(F16)
-            fg.write(b, hk, tlen, kr[hk], vr[hk], update_stats=dyn_pages is not None)
+            fg.write(b, hk, tlen, kr[hk], vr[hk], update_stats=dyn_pages is not None, decode=True)
     return out

@@ -48,6 +48,9 @@ REFERENCE_API = {
     "fused_attention_fine_grained_dense": {"apply_bias_rope_update_kv_cache": 27, "compute_padding_offsets": 3,
                                            "single_query_attention": 27},
     "fused_attention_fine_grained_sparse": {"single_query_attention": 30},
+    # per_tensor KV8 family (fused_attention_per_tensor/*/fused_attention.h, per_tensor_common/update_kv_cache.h)
+    "fused_attention_per_tensor_dense": {"apply_bias_rope_update_kv_cache": 28, "single_query_attention": 29},
+    "fused_attention_per_tensor_sparse": {"single_query_attention": 32},
 }
 
 THIRD_PARTY_API = {   # un-vendored packages the reference imports for prefill attention

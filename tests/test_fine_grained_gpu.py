@@ -16,8 +16,11 @@ ROPE_BASE = 500000.0
 
 
 class Case:
-    def __init__(self, seq_lens, Hq, flags, tpb, sink, local, seed, sub_chunk=0, extra_tokens=8, scale=1.0):
+    def __init__(self, seq_lens, Hq, flags, tpb, sink, local, seed, sub_chunk=0, extra_tokens=8, scale=1.0,
+                 kv8_scales=None):
+        """kv8_scales = (k_scale_quant_orig, v_scale_quant_orig): the per-tensor KV8 family instead of KV4."""
         self.rng = np.random.default_rng(seed)
+        self.kv8 = kv8_scales
         self.seq_lens = [int(x) for x in seq_lens]
         self.B, self.Hq, self.Hk, self.tpb = len(seq_lens), Hq, len(flags), tpb
         self.flags = np.asarray(flags, np.int32)
@@ -38,11 +41,20 @@ class Case:
         perm = lambda n, m: self.rng.permutation(n * m).reshape(n, m)
         self.rk_idx, self.rv_idx = perm(B, rpages), perm(B, rpages)
         self.sk_idx, self.sv_idx = perm(B, spages), perm(B, spages)
-        mk = kv4.PagedKV4
-        self.rk = mk(B * rpages, max(nr, 1), D, tpb, fill=0x3C, stats_sub_chunk=sub_chunk)
-        self.rv = mk(B * rpages, max(nr, 1), D, tpb, fill=0x3C)
-        self.sk = mk(B * spages, max(ns, 1), D, tpb, fill=0x3C)
-        self.sv = mk(B * spages, max(ns, 1), D, tpb, fill=0x3C)
+        if kv8_scales is None:
+            mk_k = mk_v = kv4.PagedKV4
+            self.row = D // 2
+        else:
+            from oracle import kv8
+            mk_k = lambda n, h, d, t, **kw: kv8.PagedKV8(n, h, d, kv8_scales[0], t, **kw)
+            mk_v = lambda n, h, d, t, **kw: kv8.PagedKV8(n, h, d, kv8_scales[1], t, **kw)
+            self.row = D
+            qo = np.asarray(kv8_scales, np.float32)
+            self.qo_d, self.oq_d = to_dev(qo), to_dev((np.float32(1.0) / qo).astype(np.float32))
+        self.rk = mk_k(B * rpages, max(nr, 1), D, tpb, fill=0x3C, stats_sub_chunk=sub_chunk)
+        self.rv = mk_v(B * rpages, max(nr, 1), D, tpb, fill=0x3C)
+        self.sk = mk_k(B * spages, max(ns, 1), D, tpb, fill=0x3C)
+        self.sv = mk_v(B * spages, max(ns, 1), D, tpb, fill=0x3C)
         self.fg = kv4.FineGrainedKV(self.rk, self.rv, self.rk_idx, self.rv_idx, self.sk, self.sv, self.sk_idx,
                                     self.sv_idx, self.flags, self.rank, sink, local, self.sink_blocks,
                                     self.local_blocks, sub_chunk)
@@ -69,10 +81,18 @@ class Case:
         pad = fa.compute_padding_offsets(to_dev(cu), max_len, T)
         qkv_d = to_dev(qkv)
         lens_d = to_dev(np.asarray(self.seq_lens, np.int32))
-        fa.apply_bias_rope_update_kv_cache(
-            qkv_d, lens_d, lens_d, pad, self.g_retr.table, self.g_strm.table, self.flags_d, self.rank_d, Hq, Hk,
-            max_len, self.tpb, self.nr * D // 2, self.ns * D // 2, self.sink, self.local, self.sink_blocks,
-            self.local_blocks, self.nr, self.ns, D, ROPE_BASE, self.scale, 1 << 20, True, True, True)
+        if self.kv8 is None:
+            fa.apply_bias_rope_update_kv_cache(
+                qkv_d, lens_d, lens_d, pad, self.g_retr.table, self.g_strm.table, self.flags_d, self.rank_d, Hq, Hk,
+                max_len, self.tpb, self.nr * D // 2, self.ns * D // 2, self.sink, self.local, self.sink_blocks,
+                self.local_blocks, self.nr, self.ns, D, ROPE_BASE, self.scale, 1 << 20, True, True, True)
+        else:
+            import omniserve_backend.fused_attention_per_tensor_dense as fp
+            fp.apply_bias_rope_update_kv_cache(
+                qkv_d, self.oq_d, lens_d, lens_d, pad, self.g_retr.table, self.g_strm.table, self.flags_d,
+                self.rank_d, Hq, Hk, max_len, self.tpb, self.nr * D, self.ns * D, self.sink, self.local,
+                self.sink_blocks, self.local_blocks, self.nr, self.ns, D, ROPE_BASE, self.scale, 1 << 20, True,
+                False, False)
         torch.cuda.synchronize()
         assert_f16_equal(qkv_d, want, "qkv after in-place RoPE")
         self.check_pools("prefill")
@@ -95,9 +115,23 @@ class Case:
             qd = qkv_d[:, : Hq * D].view(B, Hq, D)
             kd = qkv_d[:, Hq * D:(Hq + Hk) * D].view(B, Hk, D)
             vd = qkv_d[:, (Hq + Hk) * D:].view(B, Hk, D)
-            common = (self.tpb, self.nr * D // 2, self.ns * D // 2, self.sink, self.local, self.sink_blocks,
-                      self.local_blocks, self.nr, self.ns, int(lens.max()), D, ROPE_BASE, self.scale, True, True, True)
-            if dyn is None:
+            kv4_mode = self.kv8 is None
+            common = (self.tpb, self.nr * self.row, self.ns * self.row, self.sink, self.local, self.sink_blocks,
+                      self.local_blocks, self.nr, self.ns, int(lens.max()), D, ROPE_BASE, self.scale, True,
+                      kv4_mode, kv4_mode)
+            if not kv4_mode:
+                import omniserve_backend.fused_attention_per_tensor_dense as fpd
+                import omniserve_backend.fused_attention_per_tensor_sparse as fps
+                if dyn is None:
+                    out = fpd.single_query_attention(qd, kd, vd, self.qo_d, self.oq_d, self.g_retr.table,
+                                                     self.g_strm.table, self.flags_d, self.rank_d, to_dev(lens),
+                                                     None, 65536, *common, 2048)
+                else:
+                    out = fps.single_query_attention(qd, kd, vd, self.qo_d, self.oq_d, self.g_retr.table,
+                                                     self.g_strm.table, self.flags_d, self.rank_d, to_dev(dyn),
+                                                     to_dev(lens), None, 65536, *common, self.sub_chunk,
+                                                     self.nr * D, 2048)
+            elif dyn is None:
                 out = fad.single_query_attention(qd, kd, vd, self.g_retr.table, self.g_strm.table, self.flags_d,
                                                  self.rank_d, to_dev(lens), None, 65536, *common, 2048)
             else:
