@@ -33,6 +33,23 @@ __device__ __forceinline__ float rounded_f32(float x) {
 
 // cvt.rni.sat.s8.f32 (reference kernels/csrc/utils.cuh:79-84): round half to
 // even, saturate to [-128,127], NaN -> 0.
+// load through a pointer that came out of an int64 page table: tell the compiler it is global memory, otherwise
+// it emits flat_load (slower path, and it also counts in lgkmcnt, tying LDS waits to outstanding memory loads)
+template <class T>
+__device__ __forceinline__ T gload(const void* p) {
+  return *(const __attribute__((address_space(1))) T*)(p);
+}
+typedef uint32_t v4u_native __attribute__((ext_vector_type(4)));
+template <>
+__device__ __forceinline__ uint4 gload<uint4>(const void* p) {
+  const v4u_native t = *(const __attribute__((address_space(1))) v4u_native*)(p);
+  return make_uint4(t[0], t[1], t[2], t[3]);
+}
+template <class T>
+__device__ __forceinline__ void gstore(void* p, T v) {
+  *(__attribute__((address_space(1))) T*)(p) = v;
+}
+
 __device__ __forceinline__ int8_t rni_sat_s8(float x) {
   float r = __builtin_rintf(x);
   r = (r != r) ? 0.0f : r;

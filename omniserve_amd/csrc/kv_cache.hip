@@ -225,18 +225,27 @@ __global__ __launch_bounds__(256) void kv4_prefill_write_kernel(
 // unpack 16 packed bytes (32 codes) and dequantise with fp16 fma(u, scale, c), c = h(-scale*zero).
 // Output order per 32-bit word of 8 codes e0..e7: half2 pairs (e0,e4) (e1,e5) (e2,e6) (e3,e7),
 // i.e. out[w*4 + j] = {e_j, e_{j+4}} of word w (the q operand is loaded in the same order).
+// (x & mask) | magic in one VALU op.  VOP3 on gfx9 takes one scalar operand, so the magic lives in a VGPR; the
+// compiler emits v_and + v_or with two literals otherwise (64 extra ops per 32-token tile of the decode kernels).
+__device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t mask, uint32_t magic) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(magic));
+  return r;
+}
+
 __device__ __forceinline__ void kv4_dequant16(const uint4 raw, v2h scale2, v2h c2, v2h out[16]) {
   const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
   const v2h k1024 = {(half_t)1024.0f, (half_t)1024.0f};
   const v2h k16th = {(half_t)0.0625f, (half_t)0.0625f};
   const v2h k64 = {(half_t)64.0f, (half_t)64.0f};
+  const uint32_t magic = 0x64006400u;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const uint32_t x = w[i], y = w[i] >> 8;
-    uint32_t h0 = (x & 0x000f000fu) | 0x64006400u;  // {1024+e0, 1024+e4}
-    uint32_t h1 = (x & 0x00f000f0u) | 0x64006400u;  // {1024+16 e1, 1024+16 e5}
-    uint32_t h2 = (y & 0x000f000fu) | 0x64006400u;  // e2, e6
-    uint32_t h3 = (y & 0x00f000f0u) | 0x64006400u;  // e3, e7
+    uint32_t h0 = and_or(x, 0x000f000fu, magic);  // {1024+e0, 1024+e4}
+    uint32_t h1 = and_or(x, 0x00f000f0u, magic);  // {1024+16 e1, 1024+16 e5}
+    uint32_t h2 = and_or(y, 0x000f000fu, magic);  // e2, e6
+    uint32_t h3 = and_or(y, 0x00f000f0u, magic);  // e3, e7
     v2h u0 = __builtin_bit_cast(v2h, h0) - k1024;
     v2h u1 = __builtin_elementwise_fma(__builtin_bit_cast(v2h, h1), k16th, -k64);
     v2h u2 = __builtin_bit_cast(v2h, h2) - k1024;
@@ -1064,6 +1073,8 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs
 // fg.dyn (one list per q head, hence G = 1), min(sink+local-1, tlen) tokens read through the page
 // ring for a streaming head (decoderMaskedMultiheadAttentionTemplate.hpp:1475-1537 of
 // fused_attention_fine_grained/dense_attention, :1566-1641 of sparse_attention).
+constexpr int FVROW = 288;          // V tile row pitch of the flash kernel (see the layout note in the kernel)
+constexpr int FVTILE = 32 * FVROW;
 #ifndef OMNI_FLASH_MIN_BLOCKS
 #define OMNI_FLASH_MIN_BLOCKS 2
 #endif
@@ -1080,7 +1091,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   int64_t* pages = reinterpret_cast<int64_t*>(red + 64);      // [2][40]
   float* xbuf = reinterpret_cast<float*>(pages + 80);         // [4 waves][G][128]
   float* mlbuf = xbuf + DEC_WAVES * G * DH;                   // [4 waves][G][2]  (max, sum) of each wave
-  uint8_t* vtile = reinterpret_cast<uint8_t*>(mlbuf + DEC_WAVES * G * 2);   // [4 waves][32][VROW]
+  uint8_t* vtile = reinterpret_cast<uint8_t*>(mlbuf + DEC_WAVES * G * 2);   // [4 waves][32][FVROW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int split = blockIdx.x;
@@ -1145,7 +1156,8 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       if (pg < p.max_blocks) my_page = tab[pg];   // entries past the sequence's pages are never dereferenced
     }
   }
-  const int64_t dummy_ptr = ktab[0];   // the sequence's first page: always allocated (an empty split reads it, unused)
+  // the sequence's first K / V page: always allocated (an empty split reads it, unused)
+  const int64_t dummy_ptr = tid < 80 ? (tid < 40 ? ktab : vtab)[0] : 0;
   constexpr int QIT = ((G + 1) * 64 + DEC_THREADS - 1) / DEC_THREADS;
   half_t qa[QIT], qbv[QIT];
 #pragma unroll
@@ -1173,7 +1185,9 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   const int t0 = min(nvirt, vt0);
   const int t1 = min(nvirt, vt0 + p.split_tokens);
   const int nt = t1 - t0;
-  if (tid < 80) pages[tid] = my_page;
+  // an empty split (nt == 0) still runs one branch-free load batch: it reads slot 0 of window entry 0, which then
+  // holds the sequence's first page (always allocated)
+  if (tid < 80) pages[tid] = (nt == 0 && (tid == 0 || tid == 40)) ? dummy_ptr : my_page;
 
   // virtual token -> (index into pages[], slot in the page)
   auto locate = [&](int vt, int& pidx, int& slot) {
@@ -1208,8 +1222,6 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   OMNI_CLK(17);
   __syncthreads();   // pages[] visible
 
-  const bool has_tokens = nt > 0;
-  const uint8_t* dummy_page = reinterpret_cast<const uint8_t*>(dummy_ptr);
   const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
   const size_t vhead_off = (size_t)hrank * lay.tpb * RB + vpiece * 16 * NQ;
   const size_t khead_off = (size_t)hrank * lay.tpb * RB + l4 * 16 * NQ;  // K: lane = (token l15, 32-value piece l4)
@@ -1219,41 +1231,42 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   constexpr int FB = 2;
   uint4 kraw[FB][2][NQ], vraw[FB][2][NQ];
   half_t ksc[FB][2], kze[FB][2], vsc[FB][2], vze[FB][2];   // KV4 only
-  auto load_batch = [&](int i0) {   // branch-free: out-of-range tokens re-read token t0 (or the dummy page)
+  // safe token of an out-of-range lane: the split's first token, or (empty split) slot 0 of window entry 0
+  const int tsafe = nt > 0 ? t0 : ((FG && streaming) ? 0 : (page0 << lay.tpb_log2));
+  auto load_batch = [&](int i0) {   // branch-free; page pointers of the whole batch first, then every load
+    const uint8_t* kp[FB][2];
+    const uint8_t* vp[FB][2];
+    int ks_[FB][2], vs_[FB][2];
 #pragma unroll
     for (int u = 0; u < FB; ++u)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int tile = wave + DEC_WAVES * (i0 + u);
-        {
-          const int ti = tile * 32 + h * 16 + l15;
-          const int tok = ti < nt ? t0 + ti : t0;
-          int pidx, slot;
-          locate(tok, pidx, slot);
-          const uint8_t* pg = has_tokens ? reinterpret_cast<const uint8_t*>(pages[has_tokens ? pidx : 0]) : dummy_page;
+        int pidx;
+        const int tik = tile * 32 + h * 16 + l15;
+        locate(tik < nt ? t0 + tik : tsafe, pidx, ks_[u][h]);
+        kp[u][h] = reinterpret_cast<const uint8_t*>(pages[pidx]);
+        const int tiv = tile * 32 + h * 16 + vtok;
+        locate(tiv < nt ? t0 + tiv : tsafe, pidx, vs_[u][h]);
+        vp[u][h] = reinterpret_cast<const uint8_t*>(pages[40 + pidx]);
+      }
 #pragma unroll
-          for (int n = 0; n < NQ; ++n)
-            kraw[u][h][n] = *reinterpret_cast<const uint4*>(pg + khead_off + (size_t)slot * RB + 16 * n);
-          if constexpr (!KV8) {
-            const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
-            ksc[u][h] = tail[0];
-            kze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
-          }
-        }
-        {
-          const int ti = tile * 32 + h * 16 + vtok;
-          const int tok = ti < nt ? t0 + ti : t0;
-          int pidx, slot;
-          locate(tok, pidx, slot);
-          const uint8_t* pg = has_tokens ? reinterpret_cast<const uint8_t*>(pages[40 + (has_tokens ? pidx : 0)]) : dummy_page;
+    for (int u = 0; u < FB; ++u)
 #pragma unroll
-          for (int n = 0; n < NQ; ++n)
-            vraw[u][h][n] = *reinterpret_cast<const uint4*>(pg + vhead_off + (size_t)slot * RB + 16 * n);
-          if constexpr (!KV8) {
-            const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
-            vsc[u][h] = tail[0];
-            vze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
-          }
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int n = 0; n < NQ; ++n)
+          kraw[u][h][n] = gload<uint4>(kp[u][h] + khead_off + (size_t)ks_[u][h] * RB + 16 * n);
+#pragma unroll
+        for (int n = 0; n < NQ; ++n)
+          vraw[u][h][n] = gload<uint4>(vp[u][h] + vhead_off + (size_t)vs_[u][h] * RB + 16 * n);
+        if constexpr (!KV8) {
+          const uint8_t* kt = kp[u][h] + tail_off + 2 * ks_[u][h];
+          ksc[u][h] = gload<half_t>(kt);
+          kze[u][h] = gload<half_t>(kt + zero_off);
+          const uint8_t* vt_ = vp[u][h] + tail_off + 2 * vs_[u][h];
+          vsc[u][h] = gload<half_t>(vt_);
+          vze[u][h] = gload<half_t>(vt_ + zero_off);
         }
       }
   };
@@ -1301,8 +1314,11 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
 #pragma unroll
   for (int c = 0; c < 8; ++c) oacc[c] = (v4f){0.f, 0.f, 0.f, 0.f};
   float m_run = -1e30f, l_run = 0.0f;   // this lane's head column: running max, partial sum over its own tokens
-  uint8_t* vt = vtile + wave * VTILE;
-  const int tr_off = (4 * l4 + (l15 >> 2)) * VROW + (l15 & 3) * 8;
+  uint8_t* vt = vtile + wave * FVTILE;
+  // V tile rows of FVROW = 288 B (72 dwords = 8 mod 64: the 8 rows a 32-lane group of ds_read_b64_tr_b16 touches
+  // fall in 8 disjoint 8-bank groups); the 16-B units of pieces 2, 3 are pair-swapped so that the 8 lanes (2 tokens x 4
+  // pieces) of a ds_write_b128 group hit 8 different 4-bank groups.  PMC before: 40 % of the LDS cycles were conflicts.
+  const int tr_off = (4 * l4 + (l15 >> 2)) * FVROW + (l15 & 3) * 8;
   const int my_tiles = ntiles > wave ? (ntiles - wave + DEC_WAVES - 1) / DEC_WAVES : 0;
   for (int i0 = 0; i0 < my_tiles; i0 += FB) {
     uint4 kr[FB][2][NQ], vr[FB][2][NQ];
@@ -1379,21 +1395,22 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
           const half_t ch = (half_t)(-(float)vs[u][h] * (float)vz[u][h]);
           kv4_dequant16(vr[u][h][0], (v2h){vs[u][h], vs[u][h]}, (v2h){ch, ch}, vd);
         }
-        uint8_t* dst = vt + (h * 16 + vtok) * VROW + vpiece * 64;   // 32 values in dequant order
+        uint8_t* dst = vt + (h * 16 + vtok) * FVROW + vpiece * 64;   // 32 values in dequant order
+        const int wsw = vpiece >> 1;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const v8h t = {vd[4 * w][0], vd[4 * w][1], vd[4 * w + 1][0], vd[4 * w + 1][1],
                          vd[4 * w + 2][0], vd[4 * w + 2][1], vd[4 * w + 3][0], vd[4 * w + 3][1]};
-          *reinterpret_cast<v8h*>(dst + w * 16) = t;
+          *reinterpret_cast<v8h*>(dst + (w ^ wsw) * 16) = t;
         }
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const uint8_t* src = vt + tr_off + c * 32;
+        const uint8_t* src = vt + (c < 4 ? tr_off : (tr_off ^ 16)) + c * 32;   // pieces 2, 3: swapped unit pairs
         const v4hp lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
             (__attribute__((address_space(3))) v4hp*)(__attribute__((address_space(3))) void*)(src));
         const v4hp hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-            (__attribute__((address_space(3))) v4hp*)(__attribute__((address_space(3))) void*)(src + 16 * VROW));
+            (__attribute__((address_space(3))) v4hp*)(__attribute__((address_space(3))) void*)(src + 16 * FVROW));
         const v8h a = {(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
                        (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
         oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb, oacc[c], 0, 0, 0);
@@ -1454,7 +1471,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       int blk8 = tlen >> lay.tpb_log2;
       if (FG && streaming) blk8 = ring_block(blk8, p.fg.sink_blocks, p.fg.local_blocks);
       const int wi8 = blk8 - page0;
-      const bool in_window8 = !(FG && dyn != nullptr) && wi8 >= 0 && wi8 < 40;
+      const bool in_window8 = nt > 0 && !(FG && dyn != nullptr) && wi8 >= 0 && wi8 < 40;
       uint8_t* pg8 = reinterpret_cast<uint8_t*>(in_window8 ? pages[(wave == 0 ? 0 : 40) + wi8] : tab[blk8]);
       const int slot8 = tlen & (lay.tpb - 1);
       uint8_t* dst8 = pg8 + ((size_t)hrank * lay.tpb + slot8) * RB;
@@ -1488,7 +1505,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
     if (FG && streaming) blk = ring_block(blk, p.fg.sink_blocks, p.fg.local_blocks);
     // the page pointer normally sits in the LDS window already (no dependent load at the kernel's end)
     const int wi = blk - page0;
-    const bool in_window = !(FG && dyn != nullptr) && wi >= 0 && wi < 40;
+    const bool in_window = nt > 0 && !(FG && dyn != nullptr) && wi >= 0 && wi < 40;   // nt == 0: entry 0 is the dummy
     uint8_t* pg = reinterpret_cast<uint8_t*>(in_window ? pages[(wave == 0 ? 0 : 40) + wi] : tab[blk]);
     const int slot = tlen & (lay.tpb - 1);
     uint8_t* dst = pg + ((size_t)hrank * lay.tpb + slot) * RB;
@@ -1556,29 +1573,42 @@ static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int ma
   pl.g = group >= 4 ? 4 : group;  // group in {1,2,4,8,...}
   if (per_q_head) pl.g = 1;       // every q head walks its own page list
   const int wgs_per_split = batch * num_kv_heads * (group / pl.g);
-  // the kernel runs one 256-thread workgroup per CU (it spends the register file on the P.V
-  // accumulators): split the KV range until there are ~2 workgroups per CU; a single split skips
-  // the merge kernel
-  int s = wgs_per_split >= 512 ? 1 : (512 + wgs_per_split - 1) / wgs_per_split;
+  // LDS bound of the two-pass kernel's score buffer; the kernels keep a window of 40 page pointers per split
+  const int st_cap = 38 * tokens_per_block < 2048 ? 38 * tokens_per_block : 2048;
+  const int max_s0 = (max_context + 63) / 64;
+  const int max_s = max_s0 < 1 ? 1 : (max_s0 > DEC_MAX_SPLITS ? DEC_MAX_SPLITS : max_s0);
+  auto split_tokens = [&](int n) { return ((max_context + n - 1) / n + 15) & ~15; };
+  // Two 256-thread workgroups fit a CU (register file): 512 slots.  The workgroups of a launch run in
+  // ceil(W*s / 512) rounds of about (tokens per split + a fixed prologue/epilogue worth ~192 tokens) each; pick
+  // the split count that minimises that product (a 17-way split of 64 (sequence, head) pairs was 3 rounds of 1936
+  // tokens where 24 splits are 3 rounds of 1376).  A single split skips the merge kernel.
+  int s_lo = 1;
+  while (s_lo < max_s && split_tokens(s_lo) > st_cap) ++s_lo;
+  int s_hi = 2048 / wgs_per_split + 1;
+  if (s_hi < 2 * s_lo + 8) s_hi = 2 * s_lo + 8;
+  if (s_hi > max_s) s_hi = max_s;
+  int s = s_lo;
+  long long best = -1;
+  for (int n = s_lo; n <= s_hi; ++n) {
+    const long long rounds = ((long long)wgs_per_split * n + 511) / 512;
+    const long long cost = rounds * (split_tokens(n) + 192);
+    if (best < 0 || cost < best) { best = cost; s = n; }
+  }
   if (g_override_nsplit > 0) s = g_override_nsplit;
-  const int max_s = (max_context + 63) / 64;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
-  if (s > DEC_MAX_SPLITS) s = DEC_MAX_SPLITS;
-  int st = ((max_context + s - 1) / s + 15) & ~15;
-  // LDS bound on the score buffer; the kernel keeps a window of 40 page pointers per split
-  const int st_cap = 38 * tokens_per_block < 2048 ? 38 * tokens_per_block : 2048;
+  int st = split_tokens(s);
   while (st > st_cap && s < DEC_MAX_SPLITS) {
     ++s;
-    st = ((max_context + s - 1) / s + 15) & ~15;
+    st = split_tokens(s);
   }
-  if (st > st_cap) st = st_cap;   // caller rejects: max_context > 64 * st_cap
+  if (st > st_cap) st = st_cap;   // caller rejects: max_context > 1024 * st_cap
   pl.nsplit = s;
   pl.split_tokens = st;
   pl.kernel = per_q_head_or_fg ? 0 : g_kernel_choice;
   if (pl.kernel == 0)
     pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * pl.g * DH * 4 +
-                   (size_t)DEC_WAVES * pl.g * 2 * 4 + (size_t)DEC_WAVES * VTILE;
+                   (size_t)DEC_WAVES * pl.g * 2 * 4 + (size_t)DEC_WAVES * FVTILE;
   else if (pl.kernel == 1)
     pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * pl.g * DH * 4 +
                    (size_t)DEC_WAVES * VTILE + (size_t)pl.g * (st + 32) * 6;
@@ -1734,10 +1764,15 @@ extern "C" void omni_kv4_decode_set_split_override(int nsplit) {
 extern "C" size_t omni_kv4_decode_workspace_bytes(int batch, int num_heads, int head_dim, int max_context) {
   (void)head_dim;
   if (batch < 1 || num_heads < 1) return 0;
-  // upper bound of the planner's split count for any tokens_per_block >= 16 (a split holds >= 512 tokens
-  // once the context forces more than 64 splits)
-  long long s = 64;
-  if ((long long)max_context > 64LL * 512) s = ((long long)max_context + 511) / 512 + 1;
+  // upper bound of the planner's split count for any tokens_per_block >= 16 and any number of kv heads (a split
+  // holds >= 512 tokens once the context forces splitting; the round-aware search looks at most up to
+  // max(2048 / workgroups-per-split + 1, 2 * minimum split count + 8))
+  long long s = 2048 / batch + 1;
+  const long long s2 = 2 * (((long long)max_context + 511) / 512 + 1) + 8;
+  if (s < s2) s = s2;
+  const long long max_s = ((long long)max_context + 63) / 64;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
   if (s > DEC_MAX_SPLITS) s = DEC_MAX_SPLITS;
   return (size_t)batch * num_heads * (size_t)s * (DH + 2) * sizeof(float);
 }

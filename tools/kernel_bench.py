@@ -13,6 +13,8 @@ import omniserve_backend.activation_ops as act  # noqa: E402
 import omniserve_backend.fused_attention_ctx_pool as ctx_pool  # noqa: E402
 import omniserve_backend.fused_attention_fine_grained_dense as fgd  # noqa: E402
 import omniserve_backend.fused_attention_fine_grained_sparse as fgs  # noqa: E402
+import omniserve_backend.fused_attention_per_tensor_dense as ptd  # noqa: E402
+import omniserve_backend.fused_attention_per_tensor_sparse as pts  # noqa: E402
 import omniserve_backend.fused_attention_pure_dense as pd  # noqa: E402
 import omniserve_backend.fused_attention_selector as selector  # noqa: E402
 import omniserve_backend.fused_kernels as fk  # noqa: E402
@@ -108,14 +110,15 @@ def row_kernels():
 class Pools:
     """Synthetic KV4 pools + pointer tables ([B,2,blocks]) for `heads` heads per page."""
 
-    def __init__(self, B, blocks, heads, tpb=64, stats_sub=0):
-        self.page_bytes = heads * tpb * 64 + 2 * heads * tpb * 2
+    def __init__(self, B, blocks, heads, tpb=64, stats_sub=0, row=64):
+        """row = bytes of one token row of one head: 64 (KV4) or 128 (per-tensor KV8)."""
+        self.page_bytes = heads * tpb * row + 2 * heads * tpb * 2
         kbytes = self.page_bytes + (2 * (tpb // stats_sub) * heads * D * 2 if stats_sub else 0)
         n = B * blocks
         self.k = torch.randint(0, 256, (n, kbytes), dtype=torch.uint8, device=dev)
         self.v = torch.randint(0, 256, (n, self.page_bytes), dtype=torch.uint8, device=dev)
         for pool in (self.k, self.v):     # sane fp16 scales / zeros
-            tail = pool[:, heads * tpb * 64: self.page_bytes].view(torch.float16).view(n, 2, heads * tpb)
+            tail = pool[:, heads * tpb * row: self.page_bytes].view(torch.float16).view(n, 2, heads * tpb)
             tail[:, 0] = 0.05
             tail[:, 1] = 7.5
         if stats_sub:
@@ -187,6 +190,59 @@ def kv_kernels():
     report("a11", "paged_min_max_pool L=%d, 4 pooled heads, sub-chunk 16" % Lp, us, Lp * nr * D * 2 + (Lp // sub) * nr * D * 4)
 
 
+def kv8_kernels():
+    """the per-tensor KV8 family (LServe's published w8a8kv8 configuration)."""
+    Hq, Hk = 32, 8
+    qo = torch.tensor([0.03, 0.035], dtype=torch.float32, device=dev)
+    oq = 1.0 / qo
+    B, L = 16, 1024
+    T = B * L
+    pools = Pools(B, L // 64 + 1, Hk, row=128)
+    qkv = torch.randn((T, (Hq + 2 * Hk) * D), dtype=torch.float16, device=dev)
+    lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+    cu = torch.arange(0, B + 1, dtype=torch.int32, device=dev) * L
+    pad = pd.compute_padding_offsets(cu, L, T)
+    flags = torch.ones((Hk,), dtype=torch.int32, device=dev); rank = torch.arange(Hk, dtype=torch.int32, device=dev)
+    us = timed(lambda: ptd.apply_bias_rope_update_kv_cache(
+        qkv, oq, lens, None, pad, pools.table, None, flags, rank, Hq, Hk, L, 64, Hk * D, 0, 0, 0, 0, 0, Hk, 0, D,
+        500000.0, 1.0, 1 << 20, True, False, False))
+    report("f2", "KV8 per-tensor prefill writer %d tokens" % T, us, T * ((Hq + Hk) * 256 * 2 + Hk * 256 + 2 * Hk * 130))
+    for (B, Tc) in [(16, 1024), (8, 32768)]:
+        pools = Pools(B, Tc // 64 + 2, Hk, row=128)
+        lens = torch.full((B,), Tc + 1, dtype=torch.int32, device=dev)
+        q = torch.randn((B, Hq, D), dtype=torch.float16, device=dev)
+        k = torch.randn((B, Hk, D), dtype=torch.float16, device=dev); v = torch.randn_like(k)
+        us = timed(lambda: ptd.single_query_attention(q, k, v, qo, oq, pools.table, None, flags, rank, lens, None,
+                                                      1 << 20, 64, Hk * D, 0, 0, 0, 0, 0, Hk, 0, Tc + 1, D, 500000.0,
+                                                      1.0, True, False, False, 2048))
+        report("f2", "KV8 per-tensor decode attention B=%d T=%d (GQA 32/8, all retrieval heads)" % (B, Tc), us,
+               2 * Hk * D * Tc * B)
+    B, Tc, sub, budget = 1, 256000, 16, 64
+    nr = ns = 4
+    flags = torch.tensor([1, 0, 1, 0, 1, 0, 1, 0], dtype=torch.int32, device=dev)
+    rank = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3], dtype=torch.int32, device=dev)
+    retr = Pools(B, Tc // 64 + 2, nr, stats_sub=sub, row=128)
+    strm = Pools(B, 2 + 5, ns, row=128)
+    lens = torch.full((B,), Tc + 1, dtype=torch.int32, device=dev)
+    q = torch.randn((B, Hq, D), dtype=torch.float16, device=dev)
+    k = torch.randn((B, Hk, D), dtype=torch.float16, device=dev); v = torch.randn_like(k)
+    common = (64, nr * D, ns * D, 128, 256, 2, 5, nr, ns, Tc + 1, D, 500000.0, 1.0, True, False, False)
+    us = timed(lambda: ptd.single_query_attention(q, k, v, qo, oq, retr.table, strm.table, flags, rank, lens, None,
+                                                  1 << 20, *common, 2048), iters=5)
+    report("f2", "KV8 per-tensor dense decode B=1 T=256000 (4 retrieval + 4 streaming kv heads)", us,
+           2 * D * nr * Tc + 2 * D * ns * 383)
+    dyn = torch.randint(0, Tc // 64 - 1, (B, Hq, budget), dtype=torch.int32, device=dev)
+    dyn[..., -1] = (Tc - 1) // 64
+    us = timed(lambda: pts.single_query_attention(q, k, v, qo, oq, retr.table, strm.table, flags, rank, dyn, lens, None,
+                                                  1 << 20, *common, sub, nr * D, 2048))
+    report("f2", "KV8 per-tensor sparse decode B=1 T=256000, 64-page budget per q head", us,
+           16 * budget * 64 * 256 + 2 * D * ns * 383)
+    us = timed(lambda: selector.single_query_page_selector(
+        q, k, v, retr.table, strm.table, flags, rank, None, lens, None, 1 << 20, 64, nr * D, ns * D, 128, 256,
+        2, 5, nr, ns, Tc, D, 500000.0, 1.0, True, False, True, sub, nr * D, 2048))
+    report("f2", "page selector on KV8 pages B=1 T=256000 sub-chunk 16", us, (Tc // sub) * nr * 2 * D * 2)
+
+
 def prefill_attention():
     Hq, Hk = 32, 8
     for L in (4096, 16384):
@@ -206,12 +262,14 @@ def prefill_attention():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gemm", "row", "kv", "attn"]
+    which = sys.argv[1:] or ["gemm", "row", "kv", "kv8", "attn"]
     if "gemm" in which:
         gemms()
     if "row" in which:
         row_kernels()
     if "kv" in which:
         kv_kernels()
+    if "kv8" in which:
+        kv8_kernels()
     if "attn" in which:
         prefill_attention()
