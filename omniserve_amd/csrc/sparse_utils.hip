@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void kv_min_max_pool_kernel(PoolArgs p) {
       mx = x > mx ? x : mx;
       mn = x < mn ? x : mn;
     }
-    kmax[((size_t)sc * p.pool_h + r) * SDH + d] = mx;
-    kmin[((size_t)sc * p.pool_h + r) * SDH + d] = mn;
+    gstore<half_t>(kmax + ((size_t)sc * p.pool_h + r) * SDH + d, mx);
+    gstore<half_t>(kmin + ((size_t)sc * p.pool_h + r) * SDH + d, mn);
   }
 }
 
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void kv_page_selector_kernel(SelArgs p) {
       const int pg = cc / subs, sc = cc - pg * subs;
       const half_t* kmax = reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(page_lds[pg]) + stats_off) +
                            ((size_t)sc * p.num_retrieval_kv_heads + rank) * SDH + part * 8;
-      mx[u] = *reinterpret_cast<const v8h*>(kmax);
-      mn[u] = *reinterpret_cast<const v8h*>(kmax + min_off);
+      mx[u] = gload<v8h>(kmax);          // global_load (the pointer came out of the int64 page table)
+      mn[u] = gload<v8h>(kmax + min_off);
     }
 #pragma unroll
     for (int u = 0; u < SEL_UN; ++u) {
