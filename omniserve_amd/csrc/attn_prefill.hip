@@ -28,7 +28,9 @@ constexpr int PWAVES = 8;             // 8 waves x 16 rows: ~120 VGPRs per wave,
 constexpr int PPT = (PKT * 16) / (64 * PWAVES);   // 16-B pieces of a K (or V) tile per thread
 constexpr int PQROWS = 16 * PQB * PWAVES;   // 128 query rows per workgroup
 constexpr int PKROW = 256;            // bytes per key row of the K tile (swizzled slots)
-constexpr int PVROW = 272;            // bytes per key row of the V tile (256 + 16 pad)
+constexpr int PVROW = 288;            // bytes per key row of the V tile: 72 dwords = 8 mod 64, so the 8 rows a 32-lane
+                                      // group of ds_read_b64_tr_b16 touches use 8 disjoint 8-bank groups (272 gave 28 %
+                                      // conflict cycles, PMC)
 constexpr int PKTILE = PKT * PKROW, PVTILE = PKT * PVROW;
 typedef __fp16 pv4hp __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -186,8 +188,7 @@ void prefill_attn_kernel(PrefillArgs p) {
           st[j][u][r] = x;
           tmax = __builtin_fmaxf(tmax, x);
         }
-      tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      tmax = rows4_max(tmax);   // the 4 lanes of a query row
       const float m_new = __builtin_fmaxf(m_run[j], tmax);
       const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
       float psum = 0.0f;
@@ -230,8 +231,7 @@ void prefill_attn_kernel(PrefillArgs p) {
 #pragma unroll
   for (int j = 0; j < PQB; ++j) {
     float l = l_run[j];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = rows4_sum(l);
     if (qrow[j] >= len_q) continue;
     const float inv = l > 0.0f ? 1.0f / l : 0.0f;
     half_t* op = p.out + ((size_t)(q_begin + qrow[j]) * p.num_heads + h) * PDH + 4 * l4;

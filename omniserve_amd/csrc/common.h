@@ -122,6 +122,26 @@ __device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v); }
 // 64-lane max / sum, result in every lane.  Pairing order: xor 1, 2 inside quads, mirrored halves and rows,
 // then the four 16-lane rows through v_readlane.  max is exact in any order; wave_sum64 is only used where
 // the summation order is not part of a parity contract (softmax denominators, q.k of the current token).
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) without LDS traffic: gfx950's
+// v_permlane32_swap (upper half of a <-> lower half of b) and v_permlane16_swap (odd rows of a <-> even rows of b)
+// on two copies of the value leave every lane holding both partners; a ds_bpermute costs an LDS round trip each.
+__device__ __forceinline__ float rows4_max(float v) {
+  unsigned x = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  v = __builtin_fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+  x = __builtin_bit_cast(unsigned, v);
+  r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  return __builtin_fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float rows4_sum(float v) {   // (l + l^32) + (l^16 + l^48), the order of the shuffle tree
+  unsigned x = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+  x = __builtin_bit_cast(unsigned, v);
+  r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
 __device__ __forceinline__ float wave_max64(float v) {
   v = __builtin_fmaxf(v, lane_xor1(v));
   v = __builtin_fmaxf(v, lane_xor2(v));

@@ -1366,8 +1366,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
           tmax = __builtin_fmaxf(tmax, x[4 * h + r]);
         }
       }
-      tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      tmax = rows4_max(tmax);
       const float m_new = __builtin_fmaxf(m_run, tmax);
       const float alpha = __expf(m_run - m_new);
       float psum = 0.0f;
@@ -1418,8 +1417,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
     }
   }
   // ---- combine the four waves' (max, sum, O); add the current token; normalise / emit partials ----------------
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
+  l_run = rows4_sum(l_run);
   if (l15 < G) {
 #pragma unroll
     for (int c = 0; c < 8; ++c)
