@@ -25,12 +25,10 @@ constexpr int PDH = 128;
 constexpr int PKT = 64;               // keys per tile
 constexpr int PQB = 1;                // 16-row query blocks per wave
 constexpr int PWAVES = 8;             // 8 waves x 16 rows: ~120 VGPRs per wave, 4 waves per SIMD hide the softmax VALU work
-constexpr int PPT = (PKT * 16) / (64 * PWAVES);   // 16-B pieces of a K (or V) tile per thread
+constexpr int PPT = (PKT * 16) / (64 * PWAVES);   // 1-KiB LDS-DMA pieces of a K (or V) tile per wave
 constexpr int PQROWS = 16 * PQB * PWAVES;   // 128 query rows per workgroup
 constexpr int PKROW = 256;            // bytes per key row of the K tile (swizzled slots)
-constexpr int PVROW = 288;            // bytes per key row of the V tile: 72 dwords = 8 mod 64, so the 8 rows a 32-lane
-                                      // group of ds_read_b64_tr_b16 touches use 8 disjoint 8-bank groups (272 gave 28 %
-                                      // conflict cycles, PMC)
+constexpr int PVROW = 256;            // bytes per key row of the V tile (swizzled slots, see the kernel)
 constexpr int PKTILE = PKT * PKROW, PVTILE = PKT * PVROW;
 typedef __fp16 pv4hp __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -104,47 +102,49 @@ void prefill_attn_kernel(PrefillArgs p) {
   const int win_lo = streaming ? q_first + off - local + 1 : 0;                   // first local key of the first row
   auto skipped = [&](int kb) { return streaming && kb >= sink && kb + PKT <= win_lo; };   // tile inside the masked band
 
-  // cooperative tile staging: thread -> PPT (key, 16-B piece) pairs of K and of V.  The staging registers are
-  // plain named values (not arrays captured by a lambda): as arrays they ended up in scratch memory, which put a
-  // full wait right behind every prefetch load.
-  static_assert(PPT == 2, "staging below is written for two pieces per thread");
-  const int skey0 = tid >> 4, spiece = tid & 15;            // piece 0: keys 0..31, piece 1: keys 32..63
-  const int skey1 = skey0 + 32;
-  uint4 kreg0, kreg1, vreg0, vreg1;
-#define PREFILL_LOAD_TILE(kb_)                                                                                    \
+  // Tile staging by LDS-DMA (global_load_lds_dwordx4: one 1-KiB piece = 4 key rows per wave-instruction, no staging
+  // registers, no ds_write pass).  The LDS image of an instruction is lane-linear (base + 16*lane), so the bank
+  // swizzles are applied to the SOURCE address: lane l of piece i fills (row 4i + l/16, physical 16-B slot l%16)
+  // and fetches the logical slot  l%16 ^ (row & 15)  of a K row  (conflict-free ds_read_b128 of the A operand)
+  //                           or  l%16 ^ 2*(row & 7) of a V row  (conflict-free ds_read_b64_tr_b16: the 8 rows a
+  // 32-lane group touches then sit in 8 disjoint 8-bank groups although the row pitch is 256 B).
+  static_assert(PPT == 2, "staging below is written for two pieces per wave");
+  const int srow0 = 8 * wave + (lane >> 4), srow1 = srow0 + 4;      // this lane's rows in pieces 2*wave, 2*wave+1
+  const int sslot = lane & 15;
+  const int ksrc0 = (sslot ^ (srow0 & 15)) * 8, ksrc1 = (sslot ^ (srow1 & 15)) * 8;          // element offsets
+  const int vsrc0 = (sslot ^ (2 * (srow0 & 7))) * 8, vsrc1 = (sslot ^ (2 * (srow1 & 7))) * 8;
+  const half_t* kbase = p.k + (size_t)hk * PDH;
+  const half_t* vbase = p.v + (size_t)hk * PDH;
+#define PREFILL_DMA_TILE(kb_, buf_)                                                                                \
   do {                                                                                                            \
-    const int ka_ = (kb_) + skey0 < len_k ? (kb_) + skey0 : (len_k - 1);                                          \
-    const int kb2_ = (kb_) + skey1 < len_k ? (kb_) + skey1 : (len_k - 1);                                         \
+    const int ka_ = (kb_) + srow0 < len_k ? (kb_) + srow0 : (len_k - 1);                                          \
+    const int kb2_ = (kb_) + srow1 < len_k ? (kb_) + srow1 : (len_k - 1);                                         \
     const size_t oa_ = (size_t)(k_begin + ka_), ob_ = (size_t)(k_begin + kb2_);                                   \
-    kreg0 = *reinterpret_cast<const uint4*>(p.k + oa_ * p.k_stride + (size_t)hk * PDH + spiece * 8);               \
-    vreg0 = *reinterpret_cast<const uint4*>(p.v + oa_ * p.v_stride + (size_t)hk * PDH + spiece * 8);               \
-    kreg1 = *reinterpret_cast<const uint4*>(p.k + ob_ * p.k_stride + (size_t)hk * PDH + spiece * 8);               \
-    vreg1 = *reinterpret_cast<const uint4*>(p.v + ob_ * p.v_stride + (size_t)hk * PDH + spiece * 8);               \
-  } while (0)
-#define PREFILL_STORE_TILE(buf_)                                                                                  \
-  do {                                                                                                            \
-    *reinterpret_cast<uint4*>(&ktile[buf_][skey0 * PKROW + ((spiece ^ (skey0 & 15)) << 4)]) = kreg0;               \
-    *reinterpret_cast<uint4*>(&vtile[buf_][skey0 * PVROW + (spiece << 4)]) = vreg0;                                \
-    *reinterpret_cast<uint4*>(&ktile[buf_][skey1 * PKROW + ((spiece ^ (skey1 & 15)) << 4)]) = kreg1;               \
-    *reinterpret_cast<uint4*>(&vtile[buf_][skey1 * PVROW + (spiece << 4)]) = vreg1;                                \
+    uint8_t* kd_ = &ktile[buf_][(8 * wave) * PKROW];                                                              \
+    uint8_t* vd_ = &vtile[buf_][(8 * wave) * PVROW];                                                              \
+    lds_dma16(kbase + oa_ * p.k_stride + ksrc0, kd_);                                                             \
+    lds_dma16(kbase + ob_ * p.k_stride + ksrc1, kd_ + 4 * PKROW);                                                 \
+    lds_dma16(vbase + oa_ * p.v_stride + vsrc0, vd_);                                                             \
+    lds_dma16(vbase + ob_ * p.v_stride + vsrc1, vd_ + 4 * PVROW);                                                 \
   } while (0)
   auto next_tile = [&](int kb) {     // first tile >= kb that is not skipped (or >= k_hi)
     while (kb < k_hi && skipped(kb)) kb += PKT;
     return kb;
   };
 
-  const int tr_off = (4 * l4 + (l15 >> 2)) * PVROW + (l15 & 3) * 8;
+  // V^T operand: row 4*l4 + l15/4 (+16, +32, +48 by immediates), 8 B at logical offset 32c + 8*(l15&3); the physical
+  // 32-B block of logical block c is c ^ (row & 7)
+  const int trow = 4 * l4 + (l15 >> 2);
+  const int tr_base = trow * PVROW + (l15 & 3) * 8;
+  const int tr_swz = (trow & 7) << 5;
   int kb = next_tile(0);
-  if (kb < k_hi) {
-    PREFILL_LOAD_TILE(kb);
-    PREFILL_STORE_TILE(0);
-  }
-  __syncthreads();
+  if (kb < k_hi) PREFILL_DMA_TILE(kb, 0);
+  __syncthreads();     // (carries the vmcnt(0) of the DMA pieces)
   int buf = 0;
   while (kb < k_hi) {
     const int kb_next = next_tile(kb + PKT);
-    // next tile in flight during the MFMAs below (past the end: the last tile again, branch-free, never stored)
-    PREFILL_LOAD_TILE(kb_next < k_hi ? kb_next : kb);
+    // next tile travels global -> LDS (other buffer: every wave left it at the previous barrier) during the MFMAs
+    if (kb_next < k_hi) PREFILL_DMA_TILE(kb_next, buf ^ 1);
     const uint8_t* kt = ktile[buf];
     const uint8_t* vt = vtile[buf];
     // ---- S^T tile: 4 blocks of 16 keys x 2 query blocks ---------------------------------------------------
@@ -169,35 +169,50 @@ void prefill_attn_kernel(PrefillArgs p) {
     if (p.causal) full = full && (kb + PKT - 1 <= q_first + off);
     if (streaming) full = full && ((kb + PKT <= sink) || (q_last + off - kb < local));
     // ---- online softmax (per query row = per lane column), probabilities straight into the B operand ----------
+    // exp2 domain: p = exp2(s*scale2 - m); the maximum is taken on the raw scores (scale2 > 0) and the scaling rides
+    // in the FMA that subtracts it.  Two code paths (workgroup-uniform): tiles that need no mask carry no predicate.
     v8h pb[PQB][2];
 #pragma unroll
     for (int j = 0; j < PQB; ++j) {
-      float tmax = -1e30f;       // scaled (and masked) scores overwrite st[j] in place: no second 16-register copy
+      float tmax = -1e30f;
+      if (full) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x = st[j][u][r] * scale2;
-          if (!full) {
+          for (int r = 0; r < 4; ++r) tmax = __builtin_fmaxf(tmax, st[j][u][r]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
             const int key = kb + 16 * u + 4 * l4 + r;
             bool ok = key < len_k && qrow[j] < len_q;
             if (p.causal) ok = ok && key <= qrow[j] + off;
             if (streaming) ok = ok && (key < sink || (qrow[j] + off) - key < local);
-            x = ok ? x : -1e30f;
+            const float x = ok ? st[j][u][r] : -1e30f;
+            st[j][u][r] = x;
+            tmax = __builtin_fmaxf(tmax, x);
           }
-          st[j][u][r] = x;
-          tmax = __builtin_fmaxf(tmax, x);
-        }
+      }
       tmax = rows4_max(tmax);   // the 4 lanes of a query row
-      const float m_new = __builtin_fmaxf(m_run[j], tmax);
+      const float m_new = __builtin_fmaxf(m_run[j], tmax * scale2);   // tmax = -1e30 (all masked) stays hugely negative
       const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
       float psum = 0.0f;
+      if (full) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float x = st[j][e >> 2][e & 3];
-        const float pe = (full || x > -1e29f) ? __builtin_amdgcn_exp2f(x - m_new) : 0.0f;
-        pb[j][e >> 3][e & 7] = (half_t)pe;   // keys 4*l4+r of blocks (2kk, 2kk+1) -> k-slots of the 32-key step kk
-        psum += pe;
+        for (int e = 0; e < 16; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[j][e >> 2][e & 3], scale2, -m_new));
+          pb[j][e >> 3][e & 7] = (half_t)pe;   // keys 4*l4+r of blocks (2kk, 2kk+1) -> k-slots of the 32-key step kk
+          psum += pe;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float x = st[j][e >> 2][e & 3];
+          const float pe = x > -1e29f ? __builtin_amdgcn_exp2f(__builtin_fmaf(x, scale2, -m_new)) : 0.0f;
+          pb[j][e >> 3][e & 7] = (half_t)pe;
+          psum += pe;
+        }
       }
       l_run[j] = l_run[j] * alpha + psum;
       if (__builtin_amdgcn_ballot_w64(m_new != m_run[j]) != 0) {   // (wave-uniform) rescale only when a row's max moved
@@ -207,22 +222,33 @@ void prefill_attn_kernel(PrefillArgs p) {
       m_run[j] = m_new;
     }
     // ---- O^T += V^T P^T ------------------------------------------------------------------------------------------
+    // The A operands (V^T through transposed reads) are fetched four blocks at a time and pinned in that order: left
+    // alone the compiler reuses ONE operand register quad, i.e. read -> lgkmcnt(0) -> MFMA sixteen times per tile
+    // (PMC: 44 % of the wave cycles parked on counters).
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const uint8_t* src = vt + (32 * kk) * PVROW + tr_off + c * 32;
-        const pv4hp lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-            (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src));
-        const pv4hp hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-            (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src + 16 * PVROW));
-        const v8h a = {(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
-                       (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+      for (int c4 = 0; c4 < 8; c4 += 4) {
+        v8h a4[4];
 #pragma unroll
-        for (int j = 0; j < PQB; ++j) oacc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[j][kk], oacc[j][c], 0, 0, 0);
+        for (int c = 0; c < 4; ++c) {
+          const uint8_t* src = vt + (32 * kk) * PVROW + (tr_base + (((c4 + c) << 5) ^ tr_swz));
+          const pv4hp lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src));
+          const pv4hp hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src + 16 * PVROW));
+          a4[c] = (v8h){(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
+                        (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int j = 0; j < PQB; ++j)
+            oacc[j][c4 + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a4[c], pb[j][kk], oacc[j][c4 + c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    // ---- publish the next tile -----------------------------------------------------------------------------------
-    if (kb_next < k_hi) PREFILL_STORE_TILE(buf ^ 1);
+    // ---- the next tile has landed (vmcnt(0) of this wave's DMA pieces rides in the barrier) ----------------------
     __syncthreads();
     buf ^= 1;
     kb = kb_next;
@@ -245,8 +271,7 @@ void prefill_attn_kernel(PrefillArgs p) {
   }
 }
 
-#undef PREFILL_LOAD_TILE
-#undef PREFILL_STORE_TILE
+#undef PREFILL_DMA_TILE
 
 }  // namespace omni
 

@@ -39,6 +39,13 @@ template <class T>
 __device__ __forceinline__ T gload(const void* p) {
   return *(const __attribute__((address_space(1))) T*)(p);
 }
+// 16 bytes per lane straight from global memory into LDS (gfx950 global_load_lds_dwordx4).  `lds_wave_base` must be
+// wave-uniform: lane l lands at lds_wave_base + 16*l.  Completion is tracked by vmcnt.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 typedef uint32_t v4u_native __attribute__((ext_vector_type(4)));
 template <>
 __device__ __forceinline__ uint4 gload<uint4>(const void* p) {
