@@ -32,6 +32,15 @@ constexpr int PVROW = 256;            // bytes per key row of the V tile (swizzl
 constexpr int PKTILE = PKT * PKROW, PVTILE = PKT * PVROW;
 typedef __fp16 pv4hp __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
+template <int V>
+struct IntTag { static constexpr int value = V; };
+
+__device__ __forceinline__ int xor_nohoist(int a, int uniform_b) {
+  int r;
+  asm volatile("v_xor_b32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(uniform_b));
+  return r;
+}
+
 struct PrefillArgs {
   const half_t* q; const half_t* k; const half_t* v; half_t* out;
   int64_t q_stride, k_stride, v_stride;     // elements between consecutive tokens
@@ -46,10 +55,15 @@ struct PrefillArgs {
 #ifndef OMNI_PREFILL_MIN_BLOCKS
 #define OMNI_PREFILL_MIN_BLOCKS 2
 #endif
-__global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) __attribute__((amdgpu_waves_per_eu(4, 4), amdgpu_num_vgpr(128)))
 void prefill_attn_kernel(PrefillArgs p) {
-  __shared__ __attribute__((aligned(16))) uint8_t ktile[2][PKTILE];
-  __shared__ __attribute__((aligned(16))) uint8_t vtile[2][PVTILE];
+  // four separate LDS objects and a loop body instantiated per buffer parity (static indices): with one array and a
+  // runtime buffer index the compiler cannot tell the DMA target from the tile being read and puts vmcnt(0) -- the
+  // whole flight time of the next tile -- in front of the first LDS read of every iteration
+  __shared__ __attribute__((aligned(16))) uint8_t ktile0[PKTILE];
+  __shared__ __attribute__((aligned(16))) uint8_t ktile1[PKTILE];
+  __shared__ __attribute__((aligned(16))) uint8_t vtile0[PVTILE];
+  __shared__ __attribute__((aligned(16))) uint8_t vtile1[PVTILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   int b = blockIdx.z, h = blockIdx.y, qt = gridDim.x - 1 - blockIdx.x;   // long (late) query tiles are scheduled first
@@ -115,13 +129,13 @@ void prefill_attn_kernel(PrefillArgs p) {
   const int vsrc0 = (sslot ^ (2 * (srow0 & 7))) * 8, vsrc1 = (sslot ^ (2 * (srow1 & 7))) * 8;
   const half_t* kbase = p.k + (size_t)hk * PDH;
   const half_t* vbase = p.v + (size_t)hk * PDH;
-#define PREFILL_DMA_TILE(kb_, buf_)                                                                                \
+#define PREFILL_DMA_TILE(kb_, kt_, vt_)                                                                               \
   do {                                                                                                            \
     const int ka_ = (kb_) + srow0 < len_k ? (kb_) + srow0 : (len_k - 1);                                          \
     const int kb2_ = (kb_) + srow1 < len_k ? (kb_) + srow1 : (len_k - 1);                                         \
     const size_t oa_ = (size_t)(k_begin + ka_), ob_ = (size_t)(k_begin + kb2_);                                   \
-    uint8_t* kd_ = &ktile[buf_][(8 * wave) * PKROW];                                                              \
-    uint8_t* vd_ = &vtile[buf_][(8 * wave) * PVROW];                                                              \
+    uint8_t* kd_ = (kt_) + (8 * wave) * PKROW;                                                                    \
+    uint8_t* vd_ = (vt_) + (8 * wave) * PVROW;                                                                    \
     lds_dma16(kbase + oa_ * p.k_stride + ksrc0, kd_);                                                             \
     lds_dma16(kbase + ob_ * p.k_stride + ksrc1, kd_ + 4 * PKROW);                                                 \
     lds_dma16(vbase + oa_ * p.v_stride + vsrc0, vd_);                                                             \
@@ -135,18 +149,15 @@ void prefill_attn_kernel(PrefillArgs p) {
   // V^T operand: row 4*l4 + l15/4 (+16, +32, +48 by immediates), 8 B at logical offset 32c + 8*(l15&3); the physical
   // 32-B block of logical block c is c ^ (row & 7)
   const int trow = 4 * l4 + (l15 >> 2);
-  const int tr_base = trow * PVROW + (l15 & 3) * 8;
-  const int tr_swz = (trow & 7) << 5;
+  const int tr_a0 = (trow * PVROW + (l15 & 3) * 8) | ((trow & 7) << 5);   // address of logical block c: tr_a0 ^ (c << 5)
   int kb = next_tile(0);
-  if (kb < k_hi) PREFILL_DMA_TILE(kb, 0);
+  if (kb < k_hi) PREFILL_DMA_TILE(kb, ktile0, vtile0);
   __syncthreads();     // (carries the vmcnt(0) of the DMA pieces)
-  int buf = 0;
-  while (kb < k_hi) {
+  auto tile_step = [&](auto parity) {
+    constexpr int B = decltype(parity)::value;
     const int kb_next = next_tile(kb + PKT);
-    // next tile travels global -> LDS (other buffer: every wave left it at the previous barrier) during the MFMAs
-    if (kb_next < k_hi) PREFILL_DMA_TILE(kb_next, buf ^ 1);
-    const uint8_t* kt = ktile[buf];
-    const uint8_t* vt = vtile[buf];
+    const uint8_t* kt = B ? ktile1 : ktile0;
+    const uint8_t* vt = B ? vtile1 : vtile0;
     // ---- S^T tile: 4 blocks of 16 keys x 2 query blocks ---------------------------------------------------
     v4f st[PQB][4];
 #pragma unroll
@@ -164,6 +175,13 @@ void prefill_attn_kernel(PrefillArgs p) {
       }
     }
     // st[j][u][r] = K[kb + 16u + 4*l4 + r] . Q[qrow[j]]
+    // The next tile starts its trip global -> LDS (other buffer: every wave left it at the previous barrier) only
+    // now: while a DMA is in flight hipcc waits lgkmcnt(0) in front of every consumer of a ds_read (it books the DMA
+    // as a second kind of LDS event), which would serialise the 16 operand reads above against their MFMAs; the
+    // softmax and the P.V phase below (whose reads are batched by hand) cover the flight time.
+    __builtin_amdgcn_sched_barrier(0);
+    if (kb_next < k_hi) PREFILL_DMA_TILE(kb_next, B ? ktile0 : ktile1, B ? vtile0 : vtile1);
+    __builtin_amdgcn_sched_barrier(0);
     // does any (row, key) pair of this workgroup's tile need the mask?  (workgroup-uniform)
     bool full = (kb + PKT <= len_k) && (q_first + PQROWS <= len_q);
     if (p.causal) full = full && (kb + PKT - 1 <= q_first + off);
@@ -185,10 +203,11 @@ void prefill_attn_kernel(PrefillArgs p) {
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int key = kb + 16 * u + 4 * l4 + r;
-            bool ok = key < len_k && qrow[j] < len_q;
-            if (p.causal) ok = ok && key <= qrow[j] + off;
-            if (streaming) ok = ok && (key < sink || (qrow[j] + off) - key < local);
+            const int key = kb + 16 * u + 4 * l4 + r;     // branch-free predicate (short-circuit && became branches)
+            const int qpos = qrow[j] + off;
+            int ok = (int)(key < len_k) & (int)(qrow[j] < len_q);
+            ok &= (int)(!p.causal) | (int)(key <= qpos);
+            ok &= (int)(!streaming) | (int)(key < sink) | (int)(qpos - key < local);
             const float x = ok ? st[j][u][r] : -1e30f;
             st[j][u][r] = x;
             tmax = __builtin_fmaxf(tmax, x);
@@ -222,36 +241,46 @@ void prefill_attn_kernel(PrefillArgs p) {
       m_run[j] = m_new;
     }
     // ---- O^T += V^T P^T ------------------------------------------------------------------------------------------
-    // The A operands (V^T through transposed reads) are fetched four blocks at a time and pinned in that order: left
-    // alone the compiler reuses ONE operand register quad, i.e. read -> lgkmcnt(0) -> MFMA sixteen times per tile
-    // (PMC: 44 % of the wave cycles parked on counters).
+    // 16 steps (kk, c), each = two transposed reads (the A operand V^T) + one MFMA.  The schedule is pinned with
+    // sched_group_barrier: the reads run three steps ahead of the MFMAs (three operand quads in flight, counted
+    // lgkmcnt waits).  Left alone the compiler reuses ONE operand quad: read -> lgkmcnt(0) -> MFMA sixteen times per
+    // tile (PMC: 44 % of the wave cycles parked on counters).
+    {
+      v8h a16[16];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int c4 = 0; c4 < 8; c4 += 4) {
-        v8h a4[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const uint8_t* src = vt + (32 * kk) * PVROW + (tr_base + (((c4 + c) << 5) ^ tr_swz));
-          const pv4hp lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-              (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src));
-          const pv4hp hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-              (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src + 16 * PVROW));
-          a4[c] = (v8h){(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
-                        (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int j = 0; j < PQB; ++j)
-            oacc[j][c4 + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a4[c], pb[j][kk], oacc[j][c4 + c], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 16; ++i) {
+        const int kk = i >> 3, c = i & 7;
+        // the xor is recomputed per step (volatile asm): hoisted out of the tile loop the eight addresses cost eight
+        // VGPRs, which pushed the kernel over the 128 that four waves per SIMD allow
+        const uint8_t* src = vt + (32 * kk) * PVROW + (tr_a0 ^ (c << 5));
+        const pv4hp lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src));
+        const pv4hp hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src + 16 * PVROW));
+        a16[i] = (v8h){(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
+                       (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
       }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int j = 0; j < PQB; ++j)
+          oacc[j][i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[i], pb[j][i >> 3], oacc[j][i & 7], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);          // DS reads of steps 0..2
+#pragma unroll
+      for (int i = 0; i < 13; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PQB, 0);      // MFMA of step i
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // DS reads of step i + 3
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * PQB, 0);
+    }
     // ---- the next tile has landed (vmcnt(0) of this wave's DMA pieces rides in the barrier) ----------------------
     __syncthreads();
-    buf ^= 1;
     kb = kb_next;
+  };
+  while (kb < k_hi) {
+    tile_step(IntTag<0>{});
+    if (kb >= k_hi) break;
+    tile_step(IntTag<1>{});
   }
   // ---- finish: row sum over the 4 lanes of a query row, normalise, store ------------------------------------
 #pragma unroll

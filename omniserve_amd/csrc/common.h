@@ -46,6 +46,21 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base)
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same DMA hidden from the compiler (inline asm): hipcc counts a pending global_load_lds as an LDS event of a
+// second kind and then waits lgkmcnt(0) in front of EVERY consumer of a ds_read while one is in flight (read -> full
+// wait -> MFMA, no LDS pipelining at all).  The caller owns the completion: lds_dma_wait_all() before the barrier that
+// publishes the tile.  M0 is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void lds_dma16_untracked(const void* gsrc, void* lds_wave_base) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)lds_wave_base);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 typedef uint32_t v4u_native __attribute__((ext_vector_type(4)));
 template <>
 __device__ __forceinline__ uint4 gload<uint4>(const void* p) {
