@@ -23,8 +23,11 @@ namespace omni {
 
 constexpr int PDH = 128;
 constexpr int PKT = 64;               // keys per tile
-constexpr int PQB = 1;                // 16-row query blocks per wave
-constexpr int PWAVES = 8;             // 8 waves x 16 rows: ~120 VGPRs per wave, 4 waves per SIMD hide the softmax VALU work
+#ifndef OMNI_PREFILL_PQB
+#define OMNI_PREFILL_PQB 1
+#endif
+constexpr int PQB = OMNI_PREFILL_PQB;   // 16-row query blocks per wave
+constexpr int PWAVES = 8 / PQB;         // 8 waves x 16 rows: ~120 VGPRs per wave, 4 waves per SIMD hide the softmax VALU work
 constexpr int PPT = (PKT * 16) / (64 * PWAVES);   // 1-KiB LDS-DMA pieces of a K (or V) tile per wave
 constexpr int PQROWS = 16 * PQB * PWAVES;   // 128 query rows per workgroup
 constexpr int PKROW = 256;            // bytes per key row of the K tile (swizzled slots)
@@ -55,7 +58,7 @@ struct PrefillArgs {
 #ifndef OMNI_PREFILL_MIN_BLOCKS
 #define OMNI_PREFILL_MIN_BLOCKS 2
 #endif
-__global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) __attribute__((amdgpu_waves_per_eu(4, 4), amdgpu_num_vgpr(128)))
+__global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) __attribute__((amdgpu_waves_per_eu(4 / PQB, 4 / PQB)))
 void prefill_attn_kernel(PrefillArgs p) {
   // four separate LDS objects and a loop body instantiated per buffer parity (static indices): with one array and a
   // runtime buffer index the compiler cannot tell the DMA target from the tile being read and puts vmcnt(0) -- the
@@ -122,24 +125,19 @@ void prefill_attn_kernel(PrefillArgs p) {
   // and fetches the logical slot  l%16 ^ (row & 15)  of a K row  (conflict-free ds_read_b128 of the A operand)
   //                           or  l%16 ^ 2*(row & 7) of a V row  (conflict-free ds_read_b64_tr_b16: the 8 rows a
   // 32-lane group touches then sit in 8 disjoint 8-bank groups although the row pitch is 256 B).
-  static_assert(PPT == 2, "staging below is written for two pieces per wave");
-  const int srow0 = 8 * wave + (lane >> 4), srow1 = srow0 + 4;      // this lane's rows in pieces 2*wave, 2*wave+1
   const int sslot = lane & 15;
-  const int ksrc0 = (sslot ^ (srow0 & 15)) * 8, ksrc1 = (sslot ^ (srow1 & 15)) * 8;          // element offsets
-  const int vsrc0 = (sslot ^ (2 * (srow0 & 7))) * 8, vsrc1 = (sslot ^ (2 * (srow1 & 7))) * 8;
   const half_t* kbase = p.k + (size_t)hk * PDH;
   const half_t* vbase = p.v + (size_t)hk * PDH;
-#define PREFILL_DMA_TILE(kb_, kt_, vt_)                                                                               \
+#define PREFILL_DMA_TILE(kb_, kt_, vt_)                                                                           \
   do {                                                                                                            \
-    const int ka_ = (kb_) + srow0 < len_k ? (kb_) + srow0 : (len_k - 1);                                          \
-    const int kb2_ = (kb_) + srow1 < len_k ? (kb_) + srow1 : (len_k - 1);                                         \
-    const size_t oa_ = (size_t)(k_begin + ka_), ob_ = (size_t)(k_begin + kb2_);                                   \
-    uint8_t* kd_ = (kt_) + (8 * wave) * PKROW;                                                                    \
-    uint8_t* vd_ = (vt_) + (8 * wave) * PVROW;                                                                    \
-    lds_dma16(kbase + oa_ * p.k_stride + ksrc0, kd_);                                                             \
-    lds_dma16(kbase + ob_ * p.k_stride + ksrc1, kd_ + 4 * PKROW);                                                 \
-    lds_dma16(vbase + oa_ * p.v_stride + vsrc0, vd_);                                                             \
-    lds_dma16(vbase + ob_ * p.v_stride + vsrc1, vd_ + 4 * PVROW);                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < PPT; ++i_) {                                                          \
+      const int row_ = 4 * PPT * wave + 4 * i_ + (lane >> 4);                                                     \
+      const int kr_ = (kb_) + row_ < len_k ? (kb_) + row_ : (len_k - 1);                                          \
+      const size_t o_ = (size_t)(k_begin + kr_);                                                                  \
+      lds_dma16(kbase + o_ * p.k_stride + ((sslot ^ (row_ & 15)) * 8), (kt_) + (4 * PPT * wave + 4 * i_) * PKROW); \
+      lds_dma16(vbase + o_ * p.v_stride + ((sslot ^ (2 * (row_ & 7))) * 8),                                       \
+                (vt_) + (4 * PPT * wave + 4 * i_) * PVROW);                                                       \
+    }                                                                                                             \
   } while (0)
   auto next_tile = [&](int kb) {     // first tile >= kb that is not skipped (or >= k_hi)
     while (kb < k_hi && skipped(kb)) kb += PKT;
@@ -159,6 +157,8 @@ void prefill_attn_kernel(PrefillArgs p) {
     const uint8_t* kt = B ? ktile1 : ktile0;
     const uint8_t* vt = B ? vtile1 : vtile0;
     // ---- S^T tile: 4 blocks of 16 keys x 2 query blocks ---------------------------------------------------
+    // (MFMA phases run at raised priority: a wave that has matrix work ready goes ahead of the waves in their softmax)
+    __builtin_amdgcn_s_setprio(1);
     v4f st[PQB][4];
 #pragma unroll
     for (int j = 0; j < PQB; ++j)
@@ -180,6 +180,7 @@ void prefill_attn_kernel(PrefillArgs p) {
     // as a second kind of LDS event), which would serialise the 16 operand reads above against their MFMAs; the
     // softmax and the P.V phase below (whose reads are batched by hand) cover the flight time.
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
     if (kb_next < k_hi) PREFILL_DMA_TILE(kb_next, B ? ktile0 : ktile1, B ? vtile0 : vtile1);
     __builtin_amdgcn_sched_barrier(0);
     // does any (row, key) pair of this workgroup's tile need the mask?  (workgroup-uniform)
@@ -245,6 +246,7 @@ void prefill_attn_kernel(PrefillArgs p) {
     // sched_group_barrier: the reads run three steps ahead of the MFMAs (three operand quads in flight, counted
     // lgkmcnt waits).  Left alone the compiler reuses ONE operand quad: read -> lgkmcnt(0) -> MFMA sixteen times per
     // tile (PMC: 44 % of the wave cycles parked on counters).
+    __builtin_amdgcn_s_setprio(1);
     {
       v8h a16[16];
 #pragma unroll
@@ -273,6 +275,7 @@ void prefill_attn_kernel(PrefillArgs p) {
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 3 * PQB, 0);
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- the next tile has landed (vmcnt(0) of this wave's DMA pieces rides in the barrier) ----------------------
     __syncthreads();
     kb = kb_next;
