@@ -193,13 +193,23 @@ void prefill_attn_kernel(PrefillArgs p) {
     v8h pb[PQB][2];
 #pragma unroll
     for (int j = 0; j < PQB; ++j) {
-      float tmax = -1e30f;
-      if (full) {
+      float tmax = -1e30f, m_new, alpha, psum = 0.0f;
+      if (full) {     // one self-contained path per case: no register copies where the two would merge
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) tmax = __builtin_fmaxf(tmax, st[j][u][r]);
+        tmax = rows4_max(tmax);   // the 4 lanes of a query row
+        m_new = __builtin_fmaxf(m_run[j], tmax * scale2);
+        alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[j][e >> 2][e & 3], scale2, -m_new));
+          pb[j][e >> 3][e & 7] = (half_t)pe;   // keys 4*l4+r of blocks (2kk, 2kk+1) -> k-slots of the 32-key step kk
+          psum += pe;
+        }
       } else {
+        bool okv[16];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -209,27 +219,15 @@ void prefill_attn_kernel(PrefillArgs p) {
             int ok = (int)(key < len_k) & (int)(qrow[j] < len_q);
             ok &= (int)(!p.causal) | (int)(key <= qpos);
             ok &= (int)(!streaming) | (int)(key < sink) | (int)(qpos - key < local);
-            const float x = ok ? st[j][u][r] : -1e30f;
-            st[j][u][r] = x;
-            tmax = __builtin_fmaxf(tmax, x);
+            okv[4 * u + r] = ok != 0;
+            tmax = __builtin_fmaxf(tmax, ok ? st[j][u][r] : -1e30f);
           }
-      }
-      tmax = rows4_max(tmax);   // the 4 lanes of a query row
-      const float m_new = __builtin_fmaxf(m_run[j], tmax * scale2);   // tmax = -1e30 (all masked) stays hugely negative
-      const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
-      float psum = 0.0f;
-      if (full) {
+        tmax = rows4_max(tmax);
+        m_new = __builtin_fmaxf(m_run[j], tmax * scale2);   // tmax = -1e30 (all masked) stays hugely negative
+        alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[j][e >> 2][e & 3], scale2, -m_new));
-          pb[j][e >> 3][e & 7] = (half_t)pe;   // keys 4*l4+r of blocks (2kk, 2kk+1) -> k-slots of the 32-key step kk
-          psum += pe;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float x = st[j][e >> 2][e & 3];
-          const float pe = x > -1e29f ? __builtin_amdgcn_exp2f(__builtin_fmaf(x, scale2, -m_new)) : 0.0f;
+          const float pe = okv[e] ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[j][e >> 2][e & 3], scale2, -m_new)) : 0.0f;
           pb[j][e >> 3][e & 7] = (half_t)pe;
           psum += pe;
         }
