@@ -145,6 +145,13 @@ int omni_kv4_decode_attention_partial(const void* q_f16, const void* k_f16, cons
 int omni_attn_merge_quant_fuse_sum(void* out_i8, const void* part_ml_f32, const void* part_o_f32, int nsplit,
                                    void* sum_f16, void* scale_f16, int batch, int num_heads, void* stream);
 
+/* Greedy-sampling helper of the decode runner (not a reference kernel: the reference's sampler is torch code,
+ * omniserve/modeling/layers/sampler.py): out_i64[r] = index of the first maximum of logits fp16 [rows, cols]
+ * (torch.argmax semantics).  workspace >= omni_argmax_workspace_bytes(rows). */
+size_t omni_argmax_workspace_bytes(int rows);
+int omni_argmax_f16(void* out_i64, const void* logits_f16, int64_t row_stride, int rows, int cols, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* omni_silu_and_mul followed by omni_quant_fuse_sum without materialising the fp16 product
  * (activation.py:54-64 calls them back to back).  in fp16 [tokens, 2d] -> out int8 [tokens, d]. */
 int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f16, void* scale_f16,

@@ -1,5 +1,7 @@
 """Opt-in fused entry points (NOT in the reference's omniserve_backend).
 Each is bit-identical to the pair of reference calls it replaces."""
+import torch
+
 from .. import _lib
 
 
@@ -77,3 +79,18 @@ def decode_attention_quant_fuse_sum(out_i8, q, k, v, kv_pointers, lengths, token
     rc = _lib.lib().omni_attn_merge_quant_fuse_sum(out_i8.data_ptr(), ws.data_ptr(), ws.data_ptr() + ml_bytes, ns.value,
                                                    input_sum.data_ptr(), scale.data_ptr(), B, Hq, _lib.current_stream())
     _lib.check(rc, "fused_ext.decode_attention_quant_fuse_sum (merge+quant)")
+
+
+def argmax(out, logits):
+    """out int64 [rows] = torch.argmax(logits fp16 [rows, cols], dim=-1) (first maximum); greedy-sampling helper of the
+    decode runner -- the reference's sampler is torch code, this is not one of its kernels."""
+    _lib.require_cuda(out, logits)
+    if logits.dtype != torch.float16 or logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError("argmax: logits must be fp16 [rows, cols] with contiguous rows")
+    if out.dtype != torch.int64 or out.numel() != logits.shape[0] or not out.is_contiguous():
+        raise RuntimeError("argmax: out must be a contiguous int64 [rows] tensor")
+    need = _lib.lib().omni_argmax_workspace_bytes(logits.shape[0])
+    ws = _lib.workspace(need, logits.device, "argmax")
+    rc = _lib.lib().omni_argmax_f16(out.data_ptr(), logits.data_ptr(), logits.stride(0), logits.shape[0],
+                                    logits.shape[1], ws.data_ptr(), ws.numel(), _lib.current_stream())
+    _lib.check(rc, "fused_ext.argmax")

@@ -294,7 +294,10 @@ class DecodeRunner:
                     self.x.add_(self.proj_buf)
         layernorm_ops.rms_norm(self.normed, self.x, self.final_norm, c.eps, False)
         logits = torch.matmul(self.normed, self.lm_head.t())
-        self.tokens.copy_(torch.argmax(logits, dim=-1))
+        if self.fused:
+            fused_ext.argmax(self.tokens, logits)      # same result as torch.argmax, 6 us instead of 47
+        else:
+            self.tokens.copy_(torch.argmax(logits, dim=-1))
 
     # ---- prefill (context stage) ---------------------------------------------------------------------------
     def prefill(self, prompt_len=None):

@@ -158,3 +158,29 @@ def test_deferred_splitk_epilogue_matches_gemm_then_add_norm():
     qo, so, smo = oe.rms_norm_general(xs, g, 1e-5, True)
     assert np.array_equal(q2.cpu().numpy(), qo)
     assert_f16_equal(sm2, smo, "sum")
+
+
+def test_argmax_matches_torch():
+    """Greedy-sampling helper (fused_ext.argmax): first maximum, -0 == +0, NaN wins, ragged and unaligned shapes."""
+    from omniserve_amd.backend import fused_ext
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for rows, cols in ((16, 128256), (3, 1000), (1, 7), (5, 32000)):
+        x = torch.randn((rows, cols), generator=g).half()
+        x[0, cols // 2] = 9.0
+        x[0, cols - 1] = 9.0                      # tie: the first index wins
+        if rows > 1:
+            x[1].zero_(); x[1, 3] = -0.0          # all equal (+0 / -0): index 0
+        if rows > 2:
+            x[2, min(500, cols - 1)] = float("nan")
+        xd = x.to(dev())
+        out = torch.empty((rows,), dtype=torch.int64, device=dev())
+        fused_ext.argmax(out, xd)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), torch.argmax(x.float(), dim=-1)), (rows, cols)
+    # strided rows (row stride not a multiple of 8 -> scalar path)
+    big = torch.randn((4, 1003), generator=g).half().to(dev())
+    view = big[:, :999]
+    out = torch.empty((4,), dtype=torch.int64, device=dev())
+    fused_ext.argmax(out, view)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), torch.argmax(view.float().cpu(), dim=-1))
