@@ -127,7 +127,10 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
     return make_uint4((uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
   };
   constexpr int WL = (MODE == MODE_W8) ? 4 : 2;  // weight loads per lane per k-step
-  uint4 wq[STEPS][WL];
+  // weight prefetch ring: a whole chunk (4 steps) ahead for the int4 modes (32 VGPRs); W8A8 rows are twice the bytes
+  // (64 VGPRs for a chunk pushed the kernel over 256 VGPRs: 100 B/lane of scratch), so it runs two steps ahead
+  constexpr int WRING = MODE == MODE_W8 ? 2 : STEPS;
+  uint4 wq[WRING][WL];
 
   // ---- activation staging --------------------------------------------------------------
   // LDS image of a chunk: [k-step s][16-B slot q of the step's B operand][row m][16 B] ("plane" layout):
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
 
   // ---- prologue --------------------------------------------------------------------------
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
+  for (int s = 0; s < WRING; ++s) {
     const int ks = s < nsteps ? s : 0;      // (short slices) re-read step 0, never consumed
 #pragma unroll
     for (int j = 0; j < WL; ++j) wq[s][j] = load_w(k_begin + ks * KSTEP, j);
@@ -259,10 +262,11 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
         if constexpr (MODE == MODE_W8) {
 #pragma unroll
           for (int rb = 0; rb < 4; ++rb)
-            wa[rb] = (v4i){(int)wq[s][rb].x, (int)wq[s][rb].y, (int)wq[s][rb].z, (int)wq[s][rb].w};
+            wa[rb] = (v4i){(int)wq[s % WRING][rb].x, (int)wq[s % WRING][rb].y, (int)wq[s % WRING][rb].z,
+                           (int)wq[s % WRING][rb].w};
         } else {
           // dwords of a chunk: x=(k5=0,n2=0) y=(k5=0,n2=1) z=(k5=1,n2=0) w=(k5=1,n2=1)
-          const uint4 t0 = wq[s][0], t1 = wq[s][1];
+          const uint4 t0 = wq[s % WRING][0], t1 = wq[s % WRING][1];
           const uint32_t d[2][4] = {{t0.x, t0.z, t1.x, t1.z}, {t0.y, t0.w, t1.y, t1.w}};
 #pragma unroll
           for (int a = 0; a < 2; ++a)
@@ -281,13 +285,13 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
               wa[a * 2 + b] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
             }
         }
-        // refill this step's weight registers for the next chunk
-        if (STEADY || (has_next && (c + 1) * STEPS + s < nsteps)) {
+        // refill this step's weight registers with the step WRING ahead (the next chunk's for the int4 modes)
+        if (STEADY || (c * STEPS + s + WRING < nsteps)) {
 #pragma unroll
-          for (int j = 0; j < WL; ++j) wq[s][j] = load_w(kc + KCHUNK + s * KSTEP, j);
-          // keep the refill HERE (a whole chunk of MFMAs ahead of its use): the scheduler otherwise sinks all
-          // four steps' loads to the end of the chunk, right in front of the wait that needs them
-          if constexpr (STEADY && MODE != MODE_W8) __builtin_amdgcn_sched_barrier(0x78F);   // everything but VMEM may still move across
+          for (int j = 0; j < WL; ++j) wq[s % WRING][j] = load_w(kc + (s + WRING) * KSTEP, j);
+          // keep the refill HERE (WRING steps of MFMAs ahead of its use): the scheduler otherwise sinks all
+          // the steps' loads to the end of the chunk, right in front of the wait that needs them
+          if constexpr (STEADY) __builtin_amdgcn_sched_barrier(0x78F);   // everything but VMEM may still move across
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
