@@ -73,6 +73,12 @@ __device__ __forceinline__ half_t epilogue(int acc, float sw, float sa, float sz
 #ifndef OMNI_GEMM_MIN_BLOCKS
 #define OMNI_GEMM_MIN_BLOCKS 2
 #endif
+#ifndef OMNI_GEMM_RING_OTHER
+#define OMNI_GEMM_RING_OTHER 2
+#endif
+#ifndef OMNI_GEMM_GRP_STEADY
+#define OMNI_GEMM_GRP_STEADY 1
+#endif
 template <int MB, int MODE, int WAVES, bool TO_SLAB, bool NT>
 __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   constexpr int WL = (MODE == MODE_W8) ? 4 : 2;  // weight loads per lane per k-step
   // weight prefetch ring: a whole chunk (4 steps) ahead for the int4 modes (32 VGPRs); W8A8 rows are twice the bytes
   // (64 VGPRs for a chunk pushed the kernel over 256 VGPRs: 100 B/lane of scratch), so it runs two steps ahead
-  constexpr int WRING = MODE == MODE_W8 ? 2 : STEPS;
+  constexpr int WRING = MODE == MODE_CHN ? STEPS : OMNI_GEMM_RING_OTHER;
   uint4 wq[WRING][WL];
 
   // ---- activation staging --------------------------------------------------------------
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   const int nfull = nsteps / STEPS;     // whole chunks
   int c = 0;
   // (per-group mode keeps the generic loop: its dequant temporaries + the pinned refills exceed 256 VGPRs and spill)
-  if constexpr (MODE != MODE_GRP) {
+  if constexpr (MODE != MODE_GRP || OMNI_GEMM_GRP_STEADY) {
     if (m0 + MT <= p.M && MT * KCHUNK / 16 == A_LOADS * NTHREADS)   // all activation rows of the tile exist
       for (; c + 1 < nfull; ++c) run_chunk(c, BoolTag<true>{});
   }
