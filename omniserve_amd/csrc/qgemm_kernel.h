@@ -76,6 +76,12 @@ __device__ __forceinline__ half_t epilogue(int acc, float sw, float sa, float sz
 #ifndef OMNI_GEMM_RING_OTHER
 #define OMNI_GEMM_RING_OTHER 2
 #endif
+#ifndef OMNI_GEMM_RING_CHN
+#define OMNI_GEMM_RING_CHN 4     // a whole chunk ahead; 2 measured 4-6 % slower for the per-channel kernel
+#endif
+#ifndef OMNI_GEMM_PIPE_B
+#define OMNI_GEMM_PIPE_B 1
+#endif
 #ifndef OMNI_GEMM_GRP_STEADY
 #define OMNI_GEMM_GRP_STEADY 1
 #endif
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   constexpr int WL = (MODE == MODE_W8) ? 4 : 2;  // weight loads per lane per k-step
   // weight prefetch ring: a whole chunk (4 steps) ahead for the int4 modes (32 VGPRs); W8A8 rows are twice the bytes
   // (64 VGPRs for a chunk pushed the kernel over 256 VGPRs: 100 B/lane of scratch), so it runs two steps ahead
-  constexpr int WRING = MODE == MODE_CHN ? STEPS : OMNI_GEMM_RING_OTHER;
+  constexpr int WRING = MODE == MODE_CHN ? OMNI_GEMM_RING_CHN : OMNI_GEMM_RING_OTHER;
   uint4 wq[WRING][WL];
 
   // ---- activation staging --------------------------------------------------------------
@@ -299,14 +305,30 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
           // the steps' loads to the end of the chunk, right in front of the wait that needs them
           if constexpr (STEADY) __builtin_amdgcn_sched_barrier(0x78F);   // everything but VMEM may still move across
         }
+        // B operands (activation rows) from LDS, pinned three row blocks ahead of the MFMAs that use them: left alone
+        // the compiler issues two reads and waits for them right away (read, read, lgkmcnt, 8 MFMAs, ...), i.e. one
+        // exposed LDS latency per 8 MFMAs -- the MFMA pipe sat at 40-50 % busy (PMC) on exactly that
+        v4i bf[MB];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const v4i bf = *reinterpret_cast<const v4i*>(abuf + ((s * 4 + (lane >> 4)) * MT + mb * 16 + (lane & 15)) * 16);
+        for (int mb = 0; mb < MB; ++mb)
+          bf[mb] = *reinterpret_cast<const v4i*>(abuf + ((s * 4 + (lane >> 4)) * MT + mb * 16 + (lane & 15)) * 16);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int ab = 0; ab < 4; ++ab)
-            acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf, acc[mb][ab], 0, 0, 0);
-        }
+            acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf[mb], acc[mb][ab], 0, 0, 0);
       }
+    }
+    if constexpr (STEADY && OMNI_GEMM_PIPE_B && MODE == MODE_CHN) {   // one read pipeline over the whole chunk (it also spans the step seams).  Per-channel mode only: per-group has no registers left
+    // for it and W8A8 measured 3 % slower with it.  Gain: +2 % at 4096^3, +4 % on the K = 14336 shape, -1 % on gate_up
+      constexpr int PRE = MB < 3 ? MB : 3;
+      __builtin_amdgcn_sched_group_barrier(0x100, PRE, 0);
+#pragma unroll
+      for (int i = 0; i < STEPS * MB - PRE; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * PRE, 0);
     }
 #ifdef OMNI_DEBUG_CLOCKS
     const unsigned long long dbg_t1 = wall_clock64();
