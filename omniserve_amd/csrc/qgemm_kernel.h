@@ -82,6 +82,9 @@ __device__ __forceinline__ half_t epilogue(int acc, float sw, float sa, float sz
 #ifndef OMNI_GEMM_PIPE_B
 #define OMNI_GEMM_PIPE_B 1
 #endif
+#ifndef OMNI_GEMM_STORE_A_STEP
+#define OMNI_GEMM_STORE_A_STEP 4     // 0..3: publish after that step; 4: at the chunk end (3 measured equal, 1-2 twice slower: the loads are not back yet)
+#endif
 #ifndef OMNI_GEMM_GRP_STEADY
 #define OMNI_GEMM_GRP_STEADY 1
 #endif
@@ -285,8 +288,13 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
               uint32_t u[4];
+#if defined(OMNI_GEMM_ABLATE) && (OMNI_GEMM_ABLATE & 1)   // timing experiment: no unpack (wrong results)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) u[q] = d[b][q];
+#else
 #pragma unroll
               for (int q = 0; q < 4; ++q) u[q] = (d[b][q] >> (4 * a)) & 0x0F0F0F0Fu;
+#endif
               if constexpr (MODE == MODE_GRP) {
                 const int h = s >> 1;  // group inside the chunk
                 const uint32_t sc = (gs[h] >> (8 * (a * 2 + b))) & 0xFFu;
@@ -311,12 +319,23 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
         v4i bf[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
+#if defined(OMNI_GEMM_ABLATE) && (OMNI_GEMM_ABLATE & 2)   // timing experiment: one LDS read per step (wrong results)
+          bf[mb] = *reinterpret_cast<const v4i*>(abuf + ((s * 4 + (lane >> 4)) * MT + (lane & 15)) * 16);
+#else
           bf[mb] = *reinterpret_cast<const v4i*>(abuf + ((s * 4 + (lane >> 4)) * MT + mb * 16 + (lane & 15)) * 16);
+#endif
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int ab = 0; ab < 4; ++ab)
             acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf[mb], acc[mb][ab], 0, 0, 0);
+        // publish the next activation tile from INSIDE the chunk (its global loads were issued at the chunk's start,
+        // OMNI_GEMM_STORE_A_STEP steps of MFMAs ago): at the chunk's end the ds_write latency, the barrier and the first
+        // ds_read latency of the next chunk queued up back to back with no MFMA to cover them (PMC: 29 % of the wave
+        // cycles parked on counters / barriers)
+        if constexpr (STEADY) {
+          if (s == OMNI_GEMM_STORE_A_STEP) store_a((c + 1) & 1);
+        }
       }
     }
     if constexpr (STEADY && OMNI_GEMM_PIPE_B && MODE == MODE_CHN) {   // one read pipeline over the whole chunk (it also spans the step seams).  Per-channel mode only: per-group has no registers left
@@ -335,7 +354,7 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (debug build) isolate the wait for the staged loads
     dbg_vmwait += wall_clock64() - dbg_t1;
 #endif
-    if (has_next) store_a((c + 1) & 1);
+    if (has_next && !(STEADY && OMNI_GEMM_STORE_A_STEP < STEPS)) store_a((c + 1) & 1);
     if constexpr (MODE == MODE_GRP) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) { gs[h] = gsn[h]; gz[h] = gzn[h]; }
