@@ -5,13 +5,14 @@
 // heads) and compute_padding_offsets (reference: kernels/csrc/fused_attention/...).
 //
 // Page (per layer, K or V):  int4 data [H_kv][tpb][Dh/2] | fp16 scale [H_kv][tpb] | fp16 zero [H_kv][tpb]
+// (per-tensor KV8 pages: int8 data [H][tpb][Dh] and the same 4 B/token-head tail).
 // A token row of one head is Dh/2 = 64 contiguous bytes, so 16 consecutive tokens of a head are
 // 1 KiB contiguous: one 16-B load per lane per wave.  Design (not a port of the TRT-LLM MMHA):
 //   * one workgroup per (kv head, sequence, KV split) serves ALL q heads of the GQA group, so the
 //     packed K/V bytes are fetched and dequantised once instead of once per q head;
-//   * 4 lanes own a token (32 dims each), dot products reduce with two xor shuffles;
-//   * scores live in LDS (two-pass softmax inside the split), partial (max, sum, O) per split are
-//     merged by a second tiny kernel (flash-decoding), so B*H_kv*S workgroups fill all 256 CUs;
+//   * flash-decoding inside the workgroup on the matrix cores (see the decode kernel below); partial
+//     (max, sum, O) per split are merged by a second tiny kernel (or by the quantiser that follows), so
+//     B*H_kv*S workgroups fill all 256 CUs;
 //   * dequant is the reference's fp16 fma(u4, scale, -scale*zero); dot products and P.V
 //     accumulate in fp32.
 #include "common.h"
@@ -271,10 +272,6 @@ __device__ __forceinline__ void kv8_dequant16(const uint4 raw, float s, v2h out[
   }
 }
 
-__device__ __forceinline__ float dot2_acc(v2h a, v2h b, float acc) {
-  return __builtin_amdgcn_fdot2(a, b, acc, false);
-}
-
 struct DecodeArgs {
   half_t* out;             // [B,Hq,128]
   const half_t* q;         // row stride q_stride
@@ -299,8 +296,6 @@ struct DecodeArgs {
 constexpr int DEC_MAX_SPLITS = 1024;   // KV splits per (sequence, head group): contexts up to 1024 x 2048 tokens
 constexpr int DEC_THREADS = 256;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
-constexpr int DEC_UK = 8;  // 16-token groups whose K loads a wave issues back to back (pass 1)
-constexpr int DEC_U = 4;   // same for V (pass 2 carries the P.V accumulators, fewer spare VGPRs)
 
 // position of head-dim element d in the "dequant order" used for q in LDS: within every 8-dim
 // word the pairs (j, j+4) are adjacent, matching the half2 pairs kv4_dequant16 produces.
@@ -309,307 +304,8 @@ __device__ __forceinline__ int perm_pos(int d) {
   return (d & ~7) | ((r & 3) << 1) | (r >> 2);
 }
 
-// reduce-scatter step over the lane bit selected by `mask`: v[0..N) -> v[0..N/2)
-template <int N>
-__device__ __forceinline__ void rs_step(float* v, int mask, int lane) {
-  const bool up = (lane & mask) != 0;
-#pragma unroll
-  for (int i = 0; i < N / 2; ++i) {
-    const float lo = v[i], hi = v[i + N / 2];
-    const float keep = up ? hi : lo;
-    const float send = up ? lo : hi;
-    v[i] = keep + __shfl_xor(send, mask, 64);
-  }
-}
-
-// G = q heads served per workgroup (<= 4); grid = (S, Hkv * nsub, B), nsub = (Hq/Hkv)/G.
-// DIRECT: S == 1, the normalised fp16 output is written straight to `out` (no merge kernel).
-template <int G, bool DIRECT>
-__global__ __launch_bounds__(DEC_THREADS) void kv4_decode_kernel(DecodeArgs p) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  constexpr int V = G * 32;       // P.V partial values per lane
-  constexpr int VPL = V / 16;     // values per lane after the in-wave reduce-scatter
-  // LDS carve (all offsets multiples of 16 B):
-  half_t* q_lds = reinterpret_cast<half_t*>(smem);            // [G][128] dequant order
-  half_t* kcur = q_lds + G * DH;                              // [128] natural order (post RoPE)
-  half_t* kcur_p = kcur + DH;                                 // [128] dequant order
-  half_t* vcur = kcur_p + DH;                                 // [128]
-  float* red = reinterpret_cast<float*>(vcur + DH);           // [64]
-  int64_t* pages = reinterpret_cast<int64_t*>(red + 64);      // [2][40] K / V page pointers of the split
-  float* xbuf = reinterpret_cast<float*>(pages + 80);         // [4][64][VPL]
-  float* scores = xbuf + DEC_WAVES * 64 * VPL;                // [G][sstride]
-  const int sstride = p.split_tokens + 16;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int split = blockIdx.x;
-  const int group = p.num_heads / p.num_kv_heads;
-  const int qg = group / G;
-  const int hk = blockIdx.y / qg;
-  const int sub = blockIdx.y % qg;
-  const int hq0 = hk * group + sub * G;
-  const int b = blockIdx.z;
-  const int tlen = p.lengths[b] - 1;  // history length = RoPE position = append slot
-  const KvLayout lay = p.lay;
-  const int64_t* ktab = p.kv_pointers + (size_t)b * 2 * p.max_blocks;
-  const int64_t* vtab = ktab + p.max_blocks;
-  const float inv_sqrt_dh = 0.08838834764831845f;  // 1/sqrt(128)
-
-  // split token range [t0, t1): multiples of 16, so a 16-token group never straddles a page
-  int per = (tlen + p.nsplit - 1) / p.nsplit;
-  per = (per + 15) & ~15;
-  if (per > p.split_tokens) per = p.split_tokens;
-  const int t0 = min(tlen, split * per);
-  const int t1 = (split == p.nsplit - 1) ? min(tlen, t0 + p.split_tokens) : min(tlen, t0 + per);
-  const int nt = t1 - t0;
-  const bool owns_cur = split == p.nsplit - 1;  // this split also takes the current token
-  const int page0 = t0 >> lay.tpb_log2;
-
-  // ---- stage: page pointers, RoPE(q) (and k of the current token) ------------------------------
-  if (tid < 80) {
-    const int pi = tid < 40 ? tid : tid - 40;
-    const int64_t* tab = tid < 40 ? ktab : vtab;
-    const int pg = page0 + pi;
-    pages[tid] = (pg < p.max_blocks && (pg << lay.tpb_log2) <= tlen) ? tab[pg] : 0;
-  }
-  {
-    const int rp = tlen < p.rope_max_pos ? tlen : p.rope_max_pos - 1;
-    const float* cs = p.rope + (size_t)rp * DH;  // [64][2]
-    for (int idx = tid; idx < (G + 1) * 64; idx += DEC_THREADS) {
-      const int h = idx >> 6, i = idx & 63;
-      if (h == G && !owns_cur) continue;
-      const half_t* src = h < G ? p.q + (size_t)b * p.q_stride + (size_t)(hq0 + h) * DH
-                                : p.k + (size_t)b * p.kv_stride + (size_t)hk * DH;
-      const float c = cs[2 * i], s = cs[2 * i + 1];
-      const float a = (float)src[i], bb = (float)src[i + 64];
-      const float t0f = c * a, t1f = s * bb, t2f = c * bb, t3f = s * a;
-      const half_t r0 = (half_t)(t0f - t1f), r1 = (half_t)(t2f + t3f);
-      if (h < G) {
-        q_lds[h * DH + perm_pos(i)] = r0;
-        q_lds[h * DH + perm_pos(i + 64)] = r1;
-      } else {
-        kcur[i] = r0; kcur[i + 64] = r1;
-        kcur_p[perm_pos(i)] = r0; kcur_p[perm_pos(i + 64)] = r1;
-      }
-    }
-    if (owns_cur && tid < DH) vcur[tid] = p.v[(size_t)b * p.kv_stride + (size_t)hk * DH + tid];
-  }
-  __syncthreads();
-
-  const int part = lane & 3;    // 32-dim part of the row (16 packed bytes)
-  const int tslot = lane >> 2;  // token within a 16-token group
-  const int ngroups = (nt + 15) >> 4;
-  const size_t head_off = (size_t)hk * lay.tpb * ROW_BYTES + part * 16;
-  const int tail_off = lay.bytes_per_seq + hk * lay.tpb * 2;      // scale tail of this head
-  const int zero_off = lay.num_kv_heads * lay.tpb * 2;             // scale -> zero distance
-
-  // ---- pass 1: scores = q.K / sqrt(Dh) -------------------------------------------------------------
-  float mloc[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) mloc[g] = -1e30f;
-  {
-    v2h qreg[G][16];
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const v8h t = *reinterpret_cast<const v8h*>(q_lds + g * DH + part * 32 + w * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) qreg[g][w * 4 + j] = (v2h){t[2 * j], t[2 * j + 1]};
-      }
-    for (int g0 = wave; g0 < ngroups; g0 += DEC_WAVES * DEC_UK) {
-      uint4 raw[DEC_UK];
-      half_t sc[DEC_UK], ze[DEC_UK];
-#pragma unroll
-      for (int u = 0; u < DEC_UK; ++u) {  // branch-free: out-of-range lanes re-read token t0
-        const int ti = (g0 + u * DEC_WAVES) * 16 + tslot;
-        const int tok = ti < nt ? t0 + ti : t0;
-        const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[(tok >> lay.tpb_log2) - page0]);
-        const int slot = tok & (lay.tpb - 1);
-        raw[u] = *reinterpret_cast<const uint4*>(pg + head_off + (size_t)slot * ROW_BYTES);
-        const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
-        sc[u] = tail[0];
-        ze[u] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
-      }
-#pragma unroll
-      for (int u = 0; u < DEC_UK; ++u) {
-        const int ti = (g0 + u * DEC_WAVES) * 16 + tslot;
-        const bool valid = ti < nt;
-        const half_t ch = (half_t)(-(float)sc[u] * (float)ze[u]);
-        v2h kd[16];
-        kv4_dequant16(raw[u], (v2h){sc[u], sc[u]}, (v2h){ch, ch}, kd);
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          float acc = 0.0f;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc = dot2_acc(kd[i], qreg[g][i], acc);
-          acc += __shfl_xor(acc, 1, 64);
-          acc += __shfl_xor(acc, 2, 64);
-          const float sv = valid ? acc * inv_sqrt_dh : -1e30f;
-          mloc[g] = __builtin_fmaxf(mloc[g], sv);
-          if (part == 0 && ti < ngroups * 16) scores[g * sstride + ti] = sv;
-        }
-      }
-    }
-  }
-  // current token: q . k_cur (both in dequant order), fp32 accumulation of the fp16 operands
-  float scur[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) scur[g] = 0.0f;
-  if (owns_cur) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float a = (float)q_lds[g * DH + lane] * (float)kcur_p[lane] +
-                (float)q_lds[g * DH + 64 + lane] * (float)kcur_p[64 + lane];
-      a = wave_sum64(a);
-      scur[g] = a * inv_sqrt_dh;
-      mloc[g] = __builtin_fmaxf(mloc[g], scur[g]);
-    }
-  }
-  // block max per head (also orders the score writes before the reads below)
-  float mblk[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const float wm = wave_max64(mloc[g]);
-    if (lane == 0) red[g * DEC_WAVES + wave] = wm;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float m = red[g * DEC_WAVES];
-#pragma unroll
-    for (int w = 1; w < DEC_WAVES; ++w) m = __builtin_fmaxf(m, red[g * DEC_WAVES + w]);
-    mblk[g] = m;
-  }
-  // p = exp(s - m) in place + block sum
-  float lloc[G];
-  const int ntp = ngroups * 16;
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float ls = 0.0f;
-    for (int i = tid; i < ntp; i += DEC_THREADS) {
-      const float e = i < nt ? __expf(scores[g * sstride + i] - mblk[g]) : 0.0f;
-      scores[g * sstride + i] = e;
-      ls += e;
-    }
-    lloc[g] = wave_sum64(ls);
-  }
-  __syncthreads();  // all reads of red[] (max) done, all p written
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-    if (lane == 0) red[g * DEC_WAVES + wave] = lloc[g];
-  __syncthreads();
-  float lblk[G], pcur[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float l = red[g * DEC_WAVES];
-#pragma unroll
-    for (int w = 1; w < DEC_WAVES; ++w) l += red[g * DEC_WAVES + w];
-    pcur[g] = owns_cur ? __expf(scur[g] - mblk[g]) : 0.0f;
-    lblk[g] = l + pcur[g];
-  }
-
-  // ---- pass 2: O = sum_t p_t * V_t -----------------------------------------------------------------
-  float o[V];   // index g*32 + 2*i + h  <->  head g, half2 pair i = w*4+j, element h
-#pragma unroll
-  for (int i = 0; i < V; ++i) o[i] = 0.0f;
-  for (int g0 = wave; g0 < ngroups; g0 += DEC_WAVES * DEC_U) {
-    uint4 raw[DEC_U];
-    half_t sc[DEC_U], ze[DEC_U];
-#pragma unroll
-    for (int u = 0; u < DEC_U; ++u) {
-      const int ti = (g0 + u * DEC_WAVES) * 16 + tslot;
-      const int tok = ti < nt ? t0 + ti : t0;
-      const uint8_t* pg = reinterpret_cast<const uint8_t*>(pages[40 + (tok >> lay.tpb_log2) - page0]);
-      const int slot = tok & (lay.tpb - 1);
-      raw[u] = *reinterpret_cast<const uint4*>(pg + head_off + (size_t)slot * ROW_BYTES);
-      const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
-      sc[u] = tail[0];
-      ze[u] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
-    }
-#pragma unroll
-    for (int u = 0; u < DEC_U; ++u) {
-      const int ti = (g0 + u * DEC_WAVES) * 16 + tslot;
-      const bool valid = ti < nt;
-      const half_t ch = (half_t)(-(float)sc[u] * (float)ze[u]);
-      v2h vd[16];
-      kv4_dequant16(raw[u], (v2h){sc[u], sc[u]}, (v2h){ch, ch}, vd);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float pv = valid ? scores[g * sstride + ti] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          o[g * 32 + 2 * i] += pv * (float)vd[i][0];
-          o[g * 32 + 2 * i + 1] += pv * (float)vd[i][1];
-        }
-      }
-    }
-  }
-
-  // ---- reduce O: in-wave reduce-scatter over the 16 token slots, then across the 4 waves via LDS ----
-  rs_step<V>(o, 32, lane);
-  rs_step<V / 2>(o, 16, lane);
-  rs_step<V / 4>(o, 8, lane);
-  rs_step<V / 8>(o, 4, lane);
-  // lane (tslot, part) now owns flattened indices tslot*VPL + r, r < VPL
-#pragma unroll
-  for (int r = 0; r < VPL; ++r) xbuf[(wave * 64 + lane) * VPL + r] = o[r];
-  __syncthreads();
-  for (int oi = tid; oi < G * DH; oi += DEC_THREADS) {
-    const int g = oi >> 7, d = oi & 127;
-    const int prt = d >> 5, dl = d & 31;
-    const int e = 2 * ((dl >> 3) * 4 + (dl & 3)) + ((dl >> 2) & 1);
-    const int fidx = g * 32 + e;
-    const int ln = (fidx / VPL) * 4 + prt, r = fidx % VPL;
-    float acc = 0.0f;
-#pragma unroll
-    for (int w = 0; w < DEC_WAVES; ++w) acc += xbuf[(w * 64 + ln) * VPL + r];
-    if (owns_cur) acc += pcur[g] * (float)vcur[d];
-    if constexpr (DIRECT) {
-      p.out[((size_t)b * p.num_heads + hq0 + g) * DH + d] = (half_t)(acc * (1.0f / (lblk[g] + 1e-6f)));
-    } else {
-      const size_t pi = ((size_t)b * p.num_heads + hq0 + g) * p.nsplit + split;
-      p.part_o[pi * DH + d] = acc;
-      if (d == 0) {
-        p.part_ml[pi * 2 + 0] = mblk[g];
-        p.part_ml[pi * 2 + 1] = lblk[g];
-      }
-    }
-  }
-
-  // ---- append the current token (quantised) to the cache ------------------------------------------
-  // (reference: only the first q head of a GQA group writes; here: sub-block 0 of the owning split)
-  if (owns_cur && sub == 0 && wave < 2) {
-    const half_t* src = wave == 0 ? kcur : vcur;
-    const int64_t* tab = wave == 0 ? ktab : vtab;
-    const float x0 = (float)src[lane], x1 = (float)src[64 + lane];
-    const float mx = wave_max64(__builtin_fmaxf(x0, x1));
-    const float mn = -wave_max64(-__builtin_fminf(x0, x1));
-    const float range = mx - mn;
-    const half_t scale_h = (half_t)(range / 15.0f);
-    const float nm = -15.0f * mn;
-    const half_t zero_h = (half_t)(nm / range);
-    const float inv = 1.0f / (float)scale_h, z = (float)zero_h;
-    uint8_t* pg = reinterpret_cast<uint8_t*>(tab[tlen >> lay.tpb_log2]);
-    const int slot = tlen & (lay.tpb - 1);
-    uint8_t* dst = pg + ((size_t)hk * lay.tpb + slot) * ROW_BYTES;
-    // lane i holds elements i and 64+i; byte j packs elements (2j, 2j+1)
-    const uint32_t c0 = kv4_code(x0, inv, z), c1 = kv4_code(x1, inv, z);
-    const uint32_t n0 = __shfl_down(c0, 1, 64), n1 = __shfl_down(c1, 1, 64);
-    if ((lane & 1) == 0) {
-      dst[lane >> 1] = (uint8_t)(c0 | (n0 << 4));
-      dst[32 + (lane >> 1)] = (uint8_t)(c1 | (n1 << 4));
-    }
-    if (lane == 0) {
-      half_t* scp = reinterpret_cast<half_t*>(pg + lay.bytes_per_seq) + hk * lay.tpb + slot;
-      scp[0] = scale_h;
-      scp[lay.num_kv_heads * lay.tpb] = zero_h;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
-// Decode attention, matrix-core version (default).  Same work decomposition and numerics contract
-// as kv4_decode_kernel above, but Q.K^T and P.V run on v_mfma_f32_16x16x32_f16:
+// Decode attention on the matrix cores (v_mfma_f32_16x16x32_f16), flash-decoding inside the workgroup:
 //   * Q.K^T: A = dequantised K (row = token, k = head dims: one packed dword = 8 codes = one
 //     lane's 8 k-slots), B = q (col = q head, padded to 16), 4 MFMAs per 16 tokens;
 //   * P.V: V is stored token-major, the contraction runs over tokens, so the dequantised fp16 V
@@ -617,457 +313,15 @@ __global__ __launch_bounds__(DEC_THREADS) void kv4_decode_kernel(DecodeArgs p) {
 //     ds_read_b64_tr_b16 (lane L of a 16-lane group passes &M[L>>2][4*(L&3)] and receives column
 //     L of the 4x16 block -- verified on hardware with tools/tr_probe.hip); A = V^T (row = dim),
 //     B = P^T (col = q head, probabilities rounded to fp16 as the reference does), 8 MFMAs per
-//     32 tokens; O accumulators are 32 VGPRs instead of 128.
+//     32 tokens; the O accumulators are 32 VGPRs.
+// (Two earlier versions -- a VALU kernel with fdot2 and a two-pass MFMA kernel that kept all scores of
+// a split in LDS -- were 15-40 % slower and are gone; see DESIGN.md 4.4 and profiles/r01_c, r01_e.)
 // ------------------------------------------------------------------------------------------
 typedef __fp16 v4hp __attribute__((__vector_size__(4 * sizeof(__fp16))));
-constexpr int VROW = 272;        // bytes per token row of the V tile in LDS (256 + 16: conflict-free b128 writes)
-constexpr int VTILE = 32 * VROW;  // one 32-token tile per wave
-constexpr int MF_UK = 8;          // K groups (16 tokens) in flight per wave
-constexpr int MF_UT = 2;          // V tiles (32 tokens) per batch; one batch is always in flight
 
 __device__ __forceinline__ int unperm_pos(int q) { return (q & ~7) | ((q >> 1) & 3) | ((q & 1) << 2); }
 
-// FG: LServe fine-grained mode.  The split runs over a head's list of *attended* cached tokens
-// ("virtual" tokens): all of them for a retrieval head, the tokens of the selected pages with
-// fg.dyn (one list per q head, hence G = 1), min(sink+local-1, tlen) tokens read through the page
-// ring for a streaming head (decoderMaskedMultiheadAttentionTemplate.hpp:1475-1537 of
-// fused_attention_fine_grained/dense_attention, :1566-1641 of sparse_attention).
-template <int G, bool DIRECT, bool FG = false>
-__global__ __launch_bounds__(DEC_THREADS) void kv4_decode_mfma_kernel(DecodeArgs p) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int sstride = p.split_tokens + 32;
-  half_t* q_lds = reinterpret_cast<half_t*>(smem);            // [G][128] dequant order
-  half_t* kcur = q_lds + G * DH;                              // [128] natural order (post RoPE)
-  half_t* kcur_p = kcur + DH;                                 // [128] dequant order
-  half_t* vcur = kcur_p + DH;                                 // [128]
-  float* red = reinterpret_cast<float*>(vcur + DH);           // [64]
-  int64_t* pages = reinterpret_cast<int64_t*>(red + 64);      // [2][40]
-  float* xbuf = reinterpret_cast<float*>(pages + 80);         // [4 waves][G][128]
-  uint8_t* vtile = reinterpret_cast<uint8_t*>(xbuf + DEC_WAVES * G * DH);  // [4 waves][32][VROW]
-  float* scores = reinterpret_cast<float*>(vtile + DEC_WAVES * VTILE);     // [G][sstride] f32
-  half_t* ph = reinterpret_cast<half_t*>(scores + G * sstride);             // [G][sstride] fp16 probabilities
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int split = blockIdx.x;
-  const int group = p.num_heads / p.num_kv_heads;
-  const int qg = group / G;
-  const int hk = blockIdx.y / qg;
-  const int sub = blockIdx.y % qg;
-  const int hq0 = hk * group + sub * G;
-  const int b = blockIdx.z;
-  OMNI_CLK(16);
-  const KvLayout lay = p.lay;
-  // The kernel is a chain of memory round trips, so the requests are ordered to need only two of them:
-  //   trip 1 (independent of the sequence length): length, page-table window, raw q / k / v rows;
-  //   trip 2: RoPE coefficients of position tlen, and every K and V byte of the split.
-  // The split geometry is fixed on the host (split s = virtual tokens [s*split_tokens, +split_tokens)),
-  // so the page window does not wait for the length.
-  // head class: pool geometry and page table of this kv head
-  int hrank = hk, hpool = lay.num_kv_heads, tab_blocks = p.max_blocks;
-  bool streaming = false;
-  const int64_t* ktab = p.kv_pointers + (size_t)b * 2 * p.max_blocks;
-  const int* dyn = nullptr;
-  if constexpr (FG) {
-    hrank = p.fg.rank[hk];
-    streaming = p.fg.flags[hk] == 0;
-    hpool = streaming ? p.fg.num_strm : p.fg.num_retr;
-    if (streaming) {
-      tab_blocks = p.fg.strm_blocks;
-      ktab = p.fg.strm_pointers + (size_t)b * 2 * tab_blocks;
-    } else if (p.fg.dyn) {
-      dyn = p.fg.dyn + ((size_t)b * p.num_heads + hq0) * p.fg.num_dyn;
-    }
-  }
-  const int64_t* vtab = ktab + tab_blocks;
-  const int pool_bytes_per_seq = hpool * lay.tpb * ROW_BYTES;
-  const float inv_sqrt_dh = 0.08838834764831845f;
-  const int vt0 = split * p.split_tokens;
-  const int page0 = (FG && streaming) ? 0 : (vt0 >> lay.tpb_log2);
-  const bool owns_cur = split == p.nsplit - 1;
-
-  // ---- trip 1 -----------------------------------------------------------------------------------------
-  int64_t my_page = 0;
-  if (tid < 80) {
-    const int pi = tid < 40 ? tid : tid - 40;
-    const int64_t* tab = tid < 40 ? ktab : vtab;
-    const int pg = page0 + pi;
-    if constexpr (FG) {
-      if (streaming) {               // the whole ring (<= 40 pages, checked on the host)
-        if (pg < tab_blocks) my_page = tab[pg];
-      } else if (dyn) {              // selected pages, in selection order
-        if (pg < p.fg.num_dyn) {
-          const int sel = dyn[pg];
-          if (sel >= 0 && sel < tab_blocks) my_page = tab[sel];
-        }
-      } else if (pg < tab_blocks) {
-        my_page = tab[pg];
-      }
-    } else {
-      if (pg < p.max_blocks) my_page = tab[pg];   // entries past the sequence's pages are never dereferenced
-    }
-  }
-  const int64_t dummy_ptr = ktab[0];   // the sequence's first page: always allocated (an empty split reads it, unused)
-  constexpr int QIT = ((G + 1) * 64 + DEC_THREADS - 1) / DEC_THREADS;
-  half_t qa[QIT], qbv[QIT];
-#pragma unroll
-  for (int j = 0; j < QIT; ++j) {
-    const int idx = tid + j * DEC_THREADS;
-    const int h = idx >> 6, i = idx & 63;
-    const half_t* src = h < G ? p.q + (size_t)b * p.q_stride + (size_t)(hq0 + h) * DH
-                              : p.k + (size_t)b * p.kv_stride + (size_t)hk * DH;   // h > G (idle slots): k again
-    qa[j] = src[i];
-    qbv[j] = src[i + 64];
-  }
-  half_t vcur_r = (half_t)0.0f;
-  if (tid < DH) vcur_r = p.v[(size_t)b * p.kv_stride + (size_t)hk * DH + tid];
-
-  const int tlen = p.lengths[b] - 1;
-  int nvirt = tlen, gap = 0;   // attended cached tokens; streaming: virtual i >= sink is token i + gap
-  if constexpr (FG) {
-    if (streaming) {
-      nvirt = min(p.fg.sink + p.fg.local - 1, tlen);
-      gap = tlen - nvirt;
-    } else if (dyn) {
-      nvirt = tlen > 0 ? (p.fg.num_dyn - 1) * lay.tpb + ((tlen - 1) & (lay.tpb - 1)) + 1 : 0;
-    }
-  }
-  const int t0 = min(nvirt, vt0);
-  const int t1 = min(nvirt, vt0 + p.split_tokens);
-  const int nt = t1 - t0;
-  if (tid < 80) pages[tid] = my_page;
-
-  // virtual token -> (index into pages[], slot in the page)
-  auto locate = [&](int vt, int& pidx, int& slot) {
-    if (FG && streaming) {
-      const int lt = vt < p.fg.sink ? vt : vt + gap;
-      pidx = ring_block(lt >> lay.tpb_log2, p.fg.sink_blocks, p.fg.local_blocks);
-      slot = lt & (lay.tpb - 1);
-    } else {
-      pidx = (vt >> lay.tpb_log2) - page0;
-      slot = vt & (lay.tpb - 1);
-    }
-  };
-
-  const int ngroups = (nt + 15) >> 4;
-  const int ntiles = (nt + 31) >> 5;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int jh = l15 < G ? l15 : 0;                               // this lane's q-head column (clamped)
-  const int tail_off = pool_bytes_per_seq + hrank * lay.tpb * 2;
-  const int zero_off = hpool * lay.tpb * 2;
-
-  // ---- trip 2: RoPE coefficients + the first K and V batches (normally: all of the split) -------------------
-  float rc[QIT], rs[QIT];
-  {
-    const int rp = tlen < p.rope_max_pos ? tlen : p.rope_max_pos - 1;
-    const float* cs = p.rope + (size_t)rp * DH;
-#pragma unroll
-    for (int j = 0; j < QIT; ++j) {
-      const int i = (tid + j * DEC_THREADS) & 63;
-      const float2 t = *reinterpret_cast<const float2*>(cs + 2 * i);
-      rc[j] = t.x; rs[j] = t.y;
-    }
-  }
-  OMNI_CLK(17);
-  __syncthreads();   // pages[] visible
-
-  const bool has_tokens = nt > 0;
-  const uint8_t* dummy_page = reinterpret_cast<const uint8_t*>(dummy_ptr);
-  const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
-  const size_t vhead_off = (size_t)hrank * lay.tpb * ROW_BYTES + vpiece * 16;
-  uint4 vraw[MF_UT][2];
-  half_t vsc[MF_UT][2], vze[MF_UT][2];
-  auto load_v_batch = [&](int tl0) {   // branch-free: out-of-range tokens re-read token t0
-#pragma unroll
-    for (int u = 0; u < MF_UT; ++u)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int ti = (tl0 + u * DEC_WAVES) * 32 + h * 16 + vtok;
-        const int tok = ti < nt ? t0 + ti : t0;
-        int pidx, slot;
-        locate(tok, pidx, slot);
-        const uint8_t* pg = has_tokens ? reinterpret_cast<const uint8_t*>(pages[40 + (has_tokens ? pidx : 0)]) : dummy_page;
-        vraw[u][h] = *reinterpret_cast<const uint4*>(pg + vhead_off + (size_t)slot * ROW_BYTES);
-        const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
-        vsc[u][h] = tail[0];
-        vze[u][h] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
-      }
-  };
-  const size_t khead_off = (size_t)hrank * lay.tpb * ROW_BYTES + l4 * 16;  // lane: token l15, 16-B piece l4
-  uint4 kraw[MF_UK];
-  half_t ksc[MF_UK], kze[MF_UK];
-  auto load_k_batch = [&](int g0) {
-#pragma unroll
-    for (int u = 0; u < MF_UK; ++u) {
-      const int ti = (g0 + u * DEC_WAVES) * 16 + l15;
-      const int tok = ti < nt ? t0 + ti : t0;
-      int pidx, slot;
-      locate(tok, pidx, slot);
-      const uint8_t* pg = has_tokens ? reinterpret_cast<const uint8_t*>(pages[has_tokens ? pidx : 0]) : dummy_page;
-      kraw[u] = *reinterpret_cast<const uint4*>(pg + khead_off + (size_t)slot * ROW_BYTES);
-      const half_t* tail = reinterpret_cast<const half_t*>(pg + tail_off) + slot;
-      ksc[u] = tail[0];
-      kze[u] = *reinterpret_cast<const half_t*>(reinterpret_cast<const uint8_t*>(tail) + zero_off);
-    }
-  };
-  // no branch around these loads (a branch would turn the wait for K into a wait for K AND V): an empty split
-  // reads the sequence's first page instead (discarded)
-  load_k_batch(wave);
-  load_v_batch(wave);
-
-  // RoPE(q) (and k of the current token) into LDS while the cache bytes are in flight
-#pragma unroll
-  for (int j = 0; j < QIT; ++j) {
-    const int idx = tid + j * DEC_THREADS;
-    const int h = idx >> 6, i = idx & 63;
-    if (h > G || (h == G && !owns_cur)) continue;
-    const float c = rc[j], sn = rs[j];
-    const float a = (float)qa[j], bb = (float)qbv[j];
-    const float t0f = c * a, t1f = sn * bb, t2f = c * bb, t3f = sn * a;
-    const half_t r0 = (half_t)(t0f - t1f), r1 = (half_t)(t2f + t3f);
-    if (h < G) {
-      q_lds[h * DH + perm_pos(i)] = r0;
-      q_lds[h * DH + perm_pos(i + 64)] = r1;
-    } else {
-      kcur[i] = r0; kcur[i + 64] = r1;
-      kcur_p[perm_pos(i)] = r0; kcur_p[perm_pos(i + 64)] = r1;
-    }
-  }
-  if (owns_cur && tid < DH) vcur[tid] = vcur_r;
-  __syncthreads();
-  OMNI_CLK(18);
-
-  // ---- pass 1: scores = q.K / sqrt(Dh) on MFMA ------------------------------------------------------
-  float mloc = -1e30f;   // running max of this lane's head column (valid for l15 < G)
-  {
-    v8h qb[4];  // B operand: q[head jh][32*l4 + 8s + (0..7 in dequant order)]
-#pragma unroll
-    for (int sidx = 0; sidx < 4; ++sidx)
-      qb[sidx] = *reinterpret_cast<const v8h*>(q_lds + jh * DH + 32 * l4 + 8 * sidx);
-    for (int g0 = wave; g0 < ngroups; g0 += DEC_WAVES * MF_UK) {
-      uint4 raw[MF_UK];
-      half_t sc[MF_UK], ze[MF_UK];
-#pragma unroll
-      for (int u = 0; u < MF_UK; ++u) { raw[u] = kraw[u]; sc[u] = ksc[u]; ze[u] = kze[u]; }
-      if (g0 + DEC_WAVES * MF_UK < ngroups) load_k_batch(g0 + DEC_WAVES * MF_UK);   // (rare) next batch
-#pragma unroll
-      for (int u = 0; u < MF_UK; ++u) {
-        const int gbase = (g0 + u * DEC_WAVES) * 16;
-        if (gbase >= ngroups * 16) continue;  // wave-uniform
-        const half_t ch = (half_t)(-(float)sc[u] * (float)ze[u]);
-        v2h kd[16];
-        kv4_dequant16(raw[u], (v2h){sc[u], sc[u]}, (v2h){ch, ch}, kd);
-        v4f acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-          const v8h a = {kd[4 * sidx][0], kd[4 * sidx][1], kd[4 * sidx + 1][0], kd[4 * sidx + 1][1],
-                         kd[4 * sidx + 2][0], kd[4 * sidx + 2][1], kd[4 * sidx + 3][0], kd[4 * sidx + 3][1]};
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qb[sidx], acc, 0, 0, 0);
-        }
-        // acc[r] = q[head l15] . K[token gbase + 4*l4 + r]
-        if (l15 < G) {
-          v4f sv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int ti = gbase + 4 * l4 + r;
-            sv[r] = ti < nt ? acc[r] * inv_sqrt_dh : -1e30f;
-            mloc = __builtin_fmaxf(mloc, sv[r]);
-          }
-          *reinterpret_cast<v4f*>(scores + l15 * sstride + gbase + 4 * l4) = sv;
-        }
-      }
-    }
-  }
-  OMNI_CLK(19);
-  float scur[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) scur[g] = 0.0f;
-  if (owns_cur) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float a = (float)q_lds[g * DH + lane] * (float)kcur_p[lane] +
-                (float)q_lds[g * DH + 64 + lane] * (float)kcur_p[64 + lane];
-      a = wave_sum64(a);
-      scur[g] = a * inv_sqrt_dh;
-    }
-  }
-  // block max per head
-  float mblk[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float m = wave_max64(l15 == g ? mloc : -1e30f);
-    if (owns_cur) m = __builtin_fmaxf(m, scur[g]);
-    if (lane == 0) red[g * DEC_WAVES + wave] = m;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float m = red[g * DEC_WAVES];
-#pragma unroll
-    for (int w = 1; w < DEC_WAVES; ++w) m = __builtin_fmaxf(m, red[g * DEC_WAVES + w]);
-    mblk[g] = m;
-  }
-  // p = fp16(exp(s - m)) into ph (zero padded to whole 32-token tiles), block sum of the rounded p
-  float lloc[G];
-  const int ntp = ntiles * 32;
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float ls = 0.0f;
-    for (int i = tid; i < ntp; i += DEC_THREADS) {
-      const half_t e = i < nt ? (half_t)__expf(scores[g * sstride + i] - mblk[g]) : (half_t)0.0f;
-      ph[g * sstride + i] = e;
-      ls += (float)e;
-    }
-    lloc[g] = wave_sum64(ls);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-    if (lane == 0) red[g * DEC_WAVES + wave] = lloc[g];
-  __syncthreads();
-  float lblk[G], pcur[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float l = red[g * DEC_WAVES];
-#pragma unroll
-    for (int w = 1; w < DEC_WAVES; ++w) l += red[g * DEC_WAVES + w];
-    pcur[g] = owns_cur ? __expf(scur[g] - mblk[g]) : 0.0f;
-    lblk[g] = l + pcur[g];
-  }
-
-  OMNI_CLK(20);
-  // ---- pass 2: O^T = V^T . P^T on MFMA (V through LDS, transposed read) ----------------------------------
-  v4f oacc[8];   // block c: rows = column positions c*16 + 4*l4 + r of the V tile, col = head l15
-#pragma unroll
-  for (int c = 0; c < 8; ++c) oacc[c] = (v4f){0.f, 0.f, 0.f, 0.f};
-  {
-    uint8_t* vt = vtile + wave * VTILE;
-    // transposed-read address of this lane inside a 16-dim column block: row (l15>>2) of the 4-token
-    // block owned by lane group l4, halves [4*(l15&3), +4)
-    const int tr_off = (4 * l4 + (l15 >> 2)) * VROW + (l15 & 3) * 8;
-    for (int tl0 = wave; tl0 < ntiles; tl0 += DEC_WAVES * MF_UT) {
-      uint4 raw[MF_UT][2];
-      half_t sc[MF_UT][2], ze[MF_UT][2];
-#pragma unroll
-      for (int u = 0; u < MF_UT; ++u)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) { raw[u][h] = vraw[u][h]; sc[u][h] = vsc[u][h]; ze[u][h] = vze[u][h]; }
-      if (tl0 + DEC_WAVES * MF_UT < ntiles) load_v_batch(tl0 + DEC_WAVES * MF_UT);   // (rare) next batch
-#pragma unroll
-      for (int u = 0; u < MF_UT; ++u) {
-        const int tbase = (tl0 + u * DEC_WAVES) * 32;
-        if (tbase >= ntp) continue;  // wave-uniform
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const half_t ch = (half_t)(-(float)sc[u][h] * (float)ze[u][h]);
-          v2h vd[16];
-          kv4_dequant16(raw[u][h], (v2h){sc[u][h], sc[u][h]}, (v2h){ch, ch}, vd);
-          uint8_t* dst = vt + (h * 16 + vtok) * VROW + vpiece * 64;   // 32 values in dequant order
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            const v8h t = {vd[4 * w][0], vd[4 * w][1], vd[4 * w + 1][0], vd[4 * w + 1][1],
-                           vd[4 * w + 2][0], vd[4 * w + 2][1], vd[4 * w + 3][0], vd[4 * w + 3][1]};
-            *reinterpret_cast<v8h*>(dst + w * 16) = t;
-          }
-        }
-        // B operand: P[head jh][tokens tbase + 4*l4 + (0..3), tbase + 16 + 4*l4 + (0..3)]
-        typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
-        const v4h_t p0 = *reinterpret_cast<const v4h_t*>(ph + jh * sstride + tbase + 4 * l4);
-        const v4h_t p1 = *reinterpret_cast<const v4h_t*>(ph + jh * sstride + tbase + 16 + 4 * l4);
-        const v8h pb = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const uint8_t* src = vt + tr_off + c * 32;
-          const v4hp lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-              (__attribute__((address_space(3))) v4hp*)(__attribute__((address_space(3))) void*)(src));
-          const v4hp hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-              (__attribute__((address_space(3))) v4hp*)(__attribute__((address_space(3))) void*)(src + 16 * VROW));
-          const v8h a = {(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
-                         (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
-          oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb, oacc[c], 0, 0, 0);
-        }
-      }
-    }
-  }
-  OMNI_CLK(21);
-  // ---- reduce O across the 4 waves via LDS, un-permute the columns, normalise / emit partials --------------
-  if (l15 < G) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-      *reinterpret_cast<v4f*>(xbuf + ((size_t)wave * G + l15) * DH + c * 16 + 4 * l4) = oacc[c];
-  }
-  __syncthreads();
-  for (int oi = tid; oi < G * DH; oi += DEC_THREADS) {
-    const int g = oi >> 7, qpos = oi & 127;
-    const int d = unperm_pos(qpos);
-    float acc = 0.0f;
-#pragma unroll
-    for (int w = 0; w < DEC_WAVES; ++w) acc += xbuf[((size_t)w * G + g) * DH + qpos];
-    if (owns_cur) acc += pcur[g] * (float)vcur[d];
-    if constexpr (DIRECT) {
-      p.out[((size_t)b * p.num_heads + hq0 + g) * DH + d] = (half_t)(acc * (1.0f / (lblk[g] + 1e-6f)));
-    } else {
-      const size_t pi = ((size_t)b * p.num_heads + hq0 + g) * p.nsplit + split;
-      p.part_o[pi * DH + d] = acc;
-      if (qpos == 0) {
-        p.part_ml[pi * 2 + 0] = mblk[g];
-        p.part_ml[pi * 2 + 1] = lblk[g];
-      }
-    }
-  }
-
-  OMNI_CLK(22);
-  // ---- append the current token (quantised) to the cache ------------------------------------------
-  if (owns_cur && sub == 0 && wave < 2) {
-    const half_t* src = wave == 0 ? kcur : vcur;
-    const int64_t* tab = wave == 0 ? ktab : vtab;
-    const float x0 = (float)src[lane], x1 = (float)src[64 + lane];
-    const float mx = wave_max64(__builtin_fmaxf(x0, x1));
-    const float mn = -wave_max64(-__builtin_fminf(x0, x1));
-    const float range = mx - mn;
-    const half_t scale_h = (half_t)(range / 15.0f);
-    const float nm = -15.0f * mn;
-    const half_t zero_h = (half_t)(nm / range);
-    const float inv = 1.0f / (float)scale_h, z = (float)zero_h;
-    int blk = tlen >> lay.tpb_log2;
-    if (FG && streaming) blk = ring_block(blk, p.fg.sink_blocks, p.fg.local_blocks);
-    // the page pointer normally sits in the LDS window already (no dependent load at the kernel's end)
-    const int wi = blk - page0;
-    const bool in_window = !(FG && dyn != nullptr) && wi >= 0 && wi < 40;
-    uint8_t* pg = reinterpret_cast<uint8_t*>(in_window ? pages[(wave == 0 ? 0 : 40) + wi] : tab[blk]);
-    const int slot = tlen & (lay.tpb - 1);
-    uint8_t* dst = pg + ((size_t)hrank * lay.tpb + slot) * ROW_BYTES;
-    const uint32_t c0 = kv4_code(x0, inv, z), c1 = kv4_code(x1, inv, z);
-    const uint32_t n0 = __shfl_down(c0, 1, 64), n1 = __shfl_down(c1, 1, 64);
-    if ((lane & 1) == 0) {
-      dst[lane >> 1] = (uint8_t)(c0 | (n0 << 4));
-      dst[32 + (lane >> 1)] = (uint8_t)(c1 | (n1 << 4));
-    }
-    if (lane == 0) {
-      half_t* scp = reinterpret_cast<half_t*>(pg + pool_bytes_per_seq) + hrank * lay.tpb + slot;
-      scp[0] = scale_h;
-      scp[hpool * lay.tpb] = zero_h;
-    }
-    if constexpr (FG) {
-      // K pages with min/max statistics: fold the new key into its sub-chunk's indicators
-      // (sparse_attention/decoderMaskedMultiheadAttentionTemplate.hpp:1414-1428)
-      if (wave == 0 && !streaming && p.fg.sub_chunk > 0) {
-        const int subs = lay.tpb / p.fg.sub_chunk;
-        half_t* kmax = reinterpret_cast<half_t*>(pg + pool_bytes_per_seq) + 2 * hpool * lay.tpb +
-                       ((size_t)(slot / p.fg.sub_chunk) * hpool + hrank) * DH;
-        half_t* kmin = kmax + (size_t)subs * hpool * DH;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int d = lane + 64 * h;
-          const half_t kv = src[d], omx = kmax[d], omn = kmin[d];
-          kmax[d] = (half_t)__builtin_fmaxf((float)omx, (float)kv);
-          kmin[d] = (half_t)__builtin_fminf((float)omn, (float)kv);
-        }
-      }
-    }
-  }
-}
-
-// Single-sweep (flash) variant of the kernel above -- the default.
+// One sweep over the split: Q.K^T -> online softmax in registers -> P.V per 32-token tile.
 // FG: LServe fine-grained mode.  The split runs over a head's list of *attended* cached tokens
 // ("virtual" tokens): all of them for a retrieval head, the tokens of the selected pages with
 // fg.dyn (one list per q head, hence G = 1), min(sink+local-1, tlen) tokens read through the page
@@ -1558,14 +812,12 @@ __global__ __launch_bounds__(128) void kv4_decode_merge_kernel(half_t* __restric
 struct DecodePlan {
   int nsplit, split_tokens, g;
   size_t lds_bytes;
-  int kernel;   // 0 = single-sweep flash kernel (default), 1 = two-pass MFMA kernel, 2 = VALU kernel
 };
 
-static int g_override_nsplit = 0;
-static int g_kernel_choice = 0;     // tuning / A-B hook, see omni_kv4_decode_set_split_override
+static int g_override_nsplit = 0;   // tuning hook, see omni_kv4_decode_set_split_override
 
 static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int max_context, int tokens_per_block,
-                              bool per_q_head = false, bool per_q_head_or_fg = false) {
+                              bool per_q_head = false) {
   DecodePlan pl;
   const int group = num_heads / num_kv_heads;
   pl.g = group >= 4 ? 4 : group;  // group in {1,2,4,8,...}
@@ -1603,16 +855,8 @@ static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int ma
   if (st > st_cap) st = st_cap;   // caller rejects: max_context > 1024 * st_cap
   pl.nsplit = s;
   pl.split_tokens = st;
-  pl.kernel = per_q_head_or_fg ? 0 : g_kernel_choice;
-  if (pl.kernel == 0)
-    pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * pl.g * DH * 4 +
-                   (size_t)DEC_WAVES * pl.g * 2 * 4 + (size_t)DEC_WAVES * FVTILE;
-  else if (pl.kernel == 1)
-    pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * pl.g * DH * 4 +
-                   (size_t)DEC_WAVES * VTILE + (size_t)pl.g * (st + 32) * 6;
-  else
-    pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * 64 * (pl.g * 2) * 4 +
-                   (size_t)pl.g * (st + 16) * 4;
+  pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * pl.g * DH * 4 +
+                 (size_t)DEC_WAVES * pl.g * 2 * 4 + (size_t)DEC_WAVES * FVTILE;
   return pl;
 }
 
@@ -1751,12 +995,8 @@ extern "C" int omni_kv8_prefill_write_per_tensor(
 }
 
 extern "C" void omni_kv4_decode_set_split_override(int nsplit) {
-  // nsplit >= 0: force the KV split count (0 = heuristic); -1 / -2 / -3: select the VALU / single-sweep (default) /
-  // two-pass MFMA kernel
-  if (nsplit == -1) omni::g_kernel_choice = 2;
-  else if (nsplit == -2) omni::g_kernel_choice = 0;
-  else if (nsplit == -3) omni::g_kernel_choice = 1;
-  else omni::g_override_nsplit = nsplit;
+  // nsplit > 0: force the KV split count of the decode attention (tuning sweeps); 0: the planner decides
+  omni::g_override_nsplit = nsplit > 0 ? nsplit : 0;
 }
 
 extern "C" size_t omni_kv4_decode_workspace_bytes(int batch, int num_heads, int head_dim, int max_context) {
@@ -1808,22 +1048,8 @@ static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, co
   dim3 grid(pl.nsplit, num_kv_heads * (group / pl.g), batch);
   hipStream_t st = (hipStream_t)stream;
   if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;
-#define OMNI_LAUNCH_DEC(G_, D_)                                                                       \
-  do {                                                                                                \
-    if (pl.kernel == 0) {                                                                             \
-      hipLaunchKernelGGL((kv4_decode_flash_kernel<G_, D_>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); \
-    } else if (pl.kernel == 1) {                                                                      \
-      if (pl.lds_bytes > 64 * 1024)                                                                   \
-        (void)hipFuncSetAttribute((const void*)kv4_decode_mfma_kernel<G_, D_>,                        \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);    \
-      hipLaunchKernelGGL((kv4_decode_mfma_kernel<G_, D_>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); \
-    } else {                                                                                          \
-      if (pl.lds_bytes > 64 * 1024)                                                                   \
-        (void)hipFuncSetAttribute((const void*)kv4_decode_kernel<G_, D_>,                             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);    \
-      hipLaunchKernelGGL((kv4_decode_kernel<G_, D_>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a);  \
-    }                                                                                                 \
-  } while (0)
+#define OMNI_LAUNCH_DEC(G_, D_) \
+  hipLaunchKernelGGL((kv4_decode_flash_kernel<G_, D_>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a)
   if (pl.nsplit == 1 && !partials_only) {
     switch (pl.g) {
       case 1: OMNI_LAUNCH_DEC(1, true); break;
@@ -1909,7 +1135,7 @@ static int decode_fg_common(
   if (num_streaming_kv_heads > 0 && num_retrieval_kv_heads == 0) span = sink_tokens + local_tokens;
   if (span > max_context && !sparse) span = max_context;
   if (span < 1) span = 1;
-  const DecodePlan pl = plan_decode(batch, num_heads, num_kv_heads, span, tokens_per_block, sparse, true);
+  const DecodePlan pl = plan_decode(batch, num_heads, num_kv_heads, span, tokens_per_block, sparse);
   if ((long long)pl.nsplit * pl.split_tokens < span) return OMNI_EINVAL;
   if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;
   const size_t need = (size_t)batch * num_heads * pl.nsplit * (DH + 2) * sizeof(float);
