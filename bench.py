@@ -124,6 +124,48 @@ def protocol_leg(runner, args, decode_s_per_step):
                     "(3005 tok/s, batch 256) follows the same protocol"}
 
 
+def lserve_leg(device, context=256000, steps=32, warmup=8):
+    """BASELINE.json configs[3] (parity/measurement case, not the headline): Llama-3-8B W8A8, LServe sparse decode at a
+    256K-token context, batch 1 -- 4 retrieval + 4 streaming kv heads, 4096-token page budget, page selector every 4th
+    step, sub-chunk 16 (scripts/lserve_benchmark/launch.sh) -- with KV4 fine_grained pages (the config as written) and
+    with the per-tensor KV8 pages upstream's published numbers use; plus one layer of the block-sparse prefill attention
+    at the same length (16 dense + 16 streaming q heads, sink 128 / local 8192)."""
+    from omniserve_amd.lserve_runtime import LServeDecodeRunner
+    from omniserve_amd.runtime import LlamaConfig
+    from block_sparse_attn import token_streaming_attn_func
+    out = {"config": "Llama-3-8B W8A8 bs=1 ctx=%d, 4+4 kv heads (retrieval+streaming), budget 4096, interval 4" % context}
+    cfg = LlamaConfig.llama3_8b(-1)
+    for fmt in ("kv4", "kv8"):
+        r = LServeDecodeRunner(cfg, 1, context, steps + warmup + 4, device, seed=7, kv_format=fmt)
+        for _ in range(warmup):
+            r.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if not torch.isfinite(r.x.float()).all():
+            raise SystemExit("non-finite activations in the LServe decode step")
+        out[fmt] = {"decode_tokens_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+                    "gemm_weight_bytes_per_step": r.weight_bytes_per_step()}
+        del r
+        torch.cuda.empty_cache()
+    L, Hq, Hk, D = context, cfg.heads, cfg.kv_heads, cfg.head_dim
+    q = torch.randn((L, Hq, D), dtype=torch.float16, device=device)
+    k = torch.randn((L, Hk, D), dtype=torch.float16, device=device)
+    v = torch.randn_like(k)
+    cu = torch.tensor([0, L], dtype=torch.int32, device=device)
+    hm = torch.tensor([0, -1] * (Hq // 2), dtype=torch.int32, device=device)
+    si = torch.tensor([128, 8192] * Hq, dtype=torch.int32, device=device)
+    ms = event_time_ms(lambda i: token_streaming_attn_func(q, k, v, cu, cu, hm, si, L, L), iters=2, warm=1)
+    win = 128 + 8192
+    flops = 4.0 * D * (Hq // 2) * (L * L / 2 + L * win - win * win / 2)
+    out["prefill_attention_one_layer"] = {"ms": round(ms, 1), "tflops": round(flops / ms * 1e-9, 1),
+                                          "frac_of_fp16_mfma_peak": round(flops / ms * 1e-9 / 2500.0, 3)}
+    return out
+
+
 def cpu_baseline(cfg, batch):
     """Oracle port of one decoder layer's four per-channel W4A8 GEMMs at M=batch on the host cores
     (unpack once, untimed; timed: torch._int_mm + the fp32 epilogue), extrapolated to a step."""
@@ -173,6 +215,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="reference call sequence (no fused extension kernels)")
     ap.add_argument("--fused-level", type=int, default=2, help="0 reference sequence, 1 fused add+norm / silu+quant, 2 + deferred split-K epilogue")
+    ap.add_argument("--no-lserve", action="store_true", help="skip the configs[3] (LServe, 256K context) leg")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / gemm_4096 legs")
     ap.add_argument("--tp", action="store_true", help="with N > 1: shard ONE model over the N GPUs (Megatron TP, fp16 "
                     "all-reduce over RCCL after o_proj / down_proj; strong scaling) instead of N replicas")
@@ -247,6 +290,8 @@ def main():
             result["w4a8_gemm_4096"] = gemm_4096(device)
             del runner
             torch.cuda.empty_cache()
+            if not args.no_lserve:
+                result["lserve_ctx256k"] = lserve_leg(device)
             result["cpu_baseline"] = cpu_baseline(cfg, args.batch)
     if dist is not None:
         dist.barrier()

@@ -250,6 +250,15 @@ int omni_kv_page_selector(void* out_f16, const void* q_f16, int64_t q_stride, co
                           int tokens_per_sub_chunk, int padded_sub_chunks, const void* rope_cos_sin_f32,
                           int rope_max_pos, void* stream);
 
+/* Page choice between the selector and the sparse decode attention (torch code upstream,
+ *   omniserve/modeling/layers/decoding_attention.py:132-142): per (sequence, q head) row of selector scores
+ *   (fp16, `subs_per_page` consecutive sub-chunk scores per page, rows `head_stride` elements apart)
+ *   out_i32[row] = the k pages of [0, total_pages-1) with the largest max-over-sub-chunks score, sorted by
+ *   descending score (ties: lower page first), followed by total_pages-1 (the newest page): k+1 entries per row.
+ *   Limits: k <= 1024, total_pages <= 14337 (a 917 K-token history at 64 tokens per page). */
+int omni_select_topk_pages(void* out_i32, const void* scores_f16, int64_t head_stride, int heads_total,
+                           int subs_per_page, int total_pages, int k, void* stream);
+
 /* ---- LServe fine-grained head classes ----------------------------------------
  * Every kv head is a retrieval head (retrieval_head_flags[h] != 0: whole history in the retrieval pool)
  * or a streaming head (sink + local window, kept in a ring of sink_blocks + local_blocks pages of the

@@ -94,3 +94,18 @@ def argmax(out, logits):
     rc = _lib.lib().omni_argmax_f16(out.data_ptr(), logits.data_ptr(), logits.stride(0), logits.shape[0],
                                     logits.shape[1], ws.data_ptr(), ws.numel(), _lib.current_stream())
     _lib.check(rc, "fused_ext.argmax")
+
+
+def select_topk_pages(out, scores, subs_per_page, total_pages, k):
+    """out int32 [B, Hq, k+1] <- the k best pages of [0, total_pages-1) by max-over-sub-chunks selector score (descending),
+    then the newest page: one kernel for the torch view / max / topk / cat / to(int32) sequence of
+    decoding_attention.py:132-142.  scores fp16 [B, Hq, padded_sub_chunks] as single_query_page_selector returns them."""
+    _lib.require_cuda(out, scores)
+    if scores.dtype != torch.float16 or scores.dim() != 3 or not scores.is_contiguous():
+        raise RuntimeError("select_topk_pages: scores must be a contiguous fp16 [B, Hq, sub_chunks] tensor")
+    B, H, _ = scores.shape
+    if out.dtype != torch.int32 or tuple(out.shape) != (B, H, k + 1) or not out.is_contiguous():
+        raise RuntimeError("select_topk_pages: out must be a contiguous int32 [B, Hq, k+1] tensor")
+    rc = _lib.lib().omni_select_topk_pages(out.data_ptr(), scores.data_ptr(), scores.stride(1), B * H,
+                                           int(subs_per_page), int(total_pages), int(k), _lib.current_stream())
+    _lib.check(rc, "fused_ext.select_topk_pages")

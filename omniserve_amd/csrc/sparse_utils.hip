@@ -155,6 +155,153 @@ __global__ __launch_bounds__(256) void kv_page_selector_kernel(SelArgs p) {
 
 using namespace omni;
 
+// ------------------------------------------------------------------------------------------
+// Page choice between the selector and the sparse attention (decoding_attention.py:132-142, torch code upstream):
+// page score = max over the sub-chunks of a page, then the k best pages of [0, total_pages - 1) plus the newest
+// page last.  One workgroup per (sequence, q head): 32-bit keys (orderable fp16 bits << 16 | ~page) in LDS, a
+// 4-pass radix select finds the k-th largest key, the survivors are sorted (descending score, as torch.topk
+// returns them).  Ties go to the lower page index.  torch needs five kernels (~80 us per layer at 4000 pages).
+// ------------------------------------------------------------------------------------------
+constexpr int TOPK_MAX_PAGES = 14336;    // dynamic LDS: 56 KiB of keys (+ 8 KiB static: histograms, survivors)
+constexpr int TOPK_MAX_K = 1024;
+
+__global__ __launch_bounds__(256) void select_topk_pages_kernel(const half_t* __restrict__ scores, int64_t head_stride,
+                                                                int subs, int total_pages, int k,
+                                                                int* __restrict__ out) {
+  // keys live in dynamic LDS; histograms and survivors are separate static objects so that the compiler may batch the
+  // key reads of a loop across the histogram atomics (one LDS round trip per 8 keys instead of one per key)
+  extern __shared__ uint32_t keys[];
+  __shared__ uint32_t hist[4 * 256];
+  __shared__ uint32_t surv[TOPK_MAX_K];
+  __shared__ uint32_t s_prefix, s_remaining, s_count;
+  const int n = total_pages - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const half_t* sc = scores + (size_t)blockIdx.x * head_stride;
+  int* o = out + (size_t)blockIdx.x * (k + 1);
+  auto make_key = [&](half_t m, int p) {
+    uint32_t h = __builtin_bit_cast(uint16_t, m);
+    if (h == 0x8000u) h = 0;
+    const uint32_t k16 = (h & 0x8000u) ? (~h & 0xFFFFu) : (h | 0x8000u);
+    return (k16 << 16) | (uint32_t)(0xFFFF - p);
+  };
+  auto hmax = [](half_t a, half_t b) { return (float)b > (float)a ? b : a; };   // torch.max semantics for finite scores
+  if (subs == 4 && (head_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 7) == 0) {
+    // the launch.sh configuration: one 8-B load per page, eight pages in flight per thread (a loop of dependent
+    // 2-B loads costs one memory round trip per page)
+    typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
+    for (int p0 = tid; p0 < n; p0 += 256 * 8) {
+      v4h_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + 256 * u;
+        v[u] = *reinterpret_cast<const v4h_t*>(sc + (size_t)(p < n ? p : p0) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + 256 * u;
+        if (p < n) keys[p] = make_key(hmax(hmax(v[u][0], v[u][1]), hmax(v[u][2], v[u][3])), p);
+      }
+    }
+  } else {
+    for (int p = tid; p < n; p += 256) {
+      half_t m = sc[(size_t)p * subs];
+      for (int j = 1; j < subs; ++j) m = hmax(m, sc[(size_t)p * subs + j]);
+      keys[p] = make_key(m, p);
+    }
+  }
+  if (tid == 0) { s_prefix = 0; s_remaining = (uint32_t)k; s_count = 0; }
+  __syncthreads();
+  // radix select, most significant byte first: after pass b the k-th largest key starts with s_prefix (b+1 bytes).
+  // One histogram per wave (less contention on the few exponent bins), scanned from the top by one wave.
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) hist[w * 256 + tid] = 0;
+    __syncthreads();
+    const uint32_t prefix = s_prefix;
+    const uint32_t pmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int p0 = tid; p0 < n; p0 += 256 * 8) {
+      uint32_t kk[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) kk[u] = keys[p0 + 256 * u < n ? p0 + 256 * u : p0];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p0 + 256 * u < n && (kk[u] & pmask) == prefix) atomicAdd(&hist[wave * 256 + ((kk[u] >> shift) & 0xFFu)], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {   // lane l owns bins 255-4l .. 252-4l (descending); inclusive scan over the lanes
+      uint32_t c[4], tot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int b = 255 - 4 * lane - j;
+        c[j] = hist[b] + hist[256 + b] + hist[512 + b] + hist[768 + b];
+        tot += c[j];
+      }
+      uint32_t incl = tot;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+      }
+      const uint32_t rem = s_remaining;
+      const unsigned long long reached = __ballot(incl >= rem);
+      const int first = __ffsll((long long)reached) - 1;      // rem <= matching keys, so some lane reaches it
+      if (lane == first) {
+        uint32_t before = incl - tot;
+        int j = 0;
+        for (; j < 3; ++j) {
+          if (before + c[j] >= rem) break;
+          before += c[j];
+        }
+        s_prefix = prefix | ((uint32_t)(255 - 4 * lane - j) << shift);
+        s_remaining = rem - before;
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t kth = s_prefix;      // keys are unique: exactly k keys are >= kth
+  for (int p0 = tid; p0 < n; p0 += 256 * 8) {
+    uint32_t kk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) kk[u] = keys[p0 + 256 * u < n ? p0 + 256 * u : p0];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (p0 + 256 * u < n && kk[u] >= kth) surv[atomicAdd(&s_count, 1u)] = kk[u];
+  }
+  __syncthreads();
+  // rank sort of the k survivors (k <= 1024: k*k/256 compares per thread)
+  for (int i = tid; i < k; i += 256) {
+    const uint32_t key = surv[i];
+    int rank = 0;
+    int j = 0;
+    for (; j + 8 <= k; j += 8) {
+      uint32_t t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = surv[j + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rank += t[u] > key ? 1 : 0;
+    }
+    for (; j < k; ++j) rank += surv[j] > key ? 1 : 0;
+    o[rank] = 0xFFFF - (int)(key & 0xFFFFu);
+  }
+  if (tid == 0) o[k] = total_pages - 1;
+}
+
+extern "C" int omni_select_topk_pages(void* out_i32, const void* scores_f16, int64_t head_stride, int heads_total,
+                                      int subs_per_page, int total_pages, int k, void* stream) {
+  if (!out_i32 || !scores_f16 || heads_total < 0 || subs_per_page < 1 || total_pages < 1 || k < 0) return OMNI_EINVAL;
+  if (k > total_pages - 1 || k > TOPK_MAX_K || total_pages - 1 > TOPK_MAX_PAGES ||
+      head_stride < (int64_t)(total_pages - 1) * subs_per_page)
+    return OMNI_EINVAL;
+  if (heads_total == 0) return OMNI_OK;
+  const size_t lds = (size_t)(total_pages - 1) * sizeof(uint32_t);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)select_topk_pages_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(select_topk_pages_kernel, dim3(heads_total), dim3(256), lds, (hipStream_t)stream,
+                     (const half_t*)scores_f16, head_stride, subs_per_page, total_pages, k, (int*)out_i32);
+  return omni_launch_status();
+}
+
 extern "C" int omni_kv_min_max_pool(const void* k_f16, const void* kv_pointers_i64, const void* cu_seqlens_i32,
                                     const void* pooling_heads_idx_i32, int batch, int max_blocks, int num_input_heads,
                                     int num_pool_heads, int head_dim, int kv_row_bytes, int max_seqlen, int pooling_size,

@@ -1,0 +1,259 @@
+"""Decode-step driver for the LServe configuration of BASELINE.json (configs[3]: Llama-3-8B-1048k, W8A8, long context,
+batch 1, half of the kv heads streaming, dynamic page selection) on one MI355X.
+
+Not an engine: like omniserve_amd/runtime.py it wires the kernels in the order of the reference's decoder layer
+(omniserve/modeling/models/llama_w8a8_unpad.py:276-345,382-427 and omniserve/modeling/layers/decoding_attention.py:
+dynamic_select_topk_pages :88-142, forward_w_dynamic_sparse_per_tensor :239-306 / the fine_grained twin :356-421) on
+synthetic weights and synthetic cache pages, so that the a10-a12 rows of SURVEY.md 8 (and f-2, the per-tensor KV8
+family the reference's published LServe numbers use) are timed end to end:
+
+    rms_norm_general -> qkv W8A8 GEMM -> [every `interval` steps: page selector -> max over sub-chunks -> top-k pages]
+    -> sparse single_query_attention (retrieval heads: selected pages, streaming heads: sink + local ring)
+    -> invoke_quant -> o_proj -> residual add -> rms_norm_general -> gate_up -> silu_and_mul -> invoke_quant -> down
+    -> residual add ... x layers, then rms_norm -> fp16 lm_head -> argmax.
+
+kv_format: "kv8" = per_tensor int8 pages (scripts/lserve_benchmark/launch.sh:6-7), "kv4" = fine_grained KV4 pages
+(BASELINE.json configs[3] as written).  The cache pages are random bytes with sane tails / statistics: the cost of the
+step does not depend on their values.  All calls go through the mirrored `omniserve_backend.*` modules.
+"""
+from __future__ import annotations
+
+import torch
+
+from .backend import (activation_ops, fused_attention_fine_grained_sparse, fused_attention_per_tensor_sparse,
+                      fused_attention_selector, fused_ext, fused_kernels, layernorm_ops, qgemm_w8a8)
+from .rope import rope_table
+from .runtime import LlamaConfig
+
+
+class W8A8Linear:
+    """Synthetic W8A8 weights in the reference layout (w8a8_linear.py:38-60): int8 [N, K] row-major + fp16 scale [N]."""
+
+    def __init__(self, n, k, gen, device):
+        self.n, self.k = n, k
+        self.weight = torch.randint(-127, 128, (n, k), dtype=torch.int8, device=device, generator=gen)
+        self.dequant_scale = (torch.rand((n,), device=device, generator=gen) * 0.0012 + 0.0002).half()
+
+    def forward(self, x_i8, scales, out):
+        qgemm_w8a8.w8a8_gemm_forward_cuda(x_i8, self.weight, self.dequant_scale, scales, out)
+
+    def weight_bytes(self):
+        return self.weight.numel()
+
+
+class LServeDecodeRunner:
+    """One sequence per batch entry with `context` cached tokens; step() decodes one token per sequence."""
+
+    def __init__(self, cfg: LlamaConfig, batch: int, context: int, max_new: int, device, seed=0, kv_format="kv8",
+                 streaming_ratio=0.5, sink=128, local=256, budget_tokens=4096, selector_interval=4,
+                 sub_chunk_per_block=4, use_graph=True, fused=True):
+        """fused: use the opt-in fused entry points (residual add + norm + quant, silu*mul + quant) -- bit-identical to the
+        reference call sequence, three launches fewer per layer."""
+        c = cfg
+        self.cfg, self.B, self.device = cfg, batch, device
+        self.fused = bool(fused)
+        if kv_format not in ("kv8", "kv4"):
+            raise ValueError("kv_format must be 'kv8' (per_tensor) or 'kv4' (fine_grained)")
+        self.kv8 = kv_format == "kv8"
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        d, Hq, Hk = c.head_dim, c.heads, c.kv_heads
+        self.tpb = 64
+        self.sub = self.tpb // sub_chunk_per_block            # tokens per sub-chunk
+        self.interval = int(selector_interval)
+        self.budget_pages = min(max(3, budget_tokens // self.tpb), context // self.tpb + 1)   # <= pages of the history
+        ns = int(round(Hk * streaming_ratio))
+        nr = Hk - ns
+        # alternate head classes like a DuoAttention pattern file would (attn_patterns/*/full_attention_heads.tsv)
+        flags = [1 if (i % 2 == 0 and i // 2 < nr) or (i % 2 == 1 and i // 2 >= ns) else 0 for i in range(Hk)]
+        if sum(flags) != nr:
+            flags = [1] * nr + [0] * ns
+        rank, a, b = [], 0, 0
+        for f in flags:
+            if f:
+                rank.append(a); a += 1
+            else:
+                rank.append(b); b += 1
+        self.nr, self.ns = nr, ns
+        self.flags = torch.tensor(flags, dtype=torch.int32, device=device)
+        self.rank = torch.tensor(rank, dtype=torch.int32, device=device)
+        self.sink, self.local = sink, local
+        self.sink_blocks = (sink + self.tpb - 1) // self.tpb
+        self.local_blocks = local // self.tpb + 1              # attn_config.py:63-64
+        self.row = d if self.kv8 else d // 2                   # bytes of one token row of one head
+        qkv_n = (Hq + 2 * Hk) * d
+        self.layers = []
+        for _ in range(c.layers):
+            self.layers.append(dict(
+                ln1=(1.0 + 0.05 * torch.randn(c.hidden, device=device, generator=gen)).half(),
+                ln2=(1.0 + 0.05 * torch.randn(c.hidden, device=device, generator=gen)).half(),
+                qkv=W8A8Linear(qkv_n, c.hidden, gen, device), o=W8A8Linear(c.hidden, Hq * d, gen, device),
+                gate_up=W8A8Linear(2 * c.inter, c.hidden, gen, device), down=W8A8Linear(c.hidden, c.inter, gen, device)))
+        self.final_norm = torch.ones(c.hidden, device=device).half()
+        self.embed = (0.02 * torch.randn(c.vocab, c.hidden, device=device, generator=gen)).half()
+        self.lm_head = (0.02 * torch.randn(c.vocab, c.hidden, device=device, generator=gen)).half()
+
+        # ---- page pools (cache_engine.py:231-300): retrieval pool (K pages carry min/max statistics) and the
+        # streaming ring, per layer ------------------------------------------------------------------------------
+        self.max_context = context + max_new + 1
+        rpages = (self.max_context + self.tpb - 1) // self.tpb
+        spages = self.sink_blocks + self.local_blocks
+        subs = self.tpb // self.sub
+
+        def pool(n_pages, heads, stats):
+            data = heads * self.tpb * self.row
+            tail = 2 * heads * self.tpb * 2
+            extra = 2 * subs * heads * d * 2 if stats else 0
+            p = torch.empty((n_pages, data + tail + extra), dtype=torch.uint8, device=device)
+            p[:, :data] = torch.randint(0, 256, (n_pages, data), dtype=torch.uint8, device=device, generator=gen)
+            t = p[:, data:data + tail].view(torch.float16).view(n_pages, 2, heads * self.tpb)
+            t[:, 0] = 0.25 * (0.5 + torch.rand((n_pages, heads * self.tpb), device=device, generator=gen))
+            t[:, 1] = 7.5
+            if stats:   # kmax > kmin, magnitudes of post-RoPE keys
+                st = p[:, data + tail:].view(torch.float16).view(n_pages, 2, subs * heads * d)
+                base = torch.randn((n_pages, subs * heads * d), device=device, generator=gen)
+                st[:, 0] = (base + 1.0).half()
+                st[:, 1] = (base - 1.0).half()
+            return p
+
+        def table(kp, vp, n_pages_per_seq):
+            tab = torch.empty((batch, 2, n_pages_per_seq), dtype=torch.int64, device=device)
+            for i, p in enumerate((kp, vp)):
+                perm = torch.randperm(p.shape[0], device=device, generator=gen).view(batch, n_pages_per_seq)
+                tab[:, i] = p.data_ptr() + perm * p.shape[1]
+            return tab
+
+        self.pools, self.retr_tables, self.strm_tables = [], [], []
+        for _ in range(c.layers):
+            rk, rv = pool(batch * rpages, max(nr, 1), True), pool(batch * rpages, max(nr, 1), False)
+            sk, sv = pool(batch * spages, max(ns, 1), False), pool(batch * spages, max(ns, 1), False)
+            self.pools.append((rk, rv, sk, sv))
+            self.retr_tables.append(table(rk, rv, rpages))
+            self.strm_tables.append(table(sk, sv, spages))
+        self.kv_qo = torch.tensor([0.03, 0.035], dtype=torch.float32, device=device)   # kv_scale_quant_orig (K, V)
+        self.kv_oq = (1.0 / self.kv_qo).contiguous()
+
+        B, f16, i8 = batch, torch.float16, torch.int8
+        self.x = torch.empty((B, c.hidden), dtype=f16, device=device)
+        self.q_hidden = torch.empty((B, c.hidden), dtype=i8, device=device)
+        self.q_inter = torch.empty((B, c.inter), dtype=i8, device=device)
+        self.q_attn = torch.empty((B, Hq * d), dtype=i8, device=device)
+        self.act_scale = torch.empty((B,), dtype=f16, device=device)
+        self.act_sum = torch.empty((B,), dtype=f16, device=device)    # by-product of the fused entry points, unused
+        self.qkv_buf = torch.empty((B, qkv_n), dtype=f16, device=device)
+        self.proj_buf = torch.empty((B, c.hidden), dtype=f16, device=device)
+        self.gate_up_buf = torch.empty((B, 2 * c.inter), dtype=f16, device=device)
+        self.mlp_act = torch.empty((B, c.inter), dtype=f16, device=device)
+        self.normed = torch.empty((B, c.hidden), dtype=f16, device=device)
+        self.context0 = context
+        self.lengths = torch.full((B,), context, dtype=torch.int32, device=device)
+        self.tokens = torch.randint(0, c.vocab, (B,), device=device, generator=gen)
+        # cached page selection per layer (decoding_attention.py: cached_dynamic_sparse_page_idx)
+        npick = self.budget_pages
+        self.page_idx = [torch.zeros((B, Hq, npick), dtype=torch.int32, device=device) for _ in range(c.layers)]
+        rope_table(self.max_context + 1, d, c.rope_theta, 1.0, device)
+        self.use_graph = use_graph
+        self.graphs = {}
+        self.steps_done = 0
+
+    # one decode step; `select` = this step refreshes the page selection (every `interval`-th step upstream)
+    def _eager_step(self, hist: int, select: bool):
+        """hist = upper bound of the history length of this step's page bucket (the kernels take the true lengths from
+        `self.lengths`; `hist` only sizes RoPE tables, split plans and the selector's padded output)."""
+        c, B = self.cfg, self.B
+        Hq, Hk, d = c.heads, c.kv_heads, c.head_dim
+        self.lengths.add_(1)
+        torch.index_select(self.embed, 0, self.tokens, out=self.x)
+        sc = self.act_scale
+        attn = fused_attention_per_tensor_sparse if self.kv8 else fused_attention_fine_grained_sparse
+        size_r, size_s = self.nr * self.row, self.ns * self.row
+        total_pages = hist // self.tpb + 1
+        sm = self.act_sum
+        for li, L in enumerate(self.layers):
+            if self.fused and li > 0:     # residual += down_proj(previous layer), then norm + quant
+                fused_ext.add_rms_norm_general_fuse_sum(self.q_hidden, self.x, self.proj_buf, L["ln1"], sm, sc, c.eps)
+            else:
+                layernorm_ops.rms_norm_general(self.q_hidden, self.x, L["ln1"], sc, c.eps, True)
+            L["qkv"].forward(self.q_hidden, sc, self.qkv_buf)
+            q = self.qkv_buf[:, : Hq * d].view(B, Hq, d)
+            k = self.qkv_buf[:, Hq * d:(Hq + Hk) * d].view(B, Hk, d)
+            v = self.qkv_buf[:, (Hq + Hk) * d:].view(B, Hk, d)
+            if select:
+                stats = fused_attention_selector.single_query_page_selector(
+                    q, k, v, self.retr_tables[li], self.strm_tables[li], self.flags, self.rank, None, self.lengths,
+                    None, self.max_context, self.tpb, size_r, size_s, self.sink, self.local, self.sink_blocks,
+                    self.local_blocks, self.nr, self.ns, hist, d, c.rope_theta, 1.0, True, not self.kv8, True,
+                    self.sub, self.nr * d, 1000000)
+                npick = self.budget_pages
+                if self.fused:      # one kernel for the torch view / max / topk / cat / to(int32) sequence
+                    fused_ext.select_topk_pages(self.page_idx[li], stats, self.tpb // self.sub, total_pages, npick - 1)
+                else:
+                    stats = stats.view(B, Hq, -1, self.tpb // self.sub).max(dim=-1).values
+                    _, idx = stats[:, :, : total_pages - 1].topk(k=npick - 1, dim=-1)
+                    self.page_idx[li][:, :, : npick - 1].copy_(idx)
+                    self.page_idx[li][:, :, npick - 1].fill_(total_pages - 1)
+            else:
+                self.page_idx[li][:, :, -1].fill_(total_pages - 1)     # the newest page is always attended
+            common = (self.tpb, size_r, size_s, self.sink, self.local, self.sink_blocks, self.local_blocks, self.nr,
+                      self.ns, hist + 1, d, c.rope_theta, 1.0, True, not self.kv8, not self.kv8, self.sub, self.nr * d,
+                      2048)
+            if self.kv8:
+                out = attn.single_query_attention(q, k, v, self.kv_qo, self.kv_oq, self.retr_tables[li],
+                                                  self.strm_tables[li], self.flags, self.rank, self.page_idx[li],
+                                                  self.lengths, None, self.max_context, *common)
+            else:
+                out = attn.single_query_attention(q, k, v, self.retr_tables[li], self.strm_tables[li], self.flags,
+                                                  self.rank, self.page_idx[li], self.lengths, None, self.max_context,
+                                                  *common)
+            fused_kernels.invoke_quant(self.q_attn, out.view(B, Hq * d), sc)
+            L["o"].forward(self.q_attn, sc, self.proj_buf)
+            if self.fused:
+                fused_ext.add_rms_norm_general_fuse_sum(self.q_hidden, self.x, self.proj_buf, L["ln2"], sm, sc, c.eps)
+            else:
+                self.x.add_(self.proj_buf)
+                layernorm_ops.rms_norm_general(self.q_hidden, self.x, L["ln2"], sc, c.eps, True)
+            L["gate_up"].forward(self.q_hidden, sc, self.gate_up_buf)
+            if self.fused:
+                fused_ext.silu_mul_quant_fuse_sum(self.q_inter, self.gate_up_buf, sm, sc)
+            else:
+                activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
+                fused_kernels.invoke_quant(self.q_inter, self.mlp_act, sc)
+            L["down"].forward(self.q_inter, sc, self.proj_buf)
+            if not self.fused or li == len(self.layers) - 1:
+                self.x.add_(self.proj_buf)
+        layernorm_ops.rms_norm(self.normed, self.x, self.final_norm, c.eps, False)
+        logits = torch.matmul(self.normed, self.lm_head.t())
+        fused_ext.argmax(self.tokens, logits)
+
+    def step(self):
+        """Decode one token.  Two HIP graphs (with / without page selection) per history length bucket: the page
+        count only changes every 64 tokens, and the benchmark runs far fewer steps than that."""
+        bucket = (self.context0 + self.steps_done) // self.tpb
+        hist = (bucket + 1) * self.tpb - 1          # largest history length with the same page count
+        select = self.steps_done % self.interval == 0
+        if not self.use_graph:
+            self._eager_step(hist, select)
+            self.steps_done += 1
+            return
+        key = (bucket, select)
+        g = self.graphs.get(key)
+        if g is None:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                saved = (self.lengths.clone(), self.tokens.clone(), [p.clone() for p in self.page_idx])
+                self._eager_step(hist, select)
+                self.lengths.copy_(saved[0]); self.tokens.copy_(saved[1])
+                for p, q in zip(self.page_idx, saved[2]):
+                    p.copy_(q)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._eager_step(hist, select)
+            self.graphs[key] = g
+            # the capture itself did not execute: replay below does
+        g.replay()
+        self.steps_done += 1
+
+    def weight_bytes_per_step(self):
+        return sum(L[k].weight_bytes() for L in self.layers for k in ("qkv", "o", "gate_up", "down"))

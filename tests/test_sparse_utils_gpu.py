@@ -60,3 +60,31 @@ def test_paged_min_max_pool_and_selector(seq_lens, Hin, pooled):
     torch.cuda.synchronize()
     assert tuple(got.shape) == want.shape
     assert f16_ulp_diff(got, want) <= 2
+
+
+@pytest.mark.parametrize("B,H,pages,subs,k", [(1, 32, 4001, 4, 63), (2, 8, 12, 4, 2), (1, 4, 300, 2, 299), (3, 2, 5000, 1, 1024)])
+def test_select_topk_pages_matches_torch(B, H, pages, subs, k):
+    """fused_ext.select_topk_pages == the torch sequence of decoding_attention.py:132-142 (max over sub-chunks, topk of
+    all pages but the newest, newest page appended); ties may be broken differently, so the chosen SCORES are compared."""
+    from omniserve_amd.backend import fused_ext
+    g = torch.Generator(device="cpu").manual_seed(pages + k)
+    scores = torch.randn((B, H, pages * subs), generator=g).half()
+    scores[0, 0, : 40 * subs] = 1.5                      # a block of ties
+    if H > 1:
+        scores[0, 1].zero_()                             # a streaming head: all zero
+    sd = scores.to(dev())
+    out = torch.empty((B, H, k + 1), dtype=torch.int32, device=dev())
+    fused_ext.select_topk_pages(out, sd, subs, pages, k)
+    torch.cuda.synchronize()
+    page_scores = scores.view(B, H, pages, subs).max(dim=-1).values
+    want_vals, _ = page_scores[:, :, : pages - 1].float().topk(k=k, dim=-1)
+    got = out.cpu().long()
+    assert (got[:, :, k] == pages - 1).all()
+    sel = got[:, :, :k]
+    assert (sel >= 0).all() and (sel < pages - 1).all()
+    assert (sel.sort(dim=-1).values.diff(dim=-1) > 0).all(), "duplicate pages"
+    got_vals = torch.gather(page_scores.float(), 2, sel)
+    assert torch.equal(got_vals, want_vals), "not the top-k scores in descending order"
+    # ties go to the lower page index: the 1.5-block of row (0, 0) comes out in ascending page order
+    tied = [int(p) for p, v in zip(sel[0, 0].tolist(), got_vals[0, 0].tolist()) if v == 1.5]
+    assert tied == sorted(tied)
