@@ -548,6 +548,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   if (owns_cur && tid < DH) vcur[tid] = vcur_r;
   __syncthreads();
 
+  OMNI_CLK(18);
   float scur[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) scur[g] = 0.0f;
@@ -670,6 +671,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       }
     }
   }
+  OMNI_CLK(19);
   // ---- combine the four waves' (max, sum, O); add the current token; normalise / emit partials ----------------
   l_run = rows4_sum(l_run);
   if (l15 < G) {

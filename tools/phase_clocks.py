@@ -39,7 +39,7 @@ show("omni_debug_clocks_elementwise", [(0, "entry"), (1, "inputs loaded, xs writ
 print("quant_v2 (last instance: attention merge or silu):")
 show("omni_debug_clocks_elementwise", [(8, "entry"), (9, "batched fetch done"), (10, "values computed"),
                                         (11, "block max done"), (12, "sum tree done"), (13, "int8 stored")], 8)
-print("kv4_decode_mfma_kernel:")
-show("omni_debug_clocks_kv", [(16, "entry"), (17, "trip 1 done (len, pages, q/k/v, rope coefs)"), (18, "K/V batch 1 landed, RoPE done"),
-                              (19, "pass 1 (QK^T) done"), (20, "softmax done"), (21, "pass 2 (PV) done"),
-                              (22, "partials written")], 16)
+print("kv4_decode_flash_kernel (workgroup 0; every mark drains the memory counters first):")
+show("omni_debug_clocks_kv", [(16, "entry"), (17, "trip 1 done (len, pages, q/k/v, rope coefs)"),
+                              (18, "first K/V batch landed, RoPE(q) in LDS"), (19, "tile sweep done"),
+                              (22, "combine + partials written")], 16)
