@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 O=$PWD/gpurun_out
 R=$PWD
 rm -rf $O/prof_final
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_final -o bench -- python $R/bench.py) 2>&1 | grep -v amdgpu.ids | tail -1 > $O/prof_final_bench_line.json
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_final -o bench -- python $R/bench.py) 2>&1 | grep "^{\"metric\"" | tail -1 > $O/prof_final_bench_line.json
 python - <<'PY'
 import csv, collections
 agg = collections.defaultdict(lambda: [0, 0.0, 1e30, 0.0])
