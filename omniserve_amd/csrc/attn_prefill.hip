@@ -27,7 +27,10 @@ constexpr int PKT = 64;               // keys per tile
 #define OMNI_PREFILL_PQB 1
 #endif
 constexpr int PQB = OMNI_PREFILL_PQB;   // 16-row query blocks per wave
-constexpr int PWAVES = 8 / PQB;         // 8 waves x 16 rows: ~120 VGPRs per wave, 4 waves per SIMD hide the softmax VALU work
+#ifndef OMNI_PREFILL_WAVES
+#define OMNI_PREFILL_WAVES (8 / OMNI_PREFILL_PQB)
+#endif
+constexpr int PWAVES = OMNI_PREFILL_WAVES;         // 8 waves x 16 rows: ~120 VGPRs per wave, 4 waves per SIMD hide the softmax VALU work
 constexpr int PPT = (PKT * 16) / (64 * PWAVES);   // 1-KiB LDS-DMA pieces of a K (or V) tile per wave
 constexpr int PQROWS = 16 * PQB * PWAVES;   // 128 query rows per workgroup
 constexpr int PKROW = 256;            // bytes per key row of the K tile (swizzled slots)
@@ -58,7 +61,7 @@ struct PrefillArgs {
 #ifndef OMNI_PREFILL_MIN_BLOCKS
 #define OMNI_PREFILL_MIN_BLOCKS 2
 #endif
-__global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) __attribute__((amdgpu_waves_per_eu(4 / PQB, 4 / PQB)))
+__global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) __attribute__((amdgpu_waves_per_eu(4 / PQB, 4 / PQB)))   // 128 VGPRs (PQB = 1) or 256 (PQB = 2)
 void prefill_attn_kernel(PrefillArgs p) {
   // four separate LDS objects and a loop body instantiated per buffer parity (static indices): with one array and a
   // runtime buffer index the compiler cannot tell the DMA target from the tile being read and puts vmcnt(0) -- the
