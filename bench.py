@@ -146,7 +146,7 @@ def lserve_leg(device, context=256000, steps=32, warmup=8):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if not torch.isfinite(r.x.float()).all():
-            raise SystemExit("non-finite activations in the LServe decode step")
+            raise RuntimeError("non-finite activations in the LServe decode step")
         out[fmt] = {"decode_tokens_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
                     "gemm_weight_bytes_per_step": r.weight_bytes_per_step()}
         del r
@@ -282,17 +282,25 @@ def main():
                    "gemm_weight_bytes_per_step": runner.gemm_weight_bytes_per_step(),
                    "kv_bytes_per_step": runner.kv_bytes_per_step(args.context)},
     }
+    def leg(name, fn):
+        """An extra leg must never cost the headline line: a failure is reported in place of its object."""
+        try:
+            result[name] = fn()
+        except Exception as exc:   # noqa: BLE001
+            result[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     if rank == 0 and not args.no_extras and not tp:
-        result["protocol"] = protocol_leg(runner, args, elapsed / args.steps)
+        leg("protocol", lambda: protocol_leg(runner, args, elapsed / args.steps))
     if rank == 0 and not args.no_extras:
-        result["roofline"] = roofline_gate_up(runner)
+        leg("roofline", lambda: roofline_gate_up(runner))
         if world == 1:
-            result["w4a8_gemm_4096"] = gemm_4096(device)
+            leg("w4a8_gemm_4096", lambda: gemm_4096(device))
             del runner
             torch.cuda.empty_cache()
             if not args.no_lserve:
-                result["lserve_ctx256k"] = lserve_leg(device)
-            result["cpu_baseline"] = cpu_baseline(cfg, args.batch)
+                leg("lserve_ctx256k", lambda: lserve_leg(device))
+                torch.cuda.empty_cache()
+            leg("cpu_baseline", lambda: cpu_baseline(cfg, args.batch))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
