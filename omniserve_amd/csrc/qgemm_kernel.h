@@ -841,7 +841,11 @@ static int launch_gemm(GemmArgs a, void* ws, size_t ws_bytes, hipStream_t st) {
   }
   a.kslice = pl.kslice;
   if (a.M > 128) {
+#ifdef OMNI_GEMM_TILE_M64
+    launch_variant<MODE, 4, 4>(a, pl, st);
+#else
     launch_variant<MODE, 8, 4>(a, pl, st);
+#endif
   } else {
     switch (pl.mb) {
       case 1: launch_gemv<MODE, 1>(a, pl, st); break;
