@@ -166,6 +166,32 @@ def lserve_leg(device, context=256000, steps=32, warmup=8):
     return out
 
 
+def tp_rank_leg(device, tp=8, batch=128, context=1024, steps=16, warmup=4):
+    """BASELINE.json configs[4] seen from ONE rank: the Llama-2-70B W4A8KV4 decode step of a TP=8 shard (column / row
+    parallel projections, one kv head, M = 128) on this GPU with the two all-reduces per layer skipped (no process group):
+    the compute the RCCL collectives would be overlapped with / added to.  The driver's multi-GPU run uses replicas of
+    configs[1]; `bench.py --gpus 8 --tp` runs the real thing."""
+    from omniserve_amd.runtime import DecodeRunner, LlamaConfig
+    cfg = LlamaConfig.llama2_70b(-1)
+    r = DecodeRunner(cfg, batch, context, steps + warmup + 4, device, seed=3, fused=1, tp_rank=0, tp_size=tp)
+    for _ in range(warmup):
+        r.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    if not torch.isfinite(r.x.float()).all():
+        raise RuntimeError("non-finite activations in the TP-shard decode step")
+    ar_bytes = 2 * cfg.layers * batch * cfg.hidden * 2
+    return {"config": "Llama-2-70B W4A8KV4 per-channel, TP=%d shard (rank 0), bs=%d, context=%d; collectives skipped" % (
+                tp, batch, context),
+            "ms_per_step_compute_only": round(dt * 1e3, 3), "tokens_per_s_if_collectives_were_free": round(batch / dt, 1),
+            "gemm_weight_bytes_per_step": r.gemm_weight_bytes_per_step(),
+            "all_reduce_calls_per_step": 2 * cfg.layers, "all_reduce_payload_bytes_per_step": ar_bytes}
+
+
 def cpu_baseline(cfg, batch):
     """Oracle port of one decoder layer's four per-channel W4A8 GEMMs at M=batch on the host cores
     (unpack once, untimed; timed: torch._int_mm + the fp32 epilogue), extrapolated to a step."""
@@ -299,6 +325,8 @@ def main():
             torch.cuda.empty_cache()
             if not args.no_lserve:
                 leg("lserve_ctx256k", lambda: lserve_leg(device))
+                torch.cuda.empty_cache()
+                leg("llama2_70b_tp8_rank", lambda: tp_rank_leg(device))
                 torch.cuda.empty_cache()
             leg("cpu_baseline", lambda: cpu_baseline(cfg, args.batch))
     if dist is not None:

@@ -43,6 +43,11 @@ class LlamaConfig:
         return LlamaConfig(group_size=group_size)
 
     @staticmethod
+    def llama2_70b(group_size=-1):
+        return LlamaConfig(hidden=8192, inter=28672, heads=64, kv_heads=8, layers=80, vocab=32000, rope_theta=10000.0,
+                           group_size=group_size)
+
+    @staticmethod
     def tiny():
         return LlamaConfig(hidden=512, inter=1024, heads=4, kv_heads=2, layers=2, vocab=512)
 
