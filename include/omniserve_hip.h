@@ -278,6 +278,21 @@ int omni_kv4_prefill_write_fine_grained(
     int sink_tokens, int local_tokens, int sink_blocks, int local_blocks, const void* rope_cos_sin_f32,
     int rope_max_pos, int max_position_embeddings, void* stream);
 
+/* ---- fused extension (nothing upstream): L2 weight prefetch --------------------------
+ * The decode step alternates bandwidth-bound GEMVs with latency-bound row kernels (norm / quant, one workgroup per
+ * token) during which HBM idles.  omni_prefetch_arm_gemm describes the NEXT decode-shape GEMM (M <= 128; mode 0 =
+ * W4A8 per-channel, 1 = per-group, 2 = W8A8; deferred != 0 for omni_w4a8_per_chn_gemm_partial) and arms a one-shot
+ * descriptor: the next decode-size (< 1024 tokens) launch of omni_quant[_fuse_sum], omni_rms_norm_general[_fuse_sum],
+ * omni_add_rms_norm_general_fuse_sum, omni_silu_mul_quant_fuse_sum, omni_splitk_add_rms_norm_general_fuse_sum or
+ * omni_attn_merge_quant_fuse_sum carries `blocks` extra workgroups that pull up to budget_bytes of that GEMM's packed
+ * weights (the head of every wave's weight stream, laid out by the GEMM's own plan) into the XCD-private L2s.
+ * weight == NULL, blocks <= 0 or budget_bytes <= 0 disarms.  A pure performance hint: results never depend on it.
+ * omni_gemm_set_weight_policy(1) makes the decode-shape GEMMs load weights with plain instead of non-temporal
+ * loads (process-wide; 0 restores the default).  Both are evaluated at enqueue time (HIP-graph capturable). */
+int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, int mode, int deferred, int64_t budget_bytes,
+                           int blocks);
+void omni_gemm_set_weight_policy(int policy);
+
 /* omni_kv4_decode_attention_fine_grained replaces
  *   omniserve_backend.fused_attention_fine_grained_dense.single_query_attention
  *     (fused_attention_fine_grained/dense_attention/fused_attention.h:18-46) and, with

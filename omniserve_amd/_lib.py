@@ -23,6 +23,8 @@ PROTOTYPES = {
     "omni_abi_version": (_i, []),
     "omni_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "omni_gemm_set_plan_override": (None, [_i, _i]),
+    "omni_gemm_set_weight_policy": (None, [_i]),
+    "omni_prefetch_arm_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i64, _i]),
     "omni_gemm_get_plan": (None, [_i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     "omni_w4a8_per_chn_gemm": (_i, [_vp] * 7 + [_i, _i, _i, _i64, _vp, _sz, _vp]),
     "omni_w4a8_per_group_gemm": (_i, [_vp] * 7 + [_i, _i, _i, _i64, _vp, _sz, _vp]),
@@ -99,17 +101,21 @@ def require_cuda(*tensors) -> None:
 
 
 _workspaces = {}
+_retired = []     # superseded scratch buffers: captured HIP graphs may still hold their raw pointers
 
 
 def workspace(nbytes: int, device, tag: str = "gemm") -> torch.Tensor:
     """Persistent per-(device, tag) scratch; grows geometrically, never shrinks.
-    (Pre-size it before HIP-graph capture: growing allocates.)"""
+    (Pre-size it before HIP-graph capture: growing allocates.)  A superseded buffer is never released: a HIP graph
+    captured earlier has its address baked in and keeps using it (geometric growth bounds the total at twice the
+    final size)."""
     key = (str(device), tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         size = max(int(nbytes), 1 << 20)
         if buf is not None:
             size = max(size, 2 * buf.numel())
+            _retired.append(buf)
         buf = torch.empty(size, dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf

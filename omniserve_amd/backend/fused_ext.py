@@ -81,6 +81,23 @@ def decode_attention_quant_fuse_sum(out_i8, q, k, v, kv_pointers, lengths, token
     _lib.check(rc, "fused_ext.decode_attention_quant_fuse_sum (merge+quant)")
 
 
+def prefetch_arm_gemm(weight, M, N, K, mode=0, deferred=False, budget_bytes=24 << 20, blocks=240):
+    """Arm the one-shot L2 weight prefetch for the NEXT decode-shape GEMM (include/omniserve_hip.h:
+    omni_prefetch_arm_gemm): the next decode-size quant / norm row kernel launched through this library carries
+    `blocks` extra workgroups that pull up to `budget_bytes` of `weight` into the L2s.  mode: 0 W4A8 per-channel,
+    1 per-group, 2 W8A8.  budget_bytes <= 0 disarms.  A performance hint only."""
+    _lib.require_cuda(weight)
+    rc = _lib.lib().omni_prefetch_arm_gemm(weight.data_ptr(), int(M), int(N), int(K), int(mode), int(bool(deferred)),
+                                           int(budget_bytes), int(blocks))
+    _lib.check(rc, "fused_ext.prefetch_arm_gemm")
+
+
+def set_weight_policy(policy):
+    """0: decode-shape GEMMs stream their weights with non-temporal loads (default); 1: plain loads (for weights a
+    preceding row kernel prefetched into L2).  Process-wide, evaluated at enqueue time."""
+    _lib.lib().omni_gemm_set_weight_policy(int(policy))
+
+
 def argmax(out, logits):
     """out int64 [rows] = torch.argmax(logits fp16 [rows, cols], dim=-1) (first maximum); greedy-sampling helper of the
     decode runner -- the reference's sampler is torch code, this is not one of its kernels."""

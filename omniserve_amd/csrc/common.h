@@ -187,6 +187,51 @@ __device__ __forceinline__ float wave_sum64(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// ---- L2 weight prefetch riding on a latency-bound row kernel (fused extension) -------------------
+// The decode step alternates bandwidth-bound GEMVs with row kernels (norm / quant: 16 workgroups, pure latency
+// chains) during which HBM idles.  A row kernel launched with `blocks` extra workgroups uses them to pull the
+// packed weights of the NEXT GEMV into the XCD-private L2s: the GEMV then finds the head of every wave's weight
+// stream on chip (L2 latency instead of HBM latency) and only streams the rest.  Purely a hint: results never
+// depend on it.  Geometry = the GEMV's own grid: workgroup (x, y) of a gx x gy grid streams `rows_per_wg`
+// consecutive rows (of row_bytes each) starting at row x*rows_per_wg, K-slice y of gy, split over kw waves, i.e.
+// parts [y*kw, (y+1)*kw) of each row; the leading pf_bytes of every part are fetched.  Workgroup id -> XCD is
+// the dispatcher's observed round-robin (id % 8), both for the GEMV's workgroups and for the fetching ones.
+struct PrefetchArgs {
+  const uint8_t* base;
+  long long row_bytes;
+  int rows_per_wg, gx, gy, kw;
+  int pf_bytes;       // multiple of 1024, <= row_bytes / (gy * kw)
+  int blocks;         // extra workgroups (0 = off)
+  int first_block;    // their first blockIdx.x (= number of row workgroups)
+};
+
+// body of a fetching workgroup; `lds_scratch` >= 1 KiB per wave (LDS-DMA target, never read)
+__device__ __forceinline__ void prefetch_weights_to_l2(const PrefetchArgs& pf, void* lds_scratch) {
+  const int b = blockIdx.x;
+  const int xcd = b & 7;
+  const int b0 = pf.first_block + ((xcd - pf.first_block) & 7);        // first fetching workgroup on this XCD
+  const int slot = (b - b0) >> 3;
+  const int nslots = (pf.first_block + pf.blocks - b0 + 7) >> 3;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6, lane = threadIdx.x & 63;
+  const int kib = pf.pf_bytes >> 10;                                   // 1-KiB pieces per part
+  const int segs = pf.rows_per_wg * pf.kw;                             // (row, part) pairs of one GEMV workgroup
+  const long long part_bytes = pf.row_bytes / ((long long)pf.gy * pf.kw);
+  uint8_t* dst = reinterpret_cast<uint8_t*>(lds_scratch) + wave * 1024;
+  const int items = pf.gx * pf.gy;
+  for (int it = xcd + 8 * slot; it < items; it += 8 * nslots) {
+    const int x = it % pf.gx, y = it / pf.gx;
+    const uint8_t* wg = pf.base + (long long)x * pf.rows_per_wg * pf.row_bytes + (long long)y * pf.kw * part_bytes;
+    // piece-major: the first KiB of every part goes first (that is what the GEMV's waves ask for first)
+    for (int u = wave; u < segs * kib; u += nwaves) {
+      const int piece = u / segs, seg = u % segs;
+      const int row = seg / pf.kw, part = seg % pf.kw;
+      lds_dma16(wg + (long long)row * pf.row_bytes + (long long)part * part_bytes + piece * 1024 + lane * 16, dst);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Phase clocks for latency debugging (tools/phase_clocks.py; build with OMNI_HIPCC_EXTRA=-DOMNI_DEBUG_CLOCKS).
 // Workgroup (0,0,0) thread 0 records the 100 MHz wall clock after draining its outstanding memory operations.
 #ifdef OMNI_DEBUG_CLOCKS

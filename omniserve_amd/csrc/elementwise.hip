@@ -3,13 +3,15 @@
 // Replaces omniserve_backend.fused_kernels / layernorm_ops / activation_ops
 // (reference: kernels/csrc/fused_kernels.cu, layernorm_kernels.cu, activation_kernels.cu).
 //
-// The reference's results depend on its reduction geometry (1024 virtual threads per token,
-// thread t accumulating elements t, t+1024, ... sequentially, then a 32-lane butterfly and a
-// butterfly over 32 warp partials; the fuse_sum norm even accumulates per-thread in fp16).
-// These kernels keep that geometry -- one 1024-thread workgroup per token, virtual warp =
-// 32-lane half of a wave64 -- so sums, scales and int8 codes are bit-identical to
-// oracle/elementwise.py.  Each thread keeps its (<= VPT) elements in registers, so the row is
-// read from HBM exactly once instead of the reference's 3-4 passes.
+// The reference's results depend on its reduction geometry (1024 virtual threads per token, thread t
+// accumulating elements t, t+1024, ... sequentially, then a 32-lane butterfly and a butterfly over 32 warp
+// partials; the fuse_sum norm even accumulates per-thread in fp16).  The kernels in use (the "v2" row kernels
+// below) keep that VIRTUAL geometry but run it on 128 / 256 / 512 physical threads per token: element values are
+// computed in parallel, parked as f32 in LDS, and the first NV/8 threads replay the reference's per-virtual-thread
+// accumulation order and reduction tree from there, so sums, scales and int8 codes are bit-identical to
+// oracle/elementwise.py whatever the physical geometry.  The row is read from HBM exactly once instead of the
+// reference's 3-4 passes.  (The first-generation kernels with one 1024-thread workgroup per token remain as the
+// fallback for row lengths the v2 geometry does not cover.)
 #include "common.h"
 
 namespace omni {
@@ -512,9 +514,13 @@ __device__ __forceinline__ void ordered_partials(const float* xs, int p, int nv,
 template <int RT, int RV, bool FUSE_SUM, typename Src>
 __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, Src src0,
                                                        half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
-                                                       int hidden, int nv) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];   // [hidden]
+                                                       int hidden, int nv, PrefetchArgs pf) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // [hidden] (>= RT/64 KiB, see OMNI_V2_LAUNCH)
   __shared__ float red[96];
+  if (pf.blocks > 0 && (int)blockIdx.x >= pf.first_block) {    // extra workgroups: L2 prefetch for the next GEMV
+    prefetch_weights_to_l2(pf, xs);
+    return;
+  }
   const int p = threadIdx.x;
   OMNI_CLK(8);
   const Src src = src0.at_row(blockIdx.x);
@@ -554,13 +560,7 @@ __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, 
   OMNI_CLK(10);
   amax = block_max_rt<RT>(amax, red);   // (its barriers also publish xs)
   OMNI_CLK(11);
-  if constexpr (FUSE_SUM) {
-    float s[1][VT], tot[1];
-    ordered_partials<1>(xs, p, nv, hidden, s, [](float (&v)[1][VT], int e, float val) { v[0][e] = v[0][e] + val; });
-    tree_sum8<1>(s, red, p, nv >> 5, tot);
-    if (p == 0) sum_out[blockIdx.x] = (half_t)tot[0];
-  }
-  OMNI_CLK(12);
+  // the codes only need the maximum: their stores go out first and drain while the ordered sum is replayed
   if (p == 0) scale_out[blockIdx.x] = (half_t)(amax / 127.0f);
   const float q = 127.0f / amax;
   int8_t* orow = out + (size_t)blockIdx.x * hidden;
@@ -569,6 +569,13 @@ __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, 
     const int i = (p + it * RT) * VT;
     if (i < hidden) store8_i8(orow + i, x[it], q);
   }
+  OMNI_CLK(12);
+  if constexpr (FUSE_SUM) {
+    float s[1][VT], tot[1];
+    ordered_partials<1>(xs, p, nv, hidden, s, [](float (&v)[1][VT], int e, float val) { v[0][e] = v[0][e] + val; });
+    tree_sum8<1>(s, red, p, nv >> 5, tot);
+    if (p == 0) sum_out[blockIdx.x] = (half_t)tot[0];
+  }
   OMNI_CLK(13);
 }
 
@@ -576,9 +583,13 @@ __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, 
 template <int RT, int RV, bool FUSE_SUM, typename Src>
 __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict__ out, Src src0, const half_t* __restrict__ gamma,
                                                               half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
-                                                              float eps, int hidden, int nv) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];   // [hidden]
+                                                              float eps, int hidden, int nv, PrefetchArgs pf) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // [hidden] (>= RT/64 KiB, see OMNI_V2_LAUNCH)
   __shared__ float red[96];
+  if (pf.blocks > 0 && (int)blockIdx.x >= pf.first_block) {    // extra workgroups: L2 prefetch for the next GEMV
+    prefetch_weights_to_l2(pf, xs);
+    return;
+  }
   const int p = threadIdx.x;
   OMNI_CLK(0);
   const Src src = src0.at_row(blockIdx.x);
@@ -643,15 +654,7 @@ __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict_
   OMNI_CLK(4);
   const float amax = block_max_rt<RT>(amax_h, red);   // barriers publish the fp16-rounded y in xs
   OMNI_CLK(5);
-  if constexpr (FUSE_SUM) {
-    float hs[1][VT], tot[1];
-    ordered_partials<1>(xs, p, nv, hidden, hs, [](float (&v)[1][VT], int e, float val) {
-      v[0][e] = (float)(half_t)(v[0][e] + val);   // the reference accumulates this sum in fp16
-    });
-    tree_sum8<1>(hs, red, p, nv >> 5, tot);
-    if (p == 0) sum_out[blockIdx.x] = (half_t)tot[0];
-  }
-  OMNI_CLK(6);
+  // the codes only need the maximum: their stores go out first and drain while the fp16 sum is replayed
   if (p == 0) scale_out[blockIdx.x] = (half_t)(amax / 127.0f);
   const float q = 127.0f / amax;
   int8_t* orow = out + (size_t)blockIdx.x * hidden;
@@ -659,6 +662,15 @@ __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict_
   for (int it = 0; it < RV; ++it) {
     const int i = (p + it * RT) * VT;
     if (i < hidden) store8_i8(orow + i, x[it], q);
+  }
+  OMNI_CLK(6);
+  if constexpr (FUSE_SUM) {
+    float hs[1][VT], tot[1];
+    ordered_partials<1>(xs, p, nv, hidden, hs, [](float (&v)[1][VT], int e, float val) {
+      v[0][e] = (float)(half_t)(v[0][e] + val);   // the reference accumulates this sum in fp16
+    });
+    tree_sum8<1>(hs, red, p, nv >> 5, tot);
+    if (p == 0) sum_out[blockIdx.x] = (half_t)tot[0];
   }
   OMNI_CLK(7);
 }
@@ -720,7 +732,17 @@ static inline bool v2_ok(int hidden, int nv) {
 #endif
 constexpr int ROWS_MANY = OMNI_ROWS_MANY;   // from here on the narrow geometries win (measured at 16384 rows)
 // KERNEL(RT, RV) must expand to a kernel instantiation; `hidden` here is the row length that sizes the f32 LDS copy
-#define OMNI_V2_LAUNCH(KERNEL, tokens, hidden, elems, ...)                                                      \
+// One-shot prefetch descriptor (omni_prefetch_arm_gemm, qgemm_plan.hip): consumed by the next v2 quant /
+// general-norm launch.
+PrefetchArgs take_armed_prefetch();
+static inline PrefetchArgs take_prefetch(int tokens) {
+  PrefetchArgs pf = take_armed_prefetch();
+  pf.first_block = tokens;
+  if (tokens >= ROWS_MANY) pf.blocks = 0;    // many-row launches are bandwidth-bound themselves: nothing idles
+  return pf;
+}
+// (kernels without a PrefetchArgs parameter)
+#define OMNI_V2_LAUNCH_PLAIN(KERNEL, tokens, hidden, elems, ...)                                                \
   do {                                                                                                          \
     const size_t lds_ = (size_t)(hidden) * sizeof(float);                                                       \
     if ((tokens) >= ROWS_MANY && (elems) <= 128 * 4 * VT)                                                       \
@@ -729,6 +751,20 @@ constexpr int ROWS_MANY = OMNI_ROWS_MANY;   // from here on the narrow geometrie
       hipLaunchKernelGGL((KERNEL(256, 8)), dim3(tokens), dim3(256), lds_, (hipStream_t)stream, __VA_ARGS__);    \
     else                                                                                                        \
       hipLaunchKernelGGL((KERNEL(512, 4)), dim3(tokens), dim3(512), lds_, (hipStream_t)stream, __VA_ARGS__);    \
+  } while (0)
+// quant / general-norm kernels: the armed prefetch descriptor rides along as extra workgroups (decode-size launches)
+#define OMNI_V2_LAUNCH(KERNEL, tokens, hidden, elems, ...)                                                      \
+  do {                                                                                                          \
+    const PrefetchArgs pf_ = take_prefetch(tokens);                                                             \
+    size_t lds_ = (size_t)(hidden) * sizeof(float);                                                             \
+    if (pf_.blocks > 0 && lds_ < 8 * 1024) lds_ = 8 * 1024;   /* 1 KiB of LDS-DMA target per wave */            \
+    if ((tokens) >= ROWS_MANY && (elems) <= 128 * 4 * VT)                                                       \
+      hipLaunchKernelGGL((KERNEL(128, 4)), dim3(tokens), dim3(128), lds_, (hipStream_t)stream, __VA_ARGS__, pf_);  \
+    else if ((tokens) >= ROWS_MANY && (elems) <= 256 * 8 * VT)                                                  \
+      hipLaunchKernelGGL((KERNEL(256, 8)), dim3(tokens), dim3(256), lds_, (hipStream_t)stream, __VA_ARGS__, pf_);  \
+    else                                                                                                        \
+      hipLaunchKernelGGL((KERNEL(512, 4)), dim3((tokens) + pf_.blocks), dim3(512), lds_, (hipStream_t)stream,   \
+                         __VA_ARGS__, pf_);                                                                     \
   } while (0)
 
 static inline int norm_block(int hidden, bool round32) {
@@ -789,8 +825,8 @@ extern "C" int omni_rms_norm(void* out_f16, const void* in_f16, const void* weig
     if (v2_ok(hidden, nv)) {
       #undef KQ_
       #define KQ_(RT_, RV_) rms_norm_v2_kernel<RT_, RV_>
-      OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (half_t*)out_f16, (const half_t*)in_f16,
-                     (const half_t*)weight_f16, eps, hidden, nv);
+      OMNI_V2_LAUNCH_PLAIN(KQ_, tokens, hidden, hidden, (half_t*)out_f16, (const half_t*)in_f16,
+                           (const half_t*)weight_f16, eps, hidden, nv);
       return omni_launch_status();
     }
   }

@@ -426,6 +426,11 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   half_t vcur_r = (half_t)0.0f;
   if (tid < DH) vcur_r = p.v[(size_t)b * p.kv_stride + (size_t)hk * DH + tid];
 
+  // (sparse) the last selected page is the newest one: requested with trip 1, it bounds the attended tokens below
+  int dyn_last = 0;
+  if constexpr (FG) {
+    if (dyn) dyn_last = dyn[p.fg.num_dyn - 1];
+  }
   const int tlen = p.lengths[b] - 1;
   int nvirt = tlen, gap = 0;   // attended cached tokens; streaming: virtual i >= sink is token i + gap
   if constexpr (FG) {
@@ -433,7 +438,16 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       nvirt = min(p.fg.sink + p.fg.local - 1, tlen);
       gap = tlen - nvirt;
     } else if (dyn) {
-      nvirt = tlen > 0 ? (p.fg.num_dyn - 1) * lay.tpb + ((tlen - 1) & (lay.tpb - 1)) + 1 : 0;
+      // Upstream counts (tlen-1) % tpb + 1 tokens for the last selected page (sparse_attention/...Template.hpp:1568)
+      // while its Python layer passes the page of the CURRENT token there (decoding_attention.py:132-142:
+      // total_page_num - 1 = timestep // tokens_per_block): when tlen % tpb == 0 that page holds no cached token
+      // yet, and upstream then exponentiates score slots it never wrote (:1737-1744 vs :1962).  Here the last
+      // page contributes the cached tokens it really holds, clamp(tlen - page * tpb, 0, tpb): identical to
+      // upstream's count whenever that is defined, 0 on the boundary step (nothing unwritten is read, no race
+      // with the append of the current token into slot 0).
+      int in_last = tlen - (dyn_last << lay.tpb_log2);
+      in_last = in_last < 0 ? 0 : (in_last > lay.tpb ? lay.tpb : in_last);
+      nvirt = (p.fg.num_dyn - 1) * lay.tpb + in_last;
     }
   }
   const int t0 = min(nvirt, vt0);

@@ -427,25 +427,29 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
 //     of round r, -> LDS (in the weights' k order, double buffered) at its end.  On-GPU ablation
 //     (tools/gemv_probe.hip, profiles/) showed that staging the whole K-slice up front costs up to
 //     2x on this kernel, while the stream + unpack + LDS reads + MFMA alone run at the plain-copy rate;
-//   * M <= 16 uses single-wave workgroups (finest scheduling granule, no barrier at all); larger M
-//     shares the staged activations between 2 or 4 waves (one barrier per round).
+//   * single-wave tiles (finest scheduling granule, no barrier inside the K loop) of 16 / 32 / 64 rows; M = 65..128 is
+//     two 64-row tiles per channel group (grid.z).
 //   * no control flow inside a round, so every wait is a counted s_waitcnt vmcnt(N).
 // ------------------------------------------------------------------------------------------
 template <int MB, int MODE>
 struct GemvCfg {
   static constexpr int WL = (MODE == MODE_W8) ? 4 : 2;
   static constexpr int RING = (MODE == MODE_W8) ? 4 : (MB <= 2 ? 8 : 4);
-  // M <= 64: single-wave tiles (no barrier; K is split over the workgroup's KW waves instead); M <= 128 keeps four
-  // channel groups per workgroup sharing the staged activations (a 128-row round is 32 KiB of LDS)
-  static constexpr int WAVES = MB == 8 ? 4 : 1;
-  static constexpr int MAX_KW = MB == 1 ? 4 : (MB == 8 ? 1 : 2);   // LDS: KW x 2 buffers x MT x RK <= 64 KiB
+  // single-wave tiles of up to 64 rows (no barrier; K is split over the workgroup's KW waves instead).  M = 65..128
+  // runs as two 64-row tiles per channel group (grid.z = 2): the second read of the packed weights is served by
+  // L2 / MALL.  (Round 1 had a 128-row tile here -- four channel groups per workgroup sharing a 32-KiB activation
+  // round, 128 accumulator registers per wave spilling into AGPRs, an 8-KiB weight ring: 0.6 TB/s; removed.)
+  static constexpr int WAVES = 1;
+  static constexpr int MAX_KW = MB == 1 ? 4 : 2;   // LDS: KW x 2 buffers x MT x RK <= 64 KiB
 };
 
 //   * KW > 1 (single 64-channel group per workgroup only): KW waves split the workgroup's K-slice,
 //     each streaming its own part with its own LDS buffers and no barrier; the int32 partials meet in
 //     LDS at the end and wave w finishes the 4/KW row blocks it owns.  More waves in flight per CU
 //     without the slab round trip of a grid-level split.
-template <int MB, int MODE, bool TO_SLAB, int KW = 1>
+// NT: weight loads carry the non-temporal hint (weights streamed once from HBM, the default); false = plain loads,
+// for weights a preceding row kernel has prefetched into the L2s (omni_prefetch_arm_gemm, omni_gemm_set_weight_policy).
+template <int MB, int MODE, bool TO_SLAB, int KW = 1, bool NT = true>
 __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_gemv_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
   constexpr int WAVES = GemvCfg<MB, MODE>::WAVES;
@@ -466,6 +470,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_
   const int tid = KW > 1 ? lane : threadIdx.x;            // index inside the staging group
   uint8_t (*lds)[MT * RK] = lds_all[kw];
   const int ng = KW > 1 ? blockIdx.x : blockIdx.x * WAVES + wave;
+  const int m0 = blockIdx.z * MT;                        // row tile (grid.z > 1 only for M > 64)
   const bool wave_active = (ng * 64) < p.N;
   const int kpart = p.kslice / KW;                        // host: kslice % (64 * KW) == 0 when KW > 1
   const int k_begin = blockIdx.y * p.kslice + kw * kpart;
@@ -483,7 +488,9 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_
     const uint8_t* ptr;
     if constexpr (MODE == MODE_W8) ptr = wbase + (size_t)j * 16 * p.K + k;
     else ptr = wbase + (size_t)(k / 32 + j) * 512;
-    const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(ptr));
+    v4i v;
+    if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(ptr));
+    else v = *reinterpret_cast<const v4i*>(ptr);
     return make_uint4((uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
   };
   const size_t gcol = (size_t)(2 * ngc + lx) * 32 + lc * 4;  // per-group param column of this lane
@@ -512,7 +519,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_
     for (int j = 0; j < APT; ++j) {
       int m, kk;
       piece(j, m, kk);
-      const int mc = m < p.M ? m : p.M - 1;  // rows >= M re-read the last row (results never stored)
+      const int mc = m0 + m < p.M ? m0 + m : p.M - 1;  // rows >= M re-read the last row (results never stored)
       areg[j] = *reinterpret_cast<const uint4*>(p.A + (size_t)mc * p.K + kr + kk * 16);
     }
   };
@@ -563,7 +570,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const int m = mb * 16 + mcol;
+      const int m = m0 + mb * 16 + mcol;
       const int mc = m < p.M ? m : p.M - 1;
       sav[mb] = p.ascales[mc];
       if constexpr (MODE == MODE_CHN) asv[mb] = p.asum[mc];
@@ -657,7 +664,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_
     if constexpr (WAVES > 1) __syncthreads();
     for (int id = tid; id < MT * 4; id += NTHREADS) {
       const int m = id >> 2, kk = id & 3;
-      const int mc = m < p.M ? m : p.M - 1;
+      const int mc = m0 + m < p.M ? m0 + m : p.M - 1;
       const uint4 a = *reinterpret_cast<const uint4*>(p.A + (size_t)mc * p.K + kn + kk * 16);
       if constexpr (MODE == MODE_W8) {
         *reinterpret_cast<uint4*>(&lds[0][m * 64 + kk * 16]) = a;
@@ -697,7 +704,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_
   }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const int m = mb * 16 + mcol;
+    const int m = m0 + mb * 16 + mcol;
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) {
       if ((ab / ABW) != kw) continue;          // row block finished by another wave of the workgroup
@@ -771,7 +778,8 @@ struct GemmPlan {
   int waves;   // waves (64-channel groups) per workgroup
   int sk;      // K splits (grid level, int32 slabs)
   int kslice;  // k per split
-  int kw;      // K parts inside a workgroup (decode kernel, M <= 16)
+  int kw;      // K parts inside a workgroup (decode kernel)
+  int mz;      // row tiles (grid.z) of the decode kernel: 2 for M = 65..128
 };
 
 // Tuning hook (tests / bench sweeps): waves<=0 and sk<=0 restore the heuristic.
@@ -795,27 +803,35 @@ static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st
   hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, false>), grid, dim3(64 * WAVES), 0, st, b);
 }
 
-template <int MODE, int MB, bool TO_SLAB>
-static void launch_gemv_kernel(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
+extern int g_weight_policy;   // qgemm_plan.hip (omni_gemm_set_weight_policy)
+
+template <int MODE, int MB, bool TO_SLAB, bool NT>
+static void launch_gemv_kernel_nt(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
   constexpr int WAVES = GemvCfg<MB, MODE>::WAVES;
-  dim3 grid((a.N / 64 + WAVES - 1) / WAVES, pl.sk, 1);
+  dim3 grid((a.N / 64 + WAVES - 1) / WAVES, pl.sk, pl.mz);
   if constexpr (MB == 1) {
     if (pl.kw == 4) {
-      hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, TO_SLAB, 4>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, TO_SLAB, 4, NT>), grid, dim3(256), 0, st, a);
       return;
     }
     if (pl.kw == 2) {
-      hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, TO_SLAB, 2>), grid, dim3(128), 0, st, a);
+      hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, TO_SLAB, 2, NT>), grid, dim3(128), 0, st, a);
       return;
     }
   }
   if constexpr (MB == 2 || MB == 4) {
     if (pl.kw == 2) {
-      hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 2>), grid, dim3(128), 0, st, a);
+      hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 2, NT>), grid, dim3(128), 0, st, a);
       return;
     }
   }
-  hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 1>), grid, dim3(64 * WAVES), 0, st, a);
+  hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 1, NT>), grid, dim3(64 * WAVES), 0, st, a);
+}
+
+template <int MODE, int MB, bool TO_SLAB>
+static void launch_gemv_kernel(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
+  if (g_weight_policy == 1) launch_gemv_kernel_nt<MODE, MB, TO_SLAB, false>(a, pl, st);
+  else launch_gemv_kernel_nt<MODE, MB, TO_SLAB, true>(a, pl, st);
 }
 
 template <int MODE, int MB>
@@ -850,8 +866,7 @@ static int launch_gemm(GemmArgs a, void* ws, size_t ws_bytes, hipStream_t st) {
     switch (pl.mb) {
       case 1: launch_gemv<MODE, 1>(a, pl, st); break;
       case 2: launch_gemv<MODE, 2>(a, pl, st); break;
-      case 4: launch_gemv<MODE, 4>(a, pl, st); break;
-      default: launch_gemv<MODE, 8>(a, pl, st); break;
+      default: launch_gemv<MODE, 4>(a, pl, st); break;
     }
   }
   return omni_launch_status();
@@ -870,8 +885,7 @@ static int launch_gemm_partial(GemmArgs a, void* slab, size_t slab_bytes, int* s
   switch (pl.mb) {
     case 1: launch_gemv_kernel<MODE, 1, true>(a, pl, st); break;
     case 2: launch_gemv_kernel<MODE, 2, true>(a, pl, st); break;
-    case 4: launch_gemv_kernel<MODE, 4, true>(a, pl, st); break;
-    default: launch_gemv_kernel<MODE, 8, true>(a, pl, st); break;
+    default: launch_gemv_kernel<MODE, 4, true>(a, pl, st); break;
   }
   *sk_out = pl.sk;
   return omni_launch_status();

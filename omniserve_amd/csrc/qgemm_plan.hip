@@ -5,20 +5,29 @@ namespace omni {
 
 static int g_override_waves = 0;
 static int g_override_sk = 0;
+int g_weight_policy = 0;             // 0: non-temporal weight loads (streamed once), 1: plain loads (L2-prefetched weights)
+static PrefetchArgs g_armed_prefetch = {};
+
+PrefetchArgs take_armed_prefetch() {
+  PrefetchArgs pf = g_armed_prefetch;
+  g_armed_prefetch = PrefetchArgs{};
+  return pf;
+}
 
 GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred) {
   GemmPlan pl;
   pl.kw = 1;
+  pl.mz = 1;
   if (M > 128) {  // MFMA-bound regime: 128 x 256 tile per workgroup, no split
     pl.mb = 8; pl.waves = 4; pl.sk = 1; pl.kslice = K;
     return pl;
   }
   // bandwidth-bound regime (decode): every CU must stream weights.  One wave owns 64 channels
   // and a K-slice; activations are staged per round of RING steps, so the slice length is free.
-  pl.mb = M <= 16 ? 1 : (M <= 32 ? 2 : (M <= 64 ? 4 : 8));
-  pl.waves = pl.mb == 8 ? 4 : 1;   // fixed per tile height (GemvCfg)
+  pl.mb = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+  pl.mz = M <= 64 ? 1 : 2;         // M = 65..128: two 64-row tiles per channel group
+  pl.waves = 1;                    // fixed per tile height (GemvCfg)
   const int ngroups = N / 64;
-  const int round_k = (pl.mb <= 2 ? 8 : 4) * 64;     // k per ring round (W8A8 uses 4 x 64 <= this)
   auto ok = [&](int s) { return s >= 1 && (K % s) == 0 && ((K / s) % kalign) == 0; };
   int sk = 1;
   if (pl.mb == 1) {
@@ -45,10 +54,11 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred) {
     if (g_override_waves == 1 || g_override_waves == 2 || g_override_waves == 4) kw = g_override_waves;
     while (kw > 1 && ((K / sk) % (kw * kalign)) != 0) kw >>= 1;
     pl.kw = kw;
-  } else if (pl.mb <= 4) {
-    // 16 < M <= 64: single-wave tiles of MB*16 rows, two K parts per workgroup; split across workgroups until a
-    // wave streams <= 2048 k (a wave keeps only RING x 2 KiB in flight, so short parts = more bytes in flight)
-    pl.waves = 1;
+  } else {
+    // 16 < M <= 128: single-wave tiles of MB*16 rows, two K parts per workgroup; split across workgroups until a
+    // wave streams <= 2048 k (a wave keeps only RING x 2 KiB in flight, so short parts = more bytes in flight).
+    // M > 64 (two row tiles, long kernels: the slab epilogue is cheap next to them) keeps splitting, down to
+    // 512 k per wave, until ~1.5 workgroups per CU are in flight.
     int kw = 2;
     while (kw > 1 && (K % (kw * kalign)) != 0) kw >>= 1;
     auto fits = [&](int s) { return ok(s) && ((K / s) % (kw * kalign)) == 0; };
@@ -56,23 +66,13 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred) {
     for (int s = 1; s <= 64; ++s) {
       if (!fits(s) || K / (s * kw) < 512) continue;
       best = s;
-      if (K / (s * kw) <= 2048) break;
+      if (K / (s * kw) <= 2048 && (pl.mz == 1 || ngroups * s * pl.mz >= 384)) break;
     }
     sk = best;
     if (g_override_sk > 0 && ok(g_override_sk)) sk = g_override_sk;
     if (g_override_waves == 1 || g_override_waves == 2) kw = g_override_waves;
     while (kw > 1 && ((K / sk) % (kw * kalign)) != 0) kw >>= 1;
     pl.kw = kw;
-  } else {
-    auto full_rounds = [&](int s) { return ((K / s) % round_k) == 0; };
-    // M <= 128: four channel groups per workgroup share the staged activations; split K until ~2 waves per CU
-    const int target_waves = 448;
-    for (int s = 1; s <= 64 && ngroups * sk < target_waves; ++s) {
-      if (!ok(s) || (K / s) < round_k) continue;
-      if (!full_rounds(s) && full_rounds(sk)) continue;
-      sk = s;
-    }
-    if (g_override_sk > 0 && ok(g_override_sk)) sk = g_override_sk;
   }
   pl.sk = sk;
   pl.kslice = K / sk;
@@ -95,10 +95,48 @@ extern "C" void omni_gemm_get_plan(int M, int N, int K, int kalign, int* mb, int
 
 extern "C" size_t omni_gemm_workspace_bytes(int M, int N, int K) {
   if (M < 1 || N < 64 || K < 64 || M > 128) return 0;   // M > 128: no split, no scratch
-  // upper bound over the three GEMM flavours (per-group needs 128-aligned slices, so never more splits)
-  // the deferred (slab-only) plan never splits less than the plain one
-  omni::GemmPlan pl = omni::plan_gemm(M, N, K, 64, true);
-  return (size_t)pl.sk * M * N * sizeof(int32_t);
+  // sized from the very plans the launches use: the maximum over the K alignments of the three GEMM flavours
+  // (64; 128 for per-group) and over the plain / deferred (slab-only) variants
+  int sk = 1;
+  for (int kalign = 64; kalign <= 128; kalign *= 2) {
+    if (K % kalign != 0) continue;
+    for (int deferred = 0; deferred < 2; ++deferred) {
+      const omni::GemmPlan pl = omni::plan_gemm(M, N, K, kalign, deferred != 0);
+      if (pl.sk > sk) sk = pl.sk;
+    }
+  }
+  return (size_t)sk * M * N * sizeof(int32_t);
 }
 
-extern "C" int omni_abi_version(void) { return 1; }
+// ---- fused extension: L2 weight prefetch riding on the next row kernel (common.h: PrefetchArgs) -------------------
+extern "C" void omni_gemm_set_weight_policy(int policy) { omni::g_weight_policy = policy == 1 ? 1 : 0; }
+
+extern "C" int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, int mode, int deferred,
+                                      int64_t budget_bytes, int blocks) {
+  using namespace omni;
+  g_armed_prefetch = PrefetchArgs{};
+  if (!weight || blocks <= 0 || budget_bytes <= 0) return OMNI_OK;          // disarm
+  if (mode < 0 || mode > 2 || M < 1 || M > 128 || N % 64 != 0 || K % 64 != 0 || K < 64) return OMNI_EINVAL;
+  const GemmPlan pl = plan_gemm(M, N, K, mode == MODE_GRP ? 128 : 64, deferred != 0);
+  PrefetchArgs pf{};
+  pf.base = static_cast<const uint8_t*>(weight);
+  const int groups_per_wg = pl.waves;                                       // 64-channel groups per workgroup
+  pf.gx = (N / 64 + groups_per_wg - 1) / groups_per_wg;
+  pf.gy = pl.sk;
+  pf.kw = pl.kw;
+  if (mode == MODE_W8) { pf.row_bytes = K; pf.rows_per_wg = 64 * groups_per_wg; }
+  else { pf.row_bytes = (long long)K * 16; pf.rows_per_wg = 2 * groups_per_wg; }
+  if ((N / 64) % groups_per_wg != 0) return OMNI_OK;                         // ragged last workgroup: skip the hint
+  const long long part_bytes = pf.row_bytes / ((long long)pf.gy * pf.kw);
+  const long long total = pf.row_bytes * pf.rows_per_wg * pf.gx;
+  long long want = part_bytes;
+  if (total > budget_bytes) want = (long long)((double)part_bytes * (double)budget_bytes / (double)total);
+  want = (want / 1024) * 1024;
+  if (want < 1024 || part_bytes < 1024) return OMNI_OK;                      // parts too small for 1-KiB pieces: skip
+  pf.pf_bytes = (int)want;
+  pf.blocks = (blocks + 7) & ~7;
+  g_armed_prefetch = pf;
+  return OMNI_OK;
+}
+
+extern "C" int omni_abi_version(void) { return 2; }

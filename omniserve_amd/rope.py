@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 _cache = {}
+_retired = []     # superseded tables stay allocated: captured HIP graphs hold their raw pointers
 
 
 def build_table_numpy(max_pos: int, dim: int, base: float, scale: float = 1.0) -> np.ndarray:
@@ -33,6 +34,8 @@ def rope_table(max_pos: int, dim: int, base: float, scale: float, device) -> tor
         rows = 4096
         while rows < max_pos:
             rows *= 2
+        if t is not None:
+            _retired.append(t)
         t = torch.from_numpy(build_table_numpy(rows, dim, base, scale)).to(device)
         _cache[key] = t
     return t

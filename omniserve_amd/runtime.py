@@ -119,7 +119,8 @@ class DecodeRunner:
     """bs sequences with `context` cached tokens each; step() decodes one token per sequence."""
 
     def __init__(self, cfg: LlamaConfig, batch: int, context: int, max_new: int, device, seed=0,
-                 use_graph=True, fused=True, tp_rank=0, tp_size=1, tp_group=None, shard_full=False):
+                 use_graph=True, fused=True, tp_rank=0, tp_size=1, tp_group=None, shard_full=False,
+                 prefetch_mb=None, prefetch_blocks=240, weight_policy=None):
         """tp_size > 1: Megatron-style tensor parallelism (omniserve_amd/tp.py): qkv / gate_up column-parallel,
         o / down row-parallel, attention by kv head, one fp16 sum all-reduce of the [B, hidden] projection after
         o_proj and after down_proj.  shard_full=True builds the full layers from the seed and keeps this
@@ -137,6 +138,18 @@ class DecodeRunner:
         self.fused = 2 if fused is True else int(fused)
         if (cfg.group_size != -1 or self.tp_size > 1) and self.fused > 1:
             self.fused = 1   # the deferred epilogue exists for the per-channel GEMM only; TP all-reduces fp16
+        # L2 weight prefetch riding on the row kernels (fused extension; a hint, results are unaffected): MiB of the
+        # next GEMV's weights each row kernel pulls into the L2s (0 = off), with how many extra workgroups, and
+        # whether the GEMVs then use plain instead of non-temporal weight loads.  Defaults: on with the fused
+        # entry points (environment overrides for sweeps: OMNI_PREFETCH_MB, OMNI_PREFETCH_BLOCKS, OMNI_WEIGHT_POLICY).
+        import os
+        if prefetch_mb is None:
+            prefetch_mb = float(os.environ.get("OMNI_PREFETCH_MB", "24")) if self.fused else 0.0
+        self.prefetch_bytes = int(float(prefetch_mb) * (1 << 20)) if self.fused else 0
+        self.prefetch_blocks = int(os.environ.get("OMNI_PREFETCH_BLOCKS", prefetch_blocks))
+        if weight_policy is None:
+            weight_policy = int(os.environ.get("OMNI_WEIGHT_POLICY", "1"))
+        self.weight_policy = int(weight_policy) if self.prefetch_bytes > 0 else 0
         c = cfg
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
@@ -238,7 +251,20 @@ class DecodeRunner:
         self.graph.replay()
         self.steps_done += 1
 
+    def _arm(self, lin, deferred=False):
+        """The next row kernel prefetches the head of `lin`'s weight stream into the L2s (no-op when disabled)."""
+        if self.prefetch_bytes > 0:
+            fused_ext.prefetch_arm_gemm(lin.qweight, self.B, lin.n, lin.k, 0 if lin.group == -1 else 1, deferred,
+                                        self.prefetch_bytes, self.prefetch_blocks)
+
     def _eager_step(self):
+        fused_ext.set_weight_policy(self.weight_policy)
+        try:
+            self._eager_step_body()
+        finally:
+            fused_ext.set_weight_policy(0)
+
+    def _eager_step_body(self):
         # one decoder layer at decode shape = llama_w4a8_unpad.py:406-438
         c = self.cfg
         self.lengths.add_(1)
@@ -251,6 +277,7 @@ class DecodeRunner:
         nl = len(self.layers)
         for li, L in enumerate(self.layers):
             qa_h, qa_i = self._q_hidden, self._q_inter
+            self._arm(L["qkv"])
             if pending is not None:     # residual += down_proj(prev layer) [deferred epilogue], norm + quant
                 sk, lin = pending
                 fused_ext.splitk_add_rms_norm_general_fuse_sum(qa_h, self.x, self.slab, sk, lin.s1_scales, sA,
@@ -264,6 +291,7 @@ class DecodeRunner:
             q = self.qkv_buf[:, : hq * d].view(B, hq, d)
             k = self.qkv_buf[:, hq * d:(hq + hk) * d].view(B, hk, d)
             v = self.qkv_buf[:, (hq + hk) * d:].view(B, hk, d)
+            self._arm(L["o"], deferred=self.fused >= 2)      # rides on the quantiser after the attention
             if self.fused >= 2:     # attention with its split merge fused into the activation quant
                 fused_ext.decode_attention_quant_fuse_sum(self._q_attn, q, k, v, self.block_tables[li], self.lengths,
                                                           self.tpb, self.max_context, c.rope_theta, mA, sA)
@@ -274,17 +302,20 @@ class DecodeRunner:
                 fused_kernels.invoke_quant_fuse_sum(self._q_attn, attn.view(B, hq * d), mA, sA)
             if self.fused >= 2:
                 sk = fused_ext.gemm_partial_per_chn(self._q_attn, L["o"].qweight, self.slab)
+                self._arm(L["gate_up"])
                 fused_ext.splitk_add_rms_norm_general_fuse_sum(qa_h, self.x, self.slab, sk, L["o"].s1_scales, sA,
                                                                L["o"].s1_szeros, mA, L["ln2"], mB, sB, c.eps)
             else:
                 L["o"].forward(self._q_attn, sA, mA, self.proj_buf)
                 self._all_reduce(self.proj_buf)
+                self._arm(L["gate_up"])
                 if self.fused:
                     fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln2"], mB, sB, c.eps)
                 else:
                     self.x.add_(self.proj_buf)
                     layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln2"], mB, sB, c.eps, True)
             L["gate_up"].forward(qa_h, sB, mB, self.gate_up_buf)
+            self._arm(L["down"], deferred=self.fused >= 2 and li < nl - 1)
             if self.fused:
                 fused_ext.silu_mul_quant_fuse_sum(qa_i, self.gate_up_buf, mA, sA)
             else:

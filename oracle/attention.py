@@ -41,3 +41,49 @@ def varlen_attention(q, k, v, cu_q, cu_k, causal=True, head_mask_type=None, stre
             o = (p @ v[k0:k1, h // g].astype(np.float64)) / p.sum(axis=1, keepdims=True)
             out[q0:q1, h] = o.astype(np.float16)
     return out
+
+
+def varlen_attention_rows(q, k, v, cu_q, cu_k, rows, causal=True, head_mask_type=None, streaming_info=None,
+                          heads=None, chunk=256):
+    """The same reference restricted to the global query rows `rows` (sorted int array) and the q heads `heads`
+    (default: all) -> fp16 [len(rows), len(heads), D].  Evaluated chunk by chunk over the query rows and, for a
+    Lambda-masked head, only over the keys the mask lets through, so that long sequences (L = 16K ... 64K) stay
+    within seconds and a few hundred MB of host memory: the tests compare a dense sample of rows of a long case."""
+    q = np.asarray(q, np.float16); k = np.asarray(k, np.float16); v = np.asarray(v, np.float16)
+    rows = np.asarray(rows, np.int64)
+    Lq, Hq, D = q.shape
+    g = Hq // k.shape[1]
+    heads = list(range(Hq)) if heads is None else list(heads)
+    out = np.zeros((len(rows), len(heads), D), np.float16)
+    scale = 1.0 / np.sqrt(D)
+    seq_of = np.searchsorted(np.asarray(cu_q, np.int64), rows, side="right") - 1
+    for b in np.unique(seq_of):
+        q0, q1, k0, k1 = int(cu_q[b]), int(cu_q[b + 1]), int(cu_k[b]), int(cu_k[b + 1])
+        off = (k1 - k0) - (q1 - q0)
+        sel = np.nonzero(seq_of == b)[0]
+        for c0 in range(0, len(sel), chunk):
+            idx = sel[c0:c0 + chunk]
+            qi = (rows[idx] - q0 + off)[:, None]                     # key position a query may look back from
+            hi = int(qi.max()) + 1 if causal else (k1 - k0)
+            for hn, h in enumerate(heads):
+                streaming = head_mask_type is not None and int(head_mask_type[h]) < 0
+                if streaming:
+                    sink, local = int(streaming_info[2 * h]), int(streaming_info[2 * h + 1])
+                    lo = max(min(sink, hi), int(qi.min()) - local + 1)
+                    ki = np.concatenate([np.arange(0, min(sink, hi)), np.arange(max(lo, 0), hi)])
+                    ki = np.unique(ki)
+                else:
+                    ki = np.arange(0, hi)
+                kk = k[k0 + ki, h // g].astype(np.float64)
+                s = (q[rows[idx], h].astype(np.float64) @ kk.T) * scale
+                mask = np.ones(s.shape, bool)
+                if causal:
+                    mask &= ki[None, :] <= qi
+                if streaming:
+                    mask &= (ki[None, :] < sink) | ((qi - ki[None, :]) < local)
+                s = np.where(mask, s, -np.inf)
+                m = s.max(axis=1, keepdims=True)
+                pr = np.where(mask, np.exp(s - m), 0.0)
+                o = (pr @ v[k0 + ki, h // g].astype(np.float64)) / pr.sum(axis=1, keepdims=True)
+                out[idx, hn] = o.astype(np.float16)
+    return out

@@ -391,9 +391,16 @@ def attended_tokens(fg: FineGrainedKV, b, hk, hq, tlen, dyn_pages=None):
             return np.arange(tlen, dtype=np.int64)
         tpb = fg.retr_k.TPB
         P = dyn_pages.shape[-1]
-        nvirt = (P - 1) * tpb + (tlen - 1) % tpb + 1 if tlen > 0 else 0
+        # sparse_attention/decoderMaskedMultiheadAttentionTemplate.hpp:1568 counts (tlen-1) % tpb + 1 tokens for the
+        # last selected page; the reference's Python (decoding_attention.py:132-142) puts the page of the CURRENT
+        # token there, which holds tlen - page*tpb cached tokens: the same number except when tlen % tpb == 0, where
+        # the page is still empty and upstream's softmax reads score slots it never wrote (:1737-1744 vs :1962,
+        # undefined).  The restatement uses the number of tokens the page really holds.
+        pages = np.asarray(dyn_pages[b, hq], np.int64)
+        in_last = int(min(tpb, max(0, tlen - int(pages[P - 1]) * tpb)))
+        nvirt = (P - 1) * tpb + in_last
         i = np.arange(nvirt, dtype=np.int64)
-        return np.asarray(dyn_pages[b, hq], np.int64)[i // tpb] * tpb + i % tpb
+        return pages[i // tpb] * tpb + i % tpb
     valid = min(fg.sink + fg.local - 1, tlen)
     gap = tlen - valid
     i = np.arange(valid, dtype=np.int64)

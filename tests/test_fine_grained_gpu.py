@@ -184,12 +184,17 @@ def test_decode_fine_grained_dense_linear_rope_scaling():
     c.decode(2)
 
 
+@pytest.mark.parametrize("newest_page", ["of_last_cached_token", "of_current_token"])
 @pytest.mark.parametrize("seq_lens,Hq,flags,tpb,sink,local,P,sub,steps", [
     ([130, 200, 97], 8, FLAGS_MIXED, 16, 16, 48, 4, 8, 3),
     ([700, 640], 16, FLAGS_MIXED, 64, 128, 256, 6, 16, 2),
-    ([255, 256], 8, [1, 1], 64, 128, 256, 3, 32, 2),            # page boundary: history ends a page exactly
+    ([255, 256], 8, [1, 1], 64, 128, 256, 3, 32, 3),            # page boundary: history ends a page exactly
+    ([63, 64, 127], 8, FLAGS_MIXED, 16, 16, 48, 3, 8, 4),       # several sequences cross a 16-token page
 ])
-def test_decode_fine_grained_sparse(seq_lens, Hq, flags, tpb, sink, local, P, sub, steps):
+def test_decode_fine_grained_sparse(seq_lens, Hq, flags, tpb, sink, local, P, sub, steps, newest_page):
+    """newest_page = "of_current_token" is the reference's own page choice (decoding_attention.py:132-142: the
+    last entry is timestep // tokens_per_block, the page the current token is appended to): on the step where the
+    history fills a page exactly that page holds no cached token yet and must contribute none."""
     c = Case(seq_lens, Hq, flags, tpb, sink, local, seed=sum(seq_lens) + P, sub_chunk=sub)
     c.prefill()
     # statistics of the prompt (oracle side), mirrored to the GPU pool before decoding
@@ -202,7 +207,7 @@ def test_decode_fine_grained_sparse(seq_lens, Hq, flags, tpb, sink, local, P, su
     def dyn_fn(hist):
         dyn = np.zeros((c.B, c.Hq, P), np.int32)
         for b in range(c.B):
-            last = (int(hist[b]) - 1) // tpb
+            last = int(hist[b]) // tpb if newest_page == "of_current_token" else (int(hist[b]) - 1) // tpb
             for h in range(c.Hq):
                 pick = c.rng.choice(last, size=P - 1, replace=False) if last >= P - 1 else np.arange(P - 1) % max(last, 1)
                 dyn[b, h, : P - 1] = np.sort(pick)

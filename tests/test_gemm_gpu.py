@@ -70,6 +70,92 @@ def test_per_chn_plan_overrides(waves, sk):
         _lib.lib().omni_gemm_set_plan_override(0, 0)
 
 
+def _run_grp(M, N, K, wrap, seed=None):
+    import omniserve_backend.qgemm_w4a8_per_group as mod
+    u, z, s2, s1 = w4a8.synth_per_group(N, K, seed=M + K if seed is None else seed, wrap=wrap)
+    qw, s1h, s2s, s2z = w4a8.pack_per_group(u, z, s2, s1)
+    a, sa, _ = _acts(M, K, M + 2)
+    want = w4a8.gemm_per_group(a, qw, s2z, s2s, s1h, sa)
+    out = torch.empty((M, N), dtype=torch.float16, device=dev())
+    mod.gemm_forward_cuda(to_dev(a), to_dev(qw), to_dev(s2z), to_dev(s2s), to_dev(s1h), to_dev(sa), out)
+    torch.cuda.synchronize()
+    assert_f16_equal(out, want, "per_group M=%d N=%d K=%d wrap=%s" % (M, N, K, wrap))
+
+
+def _run_w8(M, N, K):
+    import omniserve_backend.qgemm_w8a8 as mod
+    rng = np.random.default_rng(M + N)
+    w = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+    sw = rng.uniform(0.001, 0.01, size=(N,)).astype(np.float16)
+    a, sa, _ = _acts(M, K, M + 3)
+    want = w4a8.gemm_w8a8(a, w, sw, sa)
+    out = torch.empty((M, N), dtype=torch.float16, device=dev())
+    mod.w8a8_gemm_forward_cuda(to_dev(a), to_dev(w), to_dev(sw), to_dev(sa), out)
+    torch.cuda.synchronize()
+    assert_f16_equal(out, want, "w8a8 M=%d N=%d K=%d" % (M, N, K))
+
+
+# ---- every M regime of the tile dispatch has an oracle case (the reference's: w4a8_per_group/gemm_cuda.cu:659-705) ----
+# Prefill kernel (M > 128), K >= 3 whole 256-k chunks: the branch-free STEADY loop of w4a8_gemm_kernel (two-step weight
+# ring refills, next-chunk group parameters, in-chunk activation publishing) with full and ragged M tiles and a ragged
+# N tile (N = 320: five 64-channel groups = 1.25 workgroup tiles).
+@pytest.mark.parametrize("wrap", [False, True])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 1024), (1000, 512, 1024), (256, 320, 2048), (1000, 512, 4096)])
+def test_per_group_prefill_steady_loop(M, N, K, wrap):
+    _run_grp(M, N, K, wrap)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 1024), (1000, 512, 1024), (256, 320, 2048), (1000, 512, 4096)])
+def test_w8a8_prefill_steady_loop(M, N, K):
+    _run_w8(M, N, K)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 1024), (300, 320, 2304)])
+def test_per_chn_prefill_steady_loop_ragged(M, N, K):
+    _run_chn(M, N, K, seed=M + K)
+
+
+def test_per_group_4096_cubed():
+    _run_grp(4096, 4096, 4096, False)
+
+
+def test_w8a8_4096_cubed():
+    _run_w8(4096, 4096, 4096)
+
+
+# Llama-2-70B TP=8 shard shapes (BASELINE.json configs[4], bs up to 128): qkv (64+16)/8 heads x 128 = 1280 x 8192,
+# o 8192 x 1024, gate_up 2 x 28672/8 = 7168 x 8192, down 8192 x 3584 -- the M = 65..128 decode tile with split-K slabs.
+LLAMA2_70B_TP8 = [(1280, 8192), (8192, 1024), (7168, 8192), (8192, 3584)]
+
+
+@pytest.mark.parametrize("M", [65, 100, 128])
+@pytest.mark.parametrize("N,K", LLAMA2_70B_TP8)
+def test_per_chn_llama2_70b_tp8_shard(M, N, K):
+    _run_chn(M, N, K, seed=M + N)
+
+
+@pytest.mark.parametrize("M", [65, 128])
+@pytest.mark.parametrize("N,K", LLAMA2_70B_TP8)
+def test_per_group_llama2_70b_tp8_shard(M, N, K):
+    _run_grp(M, N, K, False)
+
+
+# BASELINE.json configs[2] (g128, bs = 64) and the LServe W8A8 decode shapes at M = 64, Llama-3-8B projections
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)])
+def test_per_group_llama3_8b_decode_bs64(N, K):
+    _run_grp(64, N, K, False)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 28672, 4096), (64, 4096, 14336), (1, 6144, 4096), (1, 28672, 4096)])
+def test_w8a8_llama3_8b_decode(M, N, K):
+    _run_w8(M, N, K)
+
+
+@pytest.mark.parametrize("M", [17, 32, 48, 64])
+def test_per_chn_llama3_8b_gate_up_mid_batches(M):
+    _run_chn(M, 28672, 4096, seed=M)
+
+
 @pytest.mark.parametrize("wrap", [False, True])
 @pytest.mark.parametrize("M,N,K", [(16, 256, 512), (64, 320, 1024), (5, 64, 128), (200, 256, 384), (16, 4096, 4096)])
 def test_per_group(M, N, K, wrap):

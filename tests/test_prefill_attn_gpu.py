@@ -1,4 +1,5 @@
-"""Prefill attention (block_sparse_attn / flash_attn shims) vs the f64 oracle: 1e-3 relative."""
+"""Prefill attention (block_sparse_attn / flash_attn shims) vs the f64 oracle: 1e-3 relative
+(|got - ref| <= 1e-3 |ref| + 1e-3 max|ref|), short ragged batches and the long-sequence regimes."""
 import numpy as np
 import pytest
 import torch
@@ -53,3 +54,61 @@ def test_dense_contiguous_inputs():
 def test_token_streaming_heads(seq_lens, sink, local):
     # kv heads alternate dense (0) / streaming (-1), expanded to q heads like ctx_attn_init.py:28-47
     _case(seq_lens, 8, 4, seed=len(seq_lens) + sink, streaming=([0, -1, -1, 0], sink, local))
+
+
+# ---- long sequences: the regimes the published prefill numbers come from (XCD-ordered 1-D grid, whole-tile skipping of
+# the causal / Lambda masks, LDS-DMA double buffering over hundreds of key tiles).  The f64 oracle is evaluated chunk
+# by chunk over the query rows (oracle.attention.varlen_attention_rows). ------------------------------------------------
+def _long_case(L, Hq, Hk, seed, streaming=None, rows=None, lens=None):
+    import block_sparse_attn as bsa
+    rng = np.random.default_rng(seed)
+    D = 128
+    lens = [L] if lens is None else lens
+    T = int(sum(lens))
+    qkv = rng.standard_normal((T, (Hq + 2 * Hk) * D)).astype(np.float16)
+    q = qkv[:, : Hq * D].reshape(T, Hq, D); k = qkv[:, Hq * D:(Hq + Hk) * D].reshape(T, Hk, D)
+    v = qkv[:, (Hq + Hk) * D:].reshape(T, Hk, D)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    d = to_dev(qkv)
+    qd = d[:, : Hq * D].view(T, Hq, D); kd = d[:, Hq * D:(Hq + Hk) * D].view(T, Hk, D); vd = d[:, (Hq + Hk) * D:].view(T, Hk, D)
+    cu_d = to_dev(cu)
+    hm = si = None
+    if streaming is None:
+        out = bsa.flash_attn_varlen_func(qd, kd, vd, cu_d, cu_d, max(lens), max(lens), dropout_p=0.0, causal=True)
+    else:
+        hmt, sink, local = streaming
+        hm = np.repeat(np.asarray(hmt, np.int32), Hq // Hk)
+        si = np.asarray([sink, local] * Hq, np.int32)
+        out = bsa.token_streaming_attn_func(qd, kd, vd, cu_d, cu_d, to_dev(hm), to_dev(si), max(lens), max(lens))
+    torch.cuda.synchronize()
+    rows = np.arange(T) if rows is None else np.unique(rows)
+    got = out.cpu().numpy().astype(np.float32)[rows]
+    assert np.isfinite(out.float()).all().item()
+    ref = oa.varlen_attention_rows(q, k, v, cu, cu, rows, True, hm, si).astype(np.float32)
+    tol = 1e-3 * np.abs(ref) + 1e-3 * np.abs(ref).max()
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), "max err %g at %s" % (np.abs(got - ref).max(), np.argwhere(bad)[:4].tolist())
+
+
+def test_long_lambda_heads_configs3_window():
+    """L > sink + local at the BASELINE configs[3] parameters (sink 128 / local 8192): 2 dense + 2 streaming kv heads,
+    every query row checked (rows past 8320 exercise the skipped middle tiles of the Lambda mask)."""
+    _long_case(10000, 8, 4, seed=3, streaming=([0, -1, -1, 0], 128, 8192))
+
+
+def test_long_dense_16k():
+    _long_case(16384, 2, 1, seed=4)
+
+
+def test_long_dense_two_sequences_ragged():
+    _long_case(0, 4, 2, seed=6, lens=[5000, 3001])
+
+
+def test_long_streaming_only_64k():
+    """L = 65536, streaming heads only: 512 query tiles per head, each attending 128 sink + 8192 local keys; a sample of
+    rows (the first and last tiles in full, every tile boundary region around sink + local, 4096 random rows)."""
+    L = 65536
+    rng = np.random.default_rng(9)
+    rows = np.concatenate([np.arange(0, 384), np.arange(8192 - 64, 8192 + 384), np.arange(L - 384, L),
+                           rng.choice(L, 4096, replace=False)])
+    _long_case(L, 2, 2, seed=8, streaming=([-1, -1], 128, 8192), rows=rows)

@@ -29,12 +29,9 @@ def test_fusion_levels_and_graph_agree_bitwise():
             assert torch.equal(a, b)
 
 
-def test_prefill_then_decode_matches_token_by_token():
-    """The context stage (prefill GEMMs at M = B*L, KV4 writer, varlen causal attention) must leave the same KV
-    pages and produce the same next token as feeding the prompt through the decode path one token at a time
-    would, up to the tolerance of the attention kernels; here: pages written by prefill are then readable by
-    decode (finite logits, valid tokens) and the prompt's KV rows are bit-identical between two prefill calls."""
-    import torch
+def test_prefill_is_deterministic_and_decodable():
+    """Two prefill calls on the same prompt write bit-identical KV pages and pick the same token; the pages are then
+    readable by the decode path (finite activations, valid tokens)."""
     from omniserve_amd.runtime import DecodeRunner, LlamaConfig
     cfg = LlamaConfig.tiny()
     r = DecodeRunner(cfg, 3, 70, 8, torch.device("cuda:0"), seed=11, use_graph=False, fused=2)
@@ -56,3 +53,68 @@ def test_prefill_then_decode_matches_token_by_token():
     assert torch.isfinite(r.x.float()).all()
     assert int(r.lengths[0]) == 73
     assert ((r.tokens >= 0) & (r.tokens < cfg.vocab)).all()
+
+
+def _kv_rows(runner, layer, L):
+    """(K rows, V rows) of the first L tokens of every sequence of one layer, gathered through the block tables:
+    uint8 [B, Hkv, L, 64 + 4] = packed codes | fp16 scale | fp16 zero of each token row."""
+    kl, tpb, B = runner.kl, runner.tpb, runner.B
+    data_bytes = kl * tpb * 64
+    out = []
+    for kv in range(2):
+        pool = runner.pools[layer][kv]
+        base = pool.data_ptr()
+        idx = ((runner.block_tables[layer][:, kv] - base) // runner.page_bytes).cpu()      # [B, pages]
+        pool_c = pool.cpu()
+        rows = torch.empty((B, kl, L, 68), dtype=torch.uint8)
+        for b in range(B):
+            for t in range(L):
+                page = pool_c[int(idx[b, t // tpb])]
+                for h in range(kl):
+                    o = (h * tpb + t % tpb)
+                    rows[b, h, t, :64] = page[o * 64:(o + 1) * 64]
+                    tail = data_bytes + 2 * o
+                    rows[b, h, t, 64:66] = page[tail:tail + 2]
+                    rows[b, h, t, 66:68] = page[tail + 2 * kl * tpb:tail + 2 * kl * tpb + 2]
+        out.append(rows)
+    return out
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+def test_prefill_matches_token_by_token_decode(fused):
+    """The context stage (prefill GEMMs at M = B*L, in-place RoPE + KV4 page writer, varlen causal attention) against the
+    generation stage fed the same prompt one token at a time from an EMPTY cache (decode GEMVs, fused RoPE + append,
+    paged KV4 decode attention).  Layer 0's K/V rows depend on the token embeddings only and go through bit-exact
+    kernels on both paths: they must be byte-identical.  Deeper state differs by what the two attention kernels may
+    differ by: prefill attends fp16 K/V, decode the KV4-quantised cache (quantisation noise of 4-bit K/V, as upstream),
+    so the final hidden state is compared with a tolerance that is measured, not assumed: <= 0.25 of its largest entry (see the assertion message for the measured value)."""
+    from omniserve_amd.runtime import DecodeRunner, LlamaConfig
+    dev = torch.device("cuda:0")
+    cfg = LlamaConfig.tiny()
+    B, L = 3, 70      # crosses the 64-token page boundary
+    a = DecodeRunner(cfg, B, L, 8, dev, seed=21, use_graph=False, fused=fused)
+    gen_state = a.gen.get_state()
+    prompt = torch.randint(0, cfg.vocab, (B * L,), device=dev, generator=a.gen).view(B, L)
+    a.gen.set_state(gen_state)       # prefill() draws the same B*L tokens from the runner's generator
+    a.prefill(L)
+    torch.cuda.synchronize()
+    x_prefill = a.x.clone().float().cpu()
+    rows_a = _kv_rows(a, 0, L)
+
+    b = DecodeRunner(cfg, B, 0, L + 8, dev, seed=21, use_graph=False, fused=fused)    # same weights, empty cache
+    for layer in b.pools:            # the synthetic runner pre-fills its pools with random pages: start from zeros
+        for pool in layer:
+            pool.zero_()
+    # same page order as runner a is not needed: rows are gathered through each runner's own tables
+    for t in range(L):
+        b.tokens.copy_(prompt[:, t])
+        b.step()
+    torch.cuda.synchronize()
+    assert int(b.lengths[0]) == L
+    rows_b = _kv_rows(b, 0, L)
+    for ra, rb, name in zip(rows_a, rows_b, ("K", "V")):
+        assert torch.equal(ra, rb), "layer-0 %s rows differ between the prefill writer and the decode append" % name
+    x_decode = b.x.float().cpu()
+    scale = x_prefill.abs().max().item()
+    err = (x_prefill - x_decode).abs().max().item()
+    assert err <= 0.25 * scale, "final hidden state: max |prefill - decode| = %g (largest entry %g)" % (err, scale)
