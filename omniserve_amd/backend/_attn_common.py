@@ -194,7 +194,8 @@ def decode_attention_fine_grained(q, k, v, retrieval_kv_pointers, streaming_kv_p
     table = rope_table(max_ctx + 1, D, float(rotary_base), float(rope_scale), q.device)
     # the sparse launch plans its KV splits on num_pages * tokens_per_block attended tokens, which may exceed a tiny
     # context: size the scratch for the larger of the two (the bound is monotone in the token count)
-    need = _lib.lib().omni_kv4_decode_workspace_bytes(B, Hq, D, max(max_ctx, ndyn * int(tokens_per_block)))
+    need = _lib.lib().omni_kv4_decode_workspace_bytes(
+        B, Hq, D, max(max_ctx, ndyn * int(tokens_per_block), int(sink_token_num) + int(local_token_num)))
     ws = _lib.workspace(need, q.device, "attn")
     out = torch.empty((B, Hq, D), dtype=q.dtype, device=q.device)
     if per_tensor:

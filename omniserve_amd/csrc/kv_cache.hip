@@ -1146,9 +1146,14 @@ static int decode_fg_common(
   a.fg.dyn = (const int*)dynamic_sparse_page_idx_i32;
   a.fg.num_dyn = sparse ? num_dynamic_pages : 0;
   a.fg.sub_chunk = sparse ? tokens_per_sub_chunk : 0;
-  // longest attended token list of any head
+  // longest attended token list of any head: retrieval heads the whole history (or the selected pages), streaming
+  // heads sink + local - 1 tokens -- which can exceed a small page budget (the splits must cover both)
   int span = sparse ? num_dynamic_pages * tokens_per_block : max_context;
-  if (num_streaming_kv_heads > 0 && num_retrieval_kv_heads == 0) span = sink_tokens + local_tokens;
+  if (num_streaming_kv_heads > 0) {
+    const int strm = sink_tokens + local_tokens < max_context ? sink_tokens + local_tokens : max_context;
+    if (num_retrieval_kv_heads == 0) span = strm;
+    else if (strm > span) span = strm;
+  }
   if (span > max_context && !sparse) span = max_context;
   if (span < 1) span = 1;
   const DecodePlan pl = plan_decode(batch, num_heads, num_kv_heads, span, tokens_per_block, sparse);

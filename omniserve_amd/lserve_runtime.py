@@ -26,6 +26,18 @@ from .rope import rope_table
 from .runtime import LlamaConfig
 
 
+def head_rank_table(retrieval_head_flags):
+    """Index of every kv head inside its class (ctx_attn_init.py:58-81 `transform_sequence`): retrieval heads
+    (flag 1) and streaming heads (flag 0) are numbered separately in head order."""
+    rank, nr, ns = [], 0, 0
+    for f in retrieval_head_flags:
+        if f:
+            rank.append(nr); nr += 1
+        else:
+            rank.append(ns); ns += 1
+    return rank
+
+
 class W8A8Linear:
     """Synthetic W8A8 weights in the reference layout (w8a8_linear.py:38-60): int8 [N, K] row-major + fp16 scale [N]."""
 
@@ -68,12 +80,7 @@ class LServeDecodeRunner:
         flags = [1 if (i % 2 == 0 and i // 2 < nr) or (i % 2 == 1 and i // 2 >= ns) else 0 for i in range(Hk)]
         if sum(flags) != nr:
             flags = [1] * nr + [0] * ns
-        rank, a, b = [], 0, 0
-        for f in flags:
-            if f:
-                rank.append(a); a += 1
-            else:
-                rank.append(b); b += 1
+        rank = head_rank_table(flags)
         self.nr, self.ns = nr, ns
         self.flags = torch.tensor(flags, dtype=torch.int32, device=device)
         self.rank = torch.tensor(rank, dtype=torch.int32, device=device)

@@ -439,3 +439,39 @@ def decode_attention_fine_grained(q_h, k_h, v_h, lengths, fg: FineGrainedKV, rop
                 out[b, hq] = (p[:, None] * vals).sum(axis=0).astype(F16)
             fg.write(b, hk, tlen, kr[hk], vr[hk], update_stats=dyn_pages is not None, decode=True)
     return out
+
+
+# ---- host-side logic of the LServe path (pure Python / torch upstream), pinned by tests/golden/host_logic.json -------
+def select_topk_pages(stats, tokens_per_block, sub_chunk, budget_tokens, timestep):
+    """decoding_attention.py:88-142 (DecodingAttentionWrapper.dynamic_select_topk_pages) after the selector kernel:
+    stats [B, Hq, padded_sub_chunks] -> int32 [B, Hq, P].  timestep = history length (current token excluded).
+    timestep <= budget: every page 0 .. timestep // tpb.  Otherwise the per-page score is the maximum over the page's
+    sub-chunks, the k = min(max(3, budget // tpb), total_pages) - 1 best pages among all but the newest are taken in
+    descending score order (ties: torch.topk leaves the order unspecified; here: lower page first) and the newest page
+    (total_pages - 1, the page of the current token) is appended."""
+    stats = np.asarray(stats)
+    B, Hq = stats.shape[:2]
+    if timestep <= budget_tokens:
+        pages = np.arange(0, timestep // tokens_per_block + 1, dtype=np.int32)
+        return np.broadcast_to(pages, (B, Hq, pages.size)).copy()
+    subs = tokens_per_block // sub_chunk
+    page_scores = stats.reshape(B, Hq, -1, subs).max(axis=-1)
+    total = page_scores.shape[-1]
+    k = min(max(3, min(budget_tokens, timestep) // tokens_per_block), total) - 1
+    order = np.argsort(-page_scores[:, :, : total - 1].astype(np.float32), axis=-1, kind="stable")[:, :, :k]
+    newest = np.full((B, Hq, 1), total - 1, np.int64)
+    return np.concatenate([order, newest], axis=-1).astype(np.int32)
+
+
+def head_classes(full_attention_heads, num_heads):
+    """ctx_attn_init.py:28-81 for one layer: kv-head flags (1 = retrieval / dense head, 0 = streaming head) ->
+    dict(head_mask_type int32 [Hq] (0 dense, -1 streaming; None when every head is dense), retrieval_head_flags,
+    head_rank_table (index of a head inside its class), pooling_heads_idx (the retrieval heads))."""
+    flags = np.asarray(full_attention_heads, np.int32)
+    rep = num_heads // flags.size
+    hm = None if (flags == 1).all() else np.where(np.repeat(flags, rep) == 0, -1, 0).astype(np.int32)
+    rank = np.empty_like(flags)
+    rank[flags == 0] = np.arange((flags == 0).sum(), dtype=np.int32)
+    rank[flags == 1] = np.arange((flags == 1).sum(), dtype=np.int32)
+    return dict(head_mask_type=hm, retrieval_head_flags=flags, head_rank_table=rank,
+                pooling_heads_idx=np.nonzero(flags == 1)[0].astype(np.int32))

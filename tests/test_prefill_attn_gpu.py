@@ -83,7 +83,7 @@ def _long_case(L, Hq, Hk, seed, streaming=None, rows=None, lens=None):
     torch.cuda.synchronize()
     rows = np.arange(T) if rows is None else np.unique(rows)
     got = out.cpu().numpy().astype(np.float32)[rows]
-    assert np.isfinite(out.float()).all().item()
+    assert torch.isfinite(out.float()).all().item()
     ref = oa.varlen_attention_rows(q, k, v, cu, cu, rows, True, hm, si).astype(np.float32)
     tol = 1e-3 * np.abs(ref) + 1e-3 * np.abs(ref).max()
     bad = np.abs(got - ref) > tol

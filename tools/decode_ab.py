@@ -14,7 +14,7 @@ from omniserve_amd.runtime import DecodeRunner, LlamaConfig  # noqa: E402
 
 
 def run(cfg, args, dev, **kw):
-    r = DecodeRunner(cfg, args.batch, args.context, args.steps + 16, dev, seed=1234, fused=args.fused, **kw)
+    r = DecodeRunner(cfg, args.batch, args.context, 3 * args.steps + 16, dev, seed=1234, fused=args.fused, **kw)
     for _ in range(6):
         r.step()
     torch.cuda.synchronize()
