@@ -203,9 +203,14 @@ struct PrefetchArgs {
   int pf_bytes;       // multiple of 1024, <= row_bytes / (gy * kw)
   int blocks;         // extra workgroups (0 = off)
   int first_block;    // their first blockIdx.x (= number of row workgroups)
+  int delay;          // s_sleep(16) iterations before the first fetch (tuning knob, normally 0)
 };
 
-// body of a fetching workgroup; `lds_scratch` >= 1 KiB per wave (LDS-DMA target, never read)
+// body of a fetching workgroup; `lds_scratch` >= 1 KiB per wave (LDS-DMA target, never read).
+// No integer division inside the loops (gfx950 has none: each one is ~40 scalar instructions): a wave owns one
+// (row, part) segment of a GEMV workgroup's bytes and walks its KiB pieces with a running pointer; with fewer
+// segments than waves the waves of a segment interleave its pieces.  All waves advance together, so the first KiB of
+// every part (what the GEMV's waves ask for first) still arrives first.
 __device__ __forceinline__ void prefetch_weights_to_l2(const PrefetchArgs& pf, void* lds_scratch) {
   const int b = blockIdx.x;
   const int xcd = b & 7;
@@ -217,16 +222,23 @@ __device__ __forceinline__ void prefetch_weights_to_l2(const PrefetchArgs& pf, v
   const int kib = pf.pf_bytes >> 10;                                   // 1-KiB pieces per part
   const int segs = pf.rows_per_wg * pf.kw;                             // (row, part) pairs of one GEMV workgroup
   const long long part_bytes = pf.row_bytes / ((long long)pf.gy * pf.kw);
+  // wave -> (first segment, segment stride, first piece, piece stride)
+  int seg0, seg_step, piece0, piece_step;
+  if (segs >= nwaves) { seg0 = wave; seg_step = nwaves; piece0 = 0; piece_step = 1; }
+  else { const int per = nwaves / segs; seg0 = wave % segs; seg_step = segs; piece0 = wave / segs; piece_step = per;
+         if (piece0 >= per) piece0 = kib; }                             // left-over waves (nwaves % segs) idle
+  for (int d = 0; d < pf.delay; ++d) __builtin_amdgcn_s_sleep(16);     // let the row workgroups' own loads go first
   uint8_t* dst = reinterpret_cast<uint8_t*>(lds_scratch) + wave * 1024;
   const int items = pf.gx * pf.gy;
   for (int it = xcd + 8 * slot; it < items; it += 8 * nslots) {
-    const int x = it % pf.gx, y = it / pf.gx;
+    const int y = it / pf.gx, x = it - y * pf.gx;                      // one division per GEMV workgroup
     const uint8_t* wg = pf.base + (long long)x * pf.rows_per_wg * pf.row_bytes + (long long)y * pf.kw * part_bytes;
-    // piece-major: the first KiB of every part goes first (that is what the GEMV's waves ask for first)
-    for (int u = wave; u < segs * kib; u += nwaves) {
-      const int piece = u / segs, seg = u % segs;
-      const int row = seg / pf.kw, part = seg % pf.kw;
-      lds_dma16(wg + (long long)row * pf.row_bytes + (long long)part * part_bytes + piece * 1024 + lane * 16, dst);
+    for (int seg = seg0; seg < segs; seg += seg_step) {
+      const int row = seg / pf.kw, part = seg - row * pf.kw;
+      const uint8_t* src = wg + (long long)row * pf.row_bytes + (long long)part * part_bytes + lane * 16 +
+                           (long long)piece0 * 1024;
+      for (int piece = piece0; piece < kib; piece += piece_step, src += (long long)piece_step * 1024)
+        lds_dma16(src, dst);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

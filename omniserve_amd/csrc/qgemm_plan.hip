@@ -1,5 +1,6 @@
 // Host-side tiling / split-K planning for the W4A8 / W8A8 GEMMs (shared by the three GEMM TUs).
 #include "qgemm_kernel.h"
+#include <cstdlib>
 
 namespace omni {
 
@@ -135,6 +136,8 @@ extern "C" int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, i
   if (want < 1024 || part_bytes < 1024) return OMNI_OK;                      // parts too small for 1-KiB pieces: skip
   pf.pf_bytes = (int)want;
   pf.blocks = (blocks + 7) & ~7;
+  static const int delay = [] { const char* e = getenv("OMNI_PREFETCH_DELAY"); return e ? atoi(e) : 0; }();
+  pf.delay = delay;
   g_armed_prefetch = pf;
   return OMNI_OK;
 }

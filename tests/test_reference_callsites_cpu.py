@@ -1,0 +1,109 @@
+"""Drop-in check against the REFERENCE's own source (build container only; skipped where /root/reference is absent):
+every call the reference's Python makes into `omniserve_backend.*`, `block_sparse_attn` and `flash_attn` is found with
+`ast`, and its positional / keyword arguments must bind to the function of the same name in this repo's mirror
+(omniserve_amd/backend/*.py through the omniserve_backend alias package).  The reference passes everything
+positionally (w4a8_linear.py:112-135, decoding_attention.py:162-179,326-353,389-421, ctx_update_kv.py:109-135,
+layernorm.py:86-101), so a mirror with a wrong arity or a renamed function fails here without a GPU."""
+import ast
+import importlib
+import inspect
+import os
+
+import pytest
+
+REF = "/root/reference/omniserve"
+# Mixtral / MoE and the fp16 model are out of scope: their files are not scanned
+SKIP_FILES = {"mixtral_w4a8_unpad.py", "llama_w16a16_unpad.py", "w4a8_moe_linear.py"}
+THIRD_PARTY = {"block_sparse_attn", "flash_attn.flash_attn_interface", "flash_attn"}
+# Ops of the static-scale SmoothQuant W8A8 path and the GPT-style activations: defined by the reference's extension,
+# called only from classes no QServe / LServe Llama model instantiates (activation.py:100-157 DequantSiluAndMulQuant /
+# NewGELU / FastGELU, layernorm.py:104-155 DequantAddResidualI8RMSNormQuant; SURVEY.md section 2 marks them unused).
+# The mirror deliberately does not define them; everything else must bind.
+OUT_OF_PATH = {("omniserve_backend.activation_ops", "gelu_new"), ("omniserve_backend.activation_ops", "gelu_fast"),
+               ("omniserve_backend.activation_ops", "invoke_dequant_silu_and_mul_quant"),
+               ("omniserve_backend.layernorm_ops", "invoke_dequant_add_residual_rms_norm_quant")}
+
+
+def _call_sites():
+    sites = []
+    for root, _, files in os.walk(REF):
+        for fn in files:
+            if not fn.endswith(".py") or fn in SKIP_FILES:
+                continue
+            path = os.path.join(root, fn)
+            tree = ast.parse(open(path).read())
+            alias = {}       # local name -> backend module path
+            direct = {}      # local function name -> (module, function)
+            for node in ast.walk(tree):
+                if isinstance(node, ast.Import):
+                    for a in node.names:
+                        if a.name.startswith("omniserve_backend."):
+                            alias[a.asname or a.name] = a.name
+                elif isinstance(node, ast.ImportFrom) and node.module:
+                    if node.module == "omniserve_backend":
+                        for a in node.names:
+                            alias[a.asname or a.name] = "omniserve_backend." + a.name
+                    elif node.module in THIRD_PARTY:
+                        for a in node.names:
+                            direct[a.asname or a.name] = (node.module, a.name)
+            for node in ast.walk(tree):
+                if not isinstance(node, ast.Call):
+                    continue
+                f = node.func
+                target = None
+                if isinstance(f, ast.Attribute):
+                    dotted = []
+                    cur = f
+                    while isinstance(cur, ast.Attribute):
+                        dotted.append(cur.attr)
+                        cur = cur.value
+                    if isinstance(cur, ast.Name):
+                        dotted.append(cur.id)
+                        dotted.reverse()
+                        full = ".".join(dotted[:-1])
+                        if full in alias:
+                            target = (alias[full], dotted[-1])
+                elif isinstance(f, ast.Name) and f.id in direct:
+                    target = direct[f.id]
+                if target is None or target[1] in ("__name__",):
+                    continue
+                if any(isinstance(a, ast.Starred) for a in node.args) or any(k.arg is None for k in node.keywords):
+                    continue
+                sites.append((os.path.relpath(path, REF), node.lineno, target[0], target[1], len(node.args),
+                              tuple(k.arg for k in node.keywords)))
+    return sites
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="/root/reference is not on this machine")
+def test_every_reference_call_site_binds_to_the_mirror():
+    sites = _call_sites()
+    modules = {s[2] for s in sites}
+    # the hot path's modules must all be reached by at least one call site (guards the scanner itself)
+    for must in ("omniserve_backend.qgemm_w4a8_per_chn", "omniserve_backend.qgemm_w4a8_per_group",
+                 "omniserve_backend.qgemm_w8a8", "omniserve_backend.layernorm_ops", "omniserve_backend.fused_kernels",
+                 "omniserve_backend.activation_ops", "omniserve_backend.fused_attention_pure_dense",
+                 "omniserve_backend.fused_attention_fine_grained_dense", "omniserve_backend.fused_attention_fine_grained_sparse",
+                 "omniserve_backend.fused_attention_per_tensor_dense", "omniserve_backend.fused_attention_per_tensor_sparse",
+                 "omniserve_backend.fused_attention_selector", "omniserve_backend.fused_attention_ctx_pool",
+                 "block_sparse_attn"):
+        assert must in modules, "no call site found for %s" % must
+    assert len(sites) >= 25
+    problems = []
+    for (path, line, mod, fn, nargs, kwnames) in sites:
+        if (mod, fn) in OUT_OF_PATH:
+            continue
+        try:
+            m = importlib.import_module(mod)
+        except ImportError as e:
+            problems.append("%s:%d imports %s: %s" % (path, line, mod, e))
+            continue
+        f = getattr(m, fn, None)
+        if f is None:
+            problems.append("%s:%d calls %s.%s which the mirror does not define" % (path, line, mod, fn))
+            continue
+        try:
+            inspect.signature(f).bind(*([None] * nargs), **{k: None for k in kwnames})
+        except TypeError as e:
+            problems.append("%s:%d %s.%s(%d positional, keywords %s) does not bind: %s" % (
+                path, line, mod, fn, nargs, list(kwnames), e))
+    assert not problems, "\n".join(problems)
