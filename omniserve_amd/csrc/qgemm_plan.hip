@@ -58,8 +58,9 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred) {
   } else {
     // 16 < M <= 128: single-wave tiles of MB*16 rows, two K parts per workgroup; split across workgroups until a
     // wave streams <= 2048 k (a wave keeps only RING x 2 KiB in flight, so short parts = more bytes in flight).
-    // M > 64 (two row tiles, long kernels: the slab epilogue is cheap next to them) keeps splitting, down to
-    // 512 k per wave, until ~1.5 workgroups per CU are in flight.
+    // M > 32 (64-row tiles: 20-us kernels, the 5-us slab epilogue is cheap next to them) keeps splitting, down to
+    // 512 k per wave, until ~1.5 workgroups per CU are in flight: at bs = 64 the Llama-3-8B qkv / o projections ran
+    // on 96 / 64 workgroups at 0.6 TB/s (profiles/r02_*).
     int kw = 2;
     while (kw > 1 && (K % (kw * kalign)) != 0) kw >>= 1;
     auto fits = [&](int s) { return ok(s) && ((K / s) % (kw * kalign)) == 0; };
@@ -67,7 +68,7 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred) {
     for (int s = 1; s <= 64; ++s) {
       if (!fits(s) || K / (s * kw) < 512) continue;
       best = s;
-      if (K / (s * kw) <= 2048 && (pl.mz == 1 || ngroups * s * pl.mz >= 384)) break;
+      if (K / (s * kw) <= 2048 && (pl.mb < 4 || ngroups * s * pl.mz >= 384)) break;
     }
     sk = best;
     if (g_override_sk > 0 && ok(g_override_sk)) sk = g_override_sk;

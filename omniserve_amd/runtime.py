@@ -144,7 +144,9 @@ class DecodeRunner:
         # entry points (environment overrides for sweeps: OMNI_PREFETCH_MB, OMNI_PREFETCH_BLOCKS, OMNI_WEIGHT_POLICY).
         import os
         if prefetch_mb is None:
-            prefetch_mb = float(os.environ.get("OMNI_PREFETCH_MB", "24")) if self.fused else 0.0
+            # measured (profiles/r02_*): +6-7 % at bs = 16 with 28-40 MiB per row kernel (the L2s hold 32 MiB; the
+            # excess lands in MALL), nothing at bs = 128, -4 % at bs = 64 where the row kernels are no longer idle
+            prefetch_mb = float(os.environ.get("OMNI_PREFETCH_MB", "40" if batch <= 32 else "0")) if self.fused else 0.0
         self.prefetch_bytes = int(float(prefetch_mb) * (1 << 20)) if self.fused else 0
         self.prefetch_blocks = int(os.environ.get("OMNI_PREFETCH_BLOCKS", prefetch_blocks))
         if weight_policy is None:

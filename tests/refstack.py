@@ -1,0 +1,233 @@
+"""Test harness: run the REFERENCE's own Python layers (omniserve/modeling/layers/*.py from /root/reference) on top of
+this repo's `omniserve_backend` mirror -- on the CPU, without a GPU.
+
+The reference modules import `omniserve_backend.*` / `block_sparse_attn`, which resolve to our mirror packages; the
+mirror marshals tensors into the C ABI (raw pointers, sizes, strides).  Here the ctypes handle of libomniserve_hip.so
+is swapped for `OracleLib`, an object with the same `omni_*` entry points that interprets the raw pointers as HOST
+memory and computes with oracle/ (numpy).  What this pins, against the reference's real call sites and argument
+values: module / function names, positional order and meaning of every argument, output ownership (caller-allocated
+buffers written in place vs returned tensors), strides of the fused-qkv views, the raw-pointer block tables.  It is
+test infrastructure (the oracle is the arithmetic), never a product path: the product still fails without the HIP
+library and rejects host tensors (tests/test_cabi_cpu.py)."""
+import contextlib
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+from oracle import attention as oattn
+from oracle import elementwise as oe
+from oracle import kv4, w4a8
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F16 = np.float16
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REF, "omniserve"))
+
+
+def _arr(ptr, shape, dtype):
+    """numpy view of host memory at raw address `ptr`."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if n == 0:
+        return np.zeros(shape, dtype)
+    buf = (ctypes.c_uint8 * n).from_address(int(ptr))
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+def _rows(ptr, rows, cols, stride, dtype):
+    """[rows, cols] view of a row-strided matrix (stride in elements)."""
+    item = np.dtype(dtype).itemsize
+    if rows == 0:
+        return np.zeros((0, cols), dtype)
+    n = ((rows - 1) * stride + cols) * item
+    buf = (ctypes.c_uint8 * n).from_address(int(ptr))
+    flat = np.frombuffer(buf, dtype=dtype)
+    return np.lib.stride_tricks.as_strided(flat, shape=(rows, cols), strides=(stride * item, item))
+
+
+class _Pages:
+    """The pages a [B,2,max_blocks] raw-pointer block table references, gathered into oracle PagedKV4 pools."""
+
+    def __init__(self, table_ptr, B, max_blocks, needed_blocks, heads, D, tpb):
+        self.tab = _arr(table_ptr, (B, 2, max_blocks), np.int64)
+        self.page_bytes = kv4.page_bytes(heads, D, tpb)
+        n = int(sum(needed_blocks))
+        self.k, self.v = kv4.PagedKV4(max(n, 1), heads, D, tpb), kv4.PagedKV4(max(n, 1), heads, D, tpb)
+        self.kt = np.zeros((B, max_blocks), np.int64)
+        self.vt = np.zeros((B, max_blocks), np.int64)
+        self.map = []
+        nxt = 0
+        for b in range(B):
+            for j in range(int(needed_blocks[b])):
+                for which, cache, t in ((0, self.k, self.kt), (1, self.v, self.vt)):
+                    src = _arr(self.tab[b, which, j], (self.page_bytes,), np.uint8)
+                    cache.pool[nxt, : self.page_bytes] = src
+                    t[b, j] = nxt
+                    self.map.append((cache, nxt, src))
+                nxt += 1
+
+    def scatter(self):
+        for cache, idx, dst in self.map:
+            dst[:] = cache.pool[idx, : self.page_bytes]
+
+
+class OracleLib:
+    """Same entry points as libomniserve_hip.so (include/omniserve_hip.h), host memory, oracle arithmetic."""
+
+    def __init__(self):
+        self.calls = []
+        self.rope = (10000.0, 1.0)       # (base, scale) of the last rope_table() the mirror built
+
+    # ---- introspection / sizing ------------------------------------------------------------------------------
+    def omni_abi_version(self):
+        return 2
+
+    def omni_gemm_workspace_bytes(self, M, N, K):
+        return 1 << 16
+
+    def omni_kv4_decode_workspace_bytes(self, B, H, D, ctx):
+        return 1 << 16
+
+    # ---- GEMMs ---------------------------------------------------------------------------------------------------
+    def omni_w4a8_per_chn_gemm(self, a, qw, wscales, ascales, wsz, asum, out, M, N, K, stride, ws, wsb, stream):
+        self.calls.append("omni_w4a8_per_chn_gemm")
+        res = w4a8.gemm_per_chn(_arr(a, (M, K), np.int8), _arr(qw, (N, K // 2), np.int8), _arr(wscales, (N,), F16),
+                                _arr(ascales, (M,), F16), _arr(wsz, (N,), F16), _arr(asum, (M,), F16))
+        _rows(out, M, N, stride, F16)[:] = res
+        return 0
+
+    def omni_w4a8_per_group_gemm(self, a, qw, zeros, scales_i8, wscales, ascales, out, M, N, K, stride, ws, wsb, stream):
+        self.calls.append("omni_w4a8_per_group_gemm")
+        res = w4a8.gemm_per_group(_arr(a, (M, K), np.int8), _arr(qw, (N, K // 2), np.int8),
+                                  _arr(zeros, (K // 128, N), np.int8), _arr(scales_i8, (K // 128, N), np.int8),
+                                  _arr(wscales, (N,), F16), _arr(ascales, (M,), F16))
+        _rows(out, M, N, stride, F16)[:] = res
+        return 0
+
+    def omni_w8a8_gemm(self, a, w, wscales, ascales, out, M, N, K, stride, ws, wsb, stream):
+        self.calls.append("omni_w8a8_gemm")
+        res = w4a8.gemm_w8a8(_arr(a, (M, K), np.int8), _arr(w, (N, K), np.int8), _arr(wscales, (N,), F16),
+                             _arr(ascales, (M,), F16))
+        _rows(out, M, N, stride, F16)[:] = res
+        return 0
+
+    # ---- row kernels -------------------------------------------------------------------------------------------------
+    def omni_quant(self, out, x, scale, tokens, hidden, stream):
+        self.calls.append("omni_quant")
+        q, s, _ = oe.quant_per_token(_arr(x, (tokens, hidden), F16), fuse_sum=False)
+        _arr(out, (tokens, hidden), np.int8)[:] = q
+        _arr(scale, (tokens,), F16)[:] = s
+        return 0
+
+    def omni_quant_fuse_sum(self, out, x, sm, scale, tokens, hidden, stream):
+        self.calls.append("omni_quant_fuse_sum")
+        q, s, t = oe.quant_per_token(_arr(x, (tokens, hidden), F16), fuse_sum=True)
+        _arr(out, (tokens, hidden), np.int8)[:] = q
+        _arr(scale, (tokens,), F16)[:] = s
+        _arr(sm, (tokens,), F16)[:] = t
+        return 0
+
+    def omni_rms_norm(self, out, x, w, eps, tokens, hidden, stream):
+        self.calls.append("omni_rms_norm")
+        _arr(out, (tokens, hidden), F16)[:] = oe.rms_norm(_arr(x, (tokens, hidden), F16), _arr(w, (hidden,), F16), eps)
+        return 0
+
+    def omni_rms_norm_general(self, out, x, w, scale, eps, tokens, hidden, stream):
+        self.calls.append("omni_rms_norm_general")
+        q, s, _ = oe.rms_norm_general(_arr(x, (tokens, hidden), F16), _arr(w, (hidden,), F16), eps, False)
+        _arr(out, (tokens, hidden), np.int8)[:] = q
+        _arr(scale, (tokens,), F16)[:] = s
+        return 0
+
+    def omni_rms_norm_general_fuse_sum(self, out, x, w, sm, scale, eps, tokens, hidden, stream):
+        self.calls.append("omni_rms_norm_general_fuse_sum")
+        q, s, t = oe.rms_norm_general(_arr(x, (tokens, hidden), F16), _arr(w, (hidden,), F16), eps, True)
+        _arr(out, (tokens, hidden), np.int8)[:] = q
+        _arr(scale, (tokens,), F16)[:] = s
+        _arr(sm, (tokens,), F16)[:] = t
+        return 0
+
+    def omni_silu_and_mul(self, out, x, tokens, d, stream):
+        self.calls.append("omni_silu_and_mul")
+        _arr(out, (tokens, d), F16)[:] = oe.silu_and_mul(_arr(x, (tokens, 2 * d), F16))
+        return 0
+
+    # ---- KV4 cache -------------------------------------------------------------------------------------------------------
+    def omni_compute_padding_offsets(self, out, cu, batch, max_len, total, stream):
+        self.calls.append("omni_compute_padding_offsets")
+        _arr(out, (total,), np.int32)[:] = kv4.compute_padding_offsets(_arr(cu, (batch + 1,), np.int32), max_len)
+        return 0
+
+    def omni_kv4_prefill_write(self, qkv, seq_lens, pad, kv_pointers, tokens, batch, max_blocks, Hq, Hkv, D, max_seq,
+                               tpb, rope, rope_max, max_pos, stream):
+        self.calls.append("omni_kv4_prefill_write")
+        lens = _arr(seq_lens, (batch,), np.int32)
+        pg = _Pages(kv_pointers, batch, max_blocks, [(int(n) + tpb - 1) // tpb for n in lens], Hkv, D, tpb)
+        x = _arr(qkv, (tokens, (Hq + 2 * Hkv) * D), F16)
+        base, scale = self.rope
+        x[:] = kv4.prefill_write(x, lens, pg.k, pg.v, pg.kt, pg.vt, Hq, Hkv, D, base, 1.0 / scale)
+        pg.scatter()
+        return 0
+
+    def omni_kv4_decode_attention(self, out, q, k, v, q_stride, kv_stride, kv_pointers, lengths, B, max_blocks, Hq, Hkv,
+                                  D, tpb, max_ctx, rope, rope_max, ws, wsb, stream):
+        self.calls.append("omni_kv4_decode_attention")
+        lens = _arr(lengths, (B,), np.int32)
+        pg = _Pages(kv_pointers, B, max_blocks, [(int(n) - 1) // tpb + 1 for n in lens], Hkv, D, tpb)
+        qa = _rows(q, B, Hq * D, q_stride, F16).reshape(B, Hq, D)
+        ka = _rows(k, B, Hkv * D, kv_stride, F16).reshape(B, Hkv, D)
+        va = _rows(v, B, Hkv * D, kv_stride, F16).reshape(B, Hkv, D)
+        res = kv4.decode_attention(qa, ka, va, lens, pg.k, pg.v, pg.kt, pg.vt, self.rope[0])
+        _arr(out, (B, Hq, D), F16)[:] = res
+        pg.scatter()
+        return 0
+
+    def omni_prefill_attention(self, out, q, k, v, qs, ks, vs, cu_q, cu_k, batch, max_q, Hq, Hkv, D, causal, hm, si, stream):
+        self.calls.append("omni_prefill_attention")
+        cq, ck = _arr(cu_q, (batch + 1,), np.int32), _arr(cu_k, (batch + 1,), np.int32)
+        Lq, Lk = int(cq[-1]), int(ck[-1])
+        qa = _rows(q, Lq, Hq * D, qs, F16).reshape(Lq, Hq, D)
+        ka = _rows(k, Lk, Hkv * D, ks, F16).reshape(Lk, Hkv, D)
+        va = _rows(v, Lk, Hkv * D, vs, F16).reshape(Lk, Hkv, D)
+        hma = _arr(hm, (Hq,), np.int32) if hm else None
+        sia = _arr(si, (2 * Hq,), np.int32) if si else None
+        _arr(out, (Lq, Hq, D), F16)[:] = oattn.varlen_attention(qa, ka, va, cq, ck, bool(causal), hma, sia)
+        return 0
+
+
+@contextlib.contextmanager
+def reference_over_mirror():
+    """Context: `import omniserve...` resolves on this CPU-only box, the mirror's C-ABI handle is an OracleLib."""
+    from omniserve_amd import _lib, rope as rope_mod
+    from omniserve_amd.backend import _attn_common
+    for p in (REF, ROOT):
+        if p in sys.path:
+            sys.path.remove(p)
+    sys.path.insert(0, REF)
+    sys.path.insert(0, ROOT)
+    fake = OracleLib()
+    saved = (_lib._lib, _lib.require_cuda, _lib.current_stream, _attn_common.rope_table, torch.cuda.current_device,
+             torch.Tensor.cuda)
+    real_rope = rope_mod.rope_table
+
+    def recording_rope(max_pos, dim, base, scale, device):
+        fake.rope = (float(base), float(scale))
+        return real_rope(max_pos, dim, base, scale, device)
+
+    _lib._lib = fake
+    _lib.require_cuda = lambda *t: None
+    _lib.current_stream = lambda: 0
+    _attn_common.rope_table = recording_rope
+    if not torch.cuda.is_available():
+        torch.cuda.current_device = lambda: 0
+        torch.Tensor.cuda = lambda self, *a, **k: self        # from_linear moves the weight to the GPU (w4a8_linear.py:286)
+    try:
+        yield fake
+    finally:
+        (_lib._lib, _lib.require_cuda, _lib.current_stream, _attn_common.rope_table, torch.cuda.current_device,
+         torch.Tensor.cuda) = saved
