@@ -15,7 +15,14 @@ Rank 0 prints ONE JSON line.  Extra objects:
   roofline      dominant kernel = the gate_up W4A8 GEMV (N=28672, K=4096, M=16): algorithmic
                 bytes (packed weights + activations + output) / average duration measured with
                 HIP events on the launch stream, weights rotated over all 32 layers (1.9 GB) so
-                nothing is cache resident.  peak = 8 TB/s (MI355X HBM3E).
+                nothing is cache resident and NO L2 prefetch runs.  peak = 8 TB/s (MI355X HBM3E).
+                `gemv_aggregate` = the same for the four projections of a layer together.
+  drop_in       the same decode step through the REFERENCE call sequence only (no fused extension
+                entry points, no HIP graph, no prefetch): what an unmodified reference host stack
+                would get from the mirror.
+  protocol      qserve_benchmark.py protocol run for real: one prefill of 1024 tokens per sequence
+                and 511 decode steps (graph replays, context growing 1024 -> 1535), B*512 / wall.
+  configs2_g128_bs64   BASELINE.json configs[2]: g128 weights, batch 64 (decode step + protocol).
   cpu_baseline  the oracle restatement of the per-channel GEMMs of one decoder layer at bs=16
                 (torch._int_mm on the host cores) extrapolated to a full step -- a reported
                 baseline, not a target.
@@ -36,8 +43,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_ACHIEVABLE_GBS = 6300.0  # same guide, "8 TB/s peak (spec); ~6.3 TB/s achievable"
 INT8_PEAK_TOPS = 5000.0     # dense int8 MFMA
-# (M, N, K, group) -> measured HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), see profiles/r01_d_*
+# (M, N, K, group) -> HBM bytes per launch of the decode GEMV measured with rocprofv3 --pmc (separate FETCH_SIZE /
+# WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide streaming reads on gfx950).  Taken
+# from the committed profile, NOT re-measured by the run that prints it (PMC collection wraps the process).
 PMC_TRAFFIC_BYTES = {(16, 28672, 4096, -1): 60415000}
+PMC_TRAFFIC_SOURCE = "profiles/r01_d_pmc_gemv_traffic_and_gemm_mfma.md (PMC pass of an earlier run of this kernel, not this run)"
 
 
 def event_time_ms(fn, iters, warm=3):
@@ -53,12 +63,12 @@ def event_time_ms(fn, iters, warm=3):
     return s.elapsed_time(e) / iters
 
 
-def roofline_gate_up(runner):
-    """Event-time the gate_up GEMV alone, rotating over the layers' weights."""
-    c = runner.cfg
+def _time_projection(runner, name):
+    """Event-time one projection's GEMV alone (the reference entry point, weights rotated over the layers so that
+    nothing is cache resident, no prefetch) -> (ms per launch, algorithmic bytes per launch)."""
     B = runner.B
     nl = len(runner.layers)
-    lin0 = runner.layers[0]["gate_up"]
+    lin0 = runner.layers[0][name]
     N, K = lin0.n, lin0.k
     x = torch.randint(-127, 128, (B, K), dtype=torch.int8, device=runner.device)
     sc = torch.full((B,), 0.01, dtype=torch.float16, device=runner.device)
@@ -66,12 +76,31 @@ def roofline_gate_up(runner):
     out = torch.empty((B, N), dtype=torch.float16, device=runner.device)
 
     def fn(i):
-        runner.layers[i % nl]["gate_up"].forward(x, sc, sm, out)
+        runner.layers[i % nl][name].forward(x, sc, sm, out)
 
     ms = event_time_ms(fn, iters=max(64, 2 * nl), warm=nl)
     # algorithmic bytes per launch: M*K + N*K/2 + 2*M*N + 4*N + 4*M (+ g128 params)
-    alg = B * K + lin0.weight_bytes() + 2 * B * N + 4 * N + 4 * B
+    return ms, B * K + lin0.weight_bytes() + 2 * B * N + 4 * N + 4 * B
+
+
+def roofline_gate_up(runner):
+    """Event-time the gate_up GEMV alone, rotating over the layers' weights; plus the four projections together."""
+    B = runner.B
+    lin0 = runner.layers[0]["gate_up"]
+    N, K = lin0.n, lin0.k
+    ms, alg = _time_projection(runner, "gate_up")
     achieved = alg / (ms * 1e-3) / 1e9
+    parts = {"gate_up": (ms, alg)}
+    for name in ("qkv", "o", "down"):
+        parts[name] = _time_projection(runner, name)
+    tot_ms = sum(v[0] for v in parts.values())
+    tot_b = sum(v[1] for v in parts.values())
+    aggregate = {"us_per_layer": round(tot_ms * 1e3, 2), "bytes_per_layer": tot_b,
+                 "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "us": {k: round(v[0] * 1e3, 2) for k, v in parts.items()},
+                 "note": "each projection's GEMV (+ its split-K epilogue kernel where the plan splits) timed alone, "
+                         "cold weights; inside the decode step the row kernels prefetch the head of each weight "
+                         "stream into L2 (profiles/r02_* has the in-step durations)"}
     # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     # runs, FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes): only known for the
     # default shape; anything else reports null.
@@ -82,8 +111,8 @@ def roofline_gate_up(runner):
             # context: MI355X_MICROARCH.md puts the ACHIEVABLE stream rate at ~6.3 TB/s (a plain copy-like probe of this
             # access pattern measures 5.7-5.9 TB/s, tools/stream_probe.hip); the launch costs ~1.6 us of the ~12.5 us
             "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
-            "traffic_source": "profiles/r01_d_pmc_gemv_traffic_and_gemm_mfma.md" if traffic else None,
-            "bytes_per_launch": alg, "us_per_launch": round(ms * 1e3, 2)}
+            "traffic_source": PMC_TRAFFIC_SOURCE if traffic else None,
+            "bytes_per_launch": alg, "us_per_launch": round(ms * 1e3, 2), "gemv_aggregate": aggregate}
 
 
 def gemm_4096(device):
@@ -103,25 +132,86 @@ def gemm_4096(device):
             "frac_of_int8_mfma_peak": round(tops / INT8_PEAK_TOPS, 4), "peak_tops": INT8_PEAK_TOPS}
 
 
-def protocol_leg(runner, args, decode_s_per_step):
-    """qserve_benchmark.py protocol (BASELINE.md): one prefill of `context` tokens per sequence, then 511 decode steps;
-    throughput = B * 512 / wall clock.  The prefill is run and timed here (eager launches, all kernels through the
-    C ABI, KV4 pages written by the prefill writer); the 511 decode steps are priced at the measured per-step time
-    (the decode graph was captured at this context)."""
-    torch.cuda.synchronize()
-    runner.prefill(args.context)          # warm-up: allocates the prefill activations, sizes workspaces
+def protocol_leg(cfg, args, device, batch=None, fused=None):
+    """qserve_benchmark.py protocol run for real: one prefill of `context` tokens per sequence (eager
+    launches, KV4 pages written by the prefill writer), then 511 decode steps as HIP-graph replays with the context
+    growing 1024 -> 1535 (the captured step increments `lengths` itself); throughput = B * 512 / wall clock.
+    One untimed round first (the reference reports the last of three rounds)."""
+    from omniserve_amd.runtime import DecodeRunner
+    B = batch or args.batch
+    gen = 512
+    r = DecodeRunner(cfg, B, args.context, gen + 8, device, seed=4321,
+                     fused=(0 if args.no_fused else args.fused_level) if fused is None else fused)
+    out = {}
+    for rnd in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r.prefill(args.context)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(gen - 1):
+            r.step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        out = {"prompt_len": args.context, "gen_len": gen, "prefill_ms": round((t1 - t0) * 1e3, 2),
+               "prefill_tokens_per_s": round(B * args.context / (t1 - t0), 1),
+               "decode_ms_per_step_mean": round((t2 - t1) / (gen - 1) * 1e3, 4),
+               "tokens_per_s": round(B * gen / (t2 - t0), 1),
+               "note": "B*512 / wall clock of (1 prefill + 511 decode graph replays, context 1024 -> 1535), second of "
+                       "two rounds; the reference's published A100 figure (3005 tok/s, batch 256) follows the same protocol"}
+    if int(r.lengths[0]) != args.context + gen - 1:
+        raise RuntimeError("protocol leg: unexpected final length %d" % int(r.lengths[0]))
+    if not torch.isfinite(r.x.float()).all():
+        raise RuntimeError("non-finite activations in the protocol leg")
+    del r
+    torch.cuda.empty_cache()
+    return out
+
+
+def drop_in_leg(cfg, args, device, steps=24, warmup=4):
+    """The decode step through the reference call sequence ONLY (llama_w4a8_unpad.py:406-438: 11 mirror calls per layer
+    plus the torch residual adds), launched eagerly: no fused extension entry points, no HIP graph, no L2 prefetch,
+    torch.argmax -- what the unmodified reference host stack would get from the drop-in mirror (minus its own Python)."""
+    from omniserve_amd.runtime import DecodeRunner
+    r = DecodeRunner(cfg, args.batch, args.context, steps + warmup + 4, device, seed=99, use_graph=False, fused=0)
+    for _ in range(warmup):
+        r.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    runner.prefill(args.context)
+    for _ in range(steps):
+        r.step()
     torch.cuda.synchronize()
-    prefill_s = time.perf_counter() - t0
-    gen = 512
-    total_s = prefill_s + (gen - 1) * decode_s_per_step
-    return {"prompt_len": args.context, "gen_len": gen, "prefill_ms": round(prefill_s * 1e3, 2),
-            "prefill_tokens_per_s": round(args.batch * args.context / prefill_s, 1),
-            "tokens_per_s": round(args.batch * gen / total_s, 1),
-            "note": "B*512 / (1 measured prefill + 511 x measured decode step); the reference's published A100 figure "
-                    "(3005 tok/s, batch 256) follows the same protocol"}
+    dt = (time.perf_counter() - t0) / steps
+    del r
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(dt * 1e3, 4), "tokens_per_s": round(args.batch / dt, 1), "hip_graph": False,
+            "fused_ext_level": 0, "prefetch": False,
+            "note": "eager launches of the reference's own call sequence; host-launch bound (~360 launches per step)"}
+
+
+def configs2_leg(args, device, steps=32, warmup=6):
+    """BASELINE.json configs[2]: Llama-3-8B W4A8KV4 g128, batch 64 (benchmark_a100.sh protocol), decode step + protocol."""
+    from omniserve_amd.runtime import DecodeRunner, LlamaConfig
+    cfg = LlamaConfig.llama3_8b(128)
+    r = DecodeRunner(cfg, 64, args.context, steps + warmup + 4, device, seed=77)
+    for _ in range(warmup):
+        r.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    if not torch.isfinite(r.x.float()).all():
+        raise RuntimeError("non-finite activations in the g128 decode step")
+    out = {"config": "Llama-3-8B W4A8KV4 g128, bs=64, context=%d" % args.context, "ms_per_step": round(dt * 1e3, 4),
+           "decode_tokens_per_s": round(64 / dt, 1), "fused_ext_level": r.fused,
+           "gemm_weight_bytes_per_step": r.gemm_weight_bytes_per_step(),
+           "kv_bytes_per_step": r.kv_bytes_per_step(args.context)}
+    del r
+    torch.cuda.empty_cache()
+    out["protocol"] = protocol_leg(cfg, args, device, batch=64, fused=1)
+    return out
 
 
 def lserve_leg(device, context=256000, steps=32, warmup=8):
@@ -197,7 +287,7 @@ def cpu_baseline(cfg, batch):
     (unpack once, untimed; timed: torch._int_mm + the fp32 epilogue), extrapolated to a step."""
     import numpy as np
     from oracle import w4a8
-    cores = min(os.cpu_count() or 1, 16)   # oneDNN int8 at M=32 does not scale past a few cores
+    cores = min(os.cpu_count() or 1, 16)   # oneDNN int8 at M=32 does not scale past a few cores; the threads actually used
     torch.set_num_threads(cores)
     shapes = [((cfg.heads + 2 * cfg.kv_heads) * cfg.head_dim, cfg.hidden), (cfg.hidden, cfg.hidden),
               (2 * cfg.inter, cfg.hidden), (cfg.hidden, cfg.inter)]
@@ -226,8 +316,9 @@ def cpu_baseline(cfg, batch):
     step_s = dt * cfg.layers
     return {"value": round(batch / step_s, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": "oracle port (torch._int_mm int8 + fp32 epilogue) of the 4 per-channel W4A8 GEMMs of one "
-                      "Llama-3-8B decoder layer at M=%d (rows padded to %d), %d reps in %.1f s, x%d layers; "
-                      "attention/norm/lm_head excluded" % (batch, M, reps, dt * reps, cfg.layers)}
+                      "Llama-3-8B decoder layer at M=%d (rows padded to %d) on %d host threads, %d reps in %.1f s, "
+                      "x%d layers; attention, norms, quantisers and lm_head are NOT in the sample (GEMMs only)" % (
+                          batch, M, cores, reps, dt * reps, cfg.layers)}
 
 
 def main():
@@ -287,6 +378,26 @@ def main():
     if not torch.isfinite(runner.x.float()).all():
         raise SystemExit("non-finite activations in the decode step")
 
+    ar = None
+    if tp:
+        # the collective of the TP path on its own: in-place fp16 sum all-reduce of one [B, hidden] projection
+        # (2 MiB at bs = 128 x 8192), event-timed on the launch stream, max over ranks
+        buf = torch.zeros((args.batch, cfg.hidden), dtype=torch.float16, device=device)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / 50 * 1e3], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        us = float(t.item())
+        nbytes = buf.numel() * 2
+        ar = {"all_reduce_us": round(us, 2), "payload_bytes": nbytes, "calls_per_step": 2 * cfg.layers,
+              "bus_GBps": round(2.0 * (world - 1) / world * nbytes / us / 1e3, 1)}
     total_tokens = args.batch * args.steps * (1 if tp else world)
     result = {
         "metric": "decode tokens/sec/GPU Llama-3-8B W4A8KV4 bs=%d" % args.batch if world == 1 else
@@ -304,10 +415,15 @@ def main():
                    "batch_per_gpu": args.batch, "context": args.context, "layers": cfg.layers,
                    "parallelism": ("tp%d (RCCL all-reduce x2 per layer)" % world if tp else
                                    "replicas x%d (no collective)" % world) if world > 1 else "single GPU",
-                   "hip_graph": not args.no_graph, "fused_ext_level": runner.fused,
+                   "hip_graph": bool(runner.use_graph), "fused_ext_level": runner.fused,
                    "gemm_weight_bytes_per_step": runner.gemm_weight_bytes_per_step(),
                    "kv_bytes_per_step": runner.kv_bytes_per_step(args.context)},
     }
+    if ar is not None:
+        result["tensor_parallel"] = ar
+        if runner.graph_error:
+            result["tensor_parallel"]["graph_capture_fell_back_to_eager"] = runner.graph_error
+
     def leg(name, fn):
         """An extra leg must never cost the headline line: a failure is reported in place of its object."""
         try:
@@ -315,14 +431,18 @@ def main():
         except Exception as exc:   # noqa: BLE001
             result[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
-    if rank == 0 and not args.no_extras and not tp:
-        leg("protocol", lambda: protocol_leg(runner, args, elapsed / args.steps))
     if rank == 0 and not args.no_extras:
         leg("roofline", lambda: roofline_gate_up(runner))
+        prefetch_mb = runner.prefetch_bytes / float(1 << 20)
+        result["config"]["l2_prefetch_mib_per_row_kernel"] = prefetch_mb
         if world == 1:
             leg("w4a8_gemm_4096", lambda: gemm_4096(device))
             del runner
             torch.cuda.empty_cache()
+            leg("protocol", lambda: protocol_leg(cfg, args, device))
+            leg("drop_in", lambda: drop_in_leg(cfg, args, device))
+            if args.group_size == -1 and args.batch == 16:
+                leg("configs2_g128_bs64", lambda: configs2_leg(args, device))
             if not args.no_lserve:
                 leg("lserve_ctx256k", lambda: lserve_leg(device))
                 torch.cuda.empty_cache()

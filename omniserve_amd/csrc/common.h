@@ -200,6 +200,7 @@ struct PrefetchArgs {
   const uint8_t* base;
   long long row_bytes;
   int rows_per_wg, gx, gy, kw;
+  int rows_pf;        // rows of a workgroup that are fetched (the first ones; <= rows_per_wg)
   int pf_bytes;       // multiple of 1024, <= row_bytes / (gy * kw)
   int blocks;         // extra workgroups (0 = off)
   int first_block;    // their first blockIdx.x (= number of row workgroups)
@@ -220,7 +221,7 @@ __device__ __forceinline__ void prefetch_weights_to_l2(const PrefetchArgs& pf, v
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6, lane = threadIdx.x & 63;
   const int kib = pf.pf_bytes >> 10;                                   // 1-KiB pieces per part
-  const int segs = pf.rows_per_wg * pf.kw;                             // (row, part) pairs of one GEMV workgroup
+  const int segs = pf.rows_pf * pf.kw;                                 // (row, part) pairs of one GEMV workgroup
   const long long part_bytes = pf.row_bytes / ((long long)pf.gy * pf.kw);
   // wave -> (first segment, segment stride, first piece, piece stride)
   int seg0, seg_step, piece0, piece_step;

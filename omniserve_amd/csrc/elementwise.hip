@@ -13,6 +13,7 @@
 // reference's 3-4 passes.  (The first-generation kernels with one 1024-thread workgroup per token remain as the
 // fallback for row lengths the v2 geometry does not cover.)
 #include "common.h"
+#include <cstdlib>
 
 namespace omni {
 
@@ -752,7 +753,13 @@ static inline PrefetchArgs take_prefetch(int tokens) {
     else                                                                                                        \
       hipLaunchKernelGGL((KERNEL(512, 4)), dim3(tokens), dim3(512), lds_, (hipStream_t)stream, __VA_ARGS__);    \
   } while (0)
-// quant / general-norm kernels: the armed prefetch descriptor rides along as extra workgroups (decode-size launches)
+// quant / general-norm kernels: the armed prefetch descriptor rides along as extra workgroups (decode-size launches).
+// OMNI_DECODE_RT=256 (tuning knob) runs decode-size rows of sources that batch their loads on 256 threads instead of 512.
+static const bool v2_batched = true;     // shadowed by `false` at the launch sites of sources that fetch per vector
+static inline int decode_rt() {
+  static const int v = [] { const char* e = getenv("OMNI_DECODE_RT"); return e ? atoi(e) : 512; }();
+  return v;
+}
 #define OMNI_V2_LAUNCH(KERNEL, tokens, hidden, elems, ...)                                                      \
   do {                                                                                                          \
     const PrefetchArgs pf_ = take_prefetch(tokens);                                                             \
@@ -760,8 +767,9 @@ static inline PrefetchArgs take_prefetch(int tokens) {
     if (pf_.blocks > 0 && lds_ < 8 * 1024) lds_ = 8 * 1024;   /* 1 KiB of LDS-DMA target per wave */            \
     if ((tokens) >= ROWS_MANY && (elems) <= 128 * 4 * VT)                                                       \
       hipLaunchKernelGGL((KERNEL(128, 4)), dim3(tokens), dim3(128), lds_, (hipStream_t)stream, __VA_ARGS__, pf_);  \
-    else if ((tokens) >= ROWS_MANY && (elems) <= 256 * 8 * VT)                                                  \
-      hipLaunchKernelGGL((KERNEL(256, 8)), dim3(tokens), dim3(256), lds_, (hipStream_t)stream, __VA_ARGS__, pf_);  \
+    else if (((tokens) >= ROWS_MANY || (decode_rt() == 256 && v2_batched)) && (elems) <= 256 * 8 * VT)          \
+      hipLaunchKernelGGL((KERNEL(256, 8)), dim3((tokens) + pf_.blocks), dim3(256), lds_, (hipStream_t)stream,   \
+                         __VA_ARGS__, pf_);                                                                     \
     else                                                                                                        \
       hipLaunchKernelGGL((KERNEL(512, 4)), dim3((tokens) + pf_.blocks), dim3(512), lds_, (hipStream_t)stream,   \
                          __VA_ARGS__, pf_);                                                                     \
@@ -995,6 +1003,7 @@ extern "C" int omni_splitk_add_rms_norm_general_fuse_sum(void* out_i8, void* res
   SrcSlabAddChn src{(half_t*)residual_f16, (const int32_t*)slab_i32, (size_t)tokens * hidden, sk, hidden,
                     (const half_t*)wscales_f16, (const half_t*)w_szs_f16, (const half_t*)ascales_in_f16,
                     (const half_t*)a_ssums_in_f16, 0.f, 0.f};
+  const bool v2_batched = false;
   #undef KQ_
   #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, true, SrcSlabAddChn>
   OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8, src,
@@ -1012,6 +1021,7 @@ extern "C" int omni_attn_merge_quant_fuse_sum(void* out_i8, const void* part_ml_
   if (!v2_ok(hidden, nv)) return OMNI_EINVAL;
   if (batch == 0) return OMNI_OK;
   SrcAttnMerge src{(const float*)part_ml_f32, (const float*)part_o_f32, nsplit, num_heads, 0};
+  const bool v2_batched = false;
   #undef KQ_
   #define KQ_(RT_, RV_) quant_v2_kernel<RT_, RV_, true, SrcAttnMerge>
   OMNI_V2_LAUNCH(KQ_, batch, hidden, hidden, (int8_t*)out_i8, src, (half_t*)sum_f16,

@@ -126,16 +126,29 @@ extern "C" int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, i
   pf.gx = (N / 64 + groups_per_wg - 1) / groups_per_wg;
   pf.gy = pl.sk;
   pf.kw = pl.kw;
-  if (mode == MODE_W8) { pf.row_bytes = K; pf.rows_per_wg = 64 * groups_per_wg; }
-  else { pf.row_bytes = (long long)K * 16; pf.rows_per_wg = 2 * groups_per_wg; }
   if ((N / 64) % groups_per_wg != 0) return OMNI_OK;                         // ragged last workgroup: skip the hint
-  const long long part_bytes = pf.row_bytes / ((long long)pf.gy * pf.kw);
-  const long long total = pf.row_bytes * pf.rows_per_wg * pf.gx;
-  long long want = part_bytes;
-  if (total > budget_bytes) want = (long long)((double)part_bytes * (double)budget_bytes / (double)total);
-  want = (want / 1024) * 1024;
-  if (want < 1024 || part_bytes < 1024) return OMNI_OK;                      // parts too small for 1-KiB pieces: skip
-  pf.pf_bytes = (int)want;
+  if (mode == MODE_W8) {
+    // [N][K] int8 rows of K bytes: a wave walks its 64 rows together along k, so a budget below the matrix size
+    // fetches whole rows of the first rows of every workgroup (K-parts of a row can be shorter than a 1-KiB piece)
+    if (pf.gy > 1 && (pf.gx & 7) != 0) return OMNI_OK;                       // K-slices of a row group on different XCDs
+    pf.row_bytes = K; pf.rows_per_wg = 64 * groups_per_wg;
+    pf.gy = 1; pf.kw = 1;
+    const long long total = (long long)N * K;
+    double f = total > budget_bytes ? (double)budget_bytes / (double)total : 1.0;
+    pf.rows_pf = (int)(pf.rows_per_wg * f);
+    pf.pf_bytes = (K / 1024) * 1024;
+    if (pf.rows_pf < 1 || pf.pf_bytes < 1024) return OMNI_OK;
+  } else {
+    pf.row_bytes = (long long)K * 16; pf.rows_per_wg = 2 * groups_per_wg;
+    pf.rows_pf = pf.rows_per_wg;
+    const long long part_bytes = pf.row_bytes / ((long long)pf.gy * pf.kw);
+    const long long total = pf.row_bytes * pf.rows_per_wg * pf.gx;
+    long long want = part_bytes;
+    if (total > budget_bytes) want = (long long)((double)part_bytes * (double)budget_bytes / (double)total);
+    want = (want / 1024) * 1024;
+    if (want < 1024 || part_bytes < 1024) return OMNI_OK;                    // parts too small for 1-KiB pieces: skip
+    pf.pf_bytes = (int)want;
+  }
   pf.blocks = (blocks + 7) & ~7;
   static const int delay = [] { const char* e = getenv("OMNI_PREFETCH_DELAY"); return e ? atoi(e) : 0; }();
   pf.delay = delay;

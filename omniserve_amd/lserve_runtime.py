@@ -58,12 +58,17 @@ class LServeDecodeRunner:
 
     def __init__(self, cfg: LlamaConfig, batch: int, context: int, max_new: int, device, seed=0, kv_format="kv8",
                  streaming_ratio=0.5, sink=128, local=256, budget_tokens=4096, selector_interval=4,
-                 sub_chunk_per_block=4, use_graph=True, fused=True):
+                 sub_chunk_per_block=4, use_graph=True, fused=True, prefetch_mb=None):
         """fused: use the opt-in fused entry points (residual add + norm + quant, silu*mul + quant) -- bit-identical to the
         reference call sequence, three launches fewer per layer."""
         c = cfg
         self.cfg, self.B, self.device = cfg, batch, device
         self.fused = bool(fused)
+        # L2 weight prefetch riding on the row kernels (see omniserve_amd/runtime.py; a hint, results unaffected)
+        import os
+        if prefetch_mb is None:
+            prefetch_mb = float(os.environ.get("OMNI_PREFETCH_MB", "40")) if self.fused else 0.0
+        self.prefetch_bytes = int(float(prefetch_mb) * (1 << 20)) if self.fused else 0
         if kv_format not in ("kv8", "kv4"):
             raise ValueError("kv_format must be 'kv8' (per_tensor) or 'kv4' (fine_grained)")
         self.kv8 = kv_format == "kv8"
@@ -163,6 +168,10 @@ class LServeDecodeRunner:
         self.graphs = {}
         self.steps_done = 0
 
+    def _arm(self, lin):
+        if self.prefetch_bytes > 0:
+            fused_ext.prefetch_arm_gemm(lin.weight, self.B, lin.n, lin.k, 2, False, self.prefetch_bytes, 240)
+
     # one decode step; `select` = this step refreshes the page selection (every `interval`-th step upstream)
     def _eager_step(self, hist: int, select: bool):
         """hist = upper bound of the history length of this step's page bucket (the kernels take the true lengths from
@@ -177,6 +186,7 @@ class LServeDecodeRunner:
         total_pages = hist // self.tpb + 1
         sm = self.act_sum
         for li, L in enumerate(self.layers):
+            self._arm(L["qkv"])
             if self.fused and li > 0:     # residual += down_proj(previous layer), then norm + quant
                 fused_ext.add_rms_norm_general_fuse_sum(self.q_hidden, self.x, self.proj_buf, L["ln1"], sm, sc, c.eps)
             else:
@@ -212,14 +222,17 @@ class LServeDecodeRunner:
                 out = attn.single_query_attention(q, k, v, self.retr_tables[li], self.strm_tables[li], self.flags,
                                                   self.rank, self.page_idx[li], self.lengths, None, self.max_context,
                                                   *common)
+            self._arm(L["o"])
             fused_kernels.invoke_quant(self.q_attn, out.view(B, Hq * d), sc)
             L["o"].forward(self.q_attn, sc, self.proj_buf)
+            self._arm(L["gate_up"])
             if self.fused:
                 fused_ext.add_rms_norm_general_fuse_sum(self.q_hidden, self.x, self.proj_buf, L["ln2"], sm, sc, c.eps)
             else:
                 self.x.add_(self.proj_buf)
                 layernorm_ops.rms_norm_general(self.q_hidden, self.x, L["ln2"], sc, c.eps, True)
             L["gate_up"].forward(self.q_hidden, sc, self.gate_up_buf)
+            self._arm(L["down"])
             if self.fused:
                 fused_ext.silu_mul_quant_fuse_sum(self.q_inter, self.gate_up_buf, sm, sc)
             else:

@@ -228,6 +228,7 @@ class DecodeRunner:
         rope_table(self.max_context + 1, c.head_dim, c.rope_theta, 1.0, device)  # pre-build (capture safe)
         self.graph = None
         self.use_graph = use_graph
+        self.graph_error = None       # set when a tensor-parallel graph capture failed and the runner fell back to eager
         self.steps_done = 0
 
     def step(self):
@@ -247,9 +248,24 @@ class DecodeRunner:
                 self.lengths.copy_(saved[0])
                 self.tokens.copy_(saved[1])
             torch.cuda.current_stream().wait_stream(s)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._eager_step()
+                self.graph = graph
+            except Exception as exc:     # noqa: BLE001  (e.g. a collective that cannot be captured on this stack)
+                if self.tp_size == 1:
+                    raise
+                # tensor-parallel first contact: an RCCL all-reduce inside a captured HIP graph has never run on
+                # hardware here; fall back to eager launches instead of losing the run, and say so
+                torch.cuda.synchronize()
+                self.use_graph = False
+                self.graph_error = "%s: %s" % (type(exc).__name__, exc)
+                self.lengths.copy_(saved[0])
+                self.tokens.copy_(saved[1])
                 self._eager_step()
+                self.steps_done += 1
+                return
         self.graph.replay()
         self.steps_done += 1
 
