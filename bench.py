@@ -78,7 +78,29 @@ def _time_projection(runner, name):
     def fn(i):
         runner.layers[i % nl][name].forward(x, sc, sm, out)
 
-    ms = event_time_ms(fn, iters=max(64, 2 * nl), warm=nl)
+    # One HIP graph of one launch per layer, replayed: host launch overhead (~10 us per eager call, more than the small
+    # projections take) stays out of the figure; HIP events bracket the replays on the launch stream.
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(nl):
+            fn(i)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(nl):
+            fn(i)
+    g.replay()
+    torch.cuda.synchronize()
+    reps = 6
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / (reps * nl)
     # algorithmic bytes per launch: M*K + N*K/2 + 2*M*N + 4*N + 4*M (+ g128 params)
     return ms, B * K + lin0.weight_bytes() + 2 * B * N + 4 * N + 4 * B
 
@@ -98,8 +120,8 @@ def roofline_gate_up(runner):
     aggregate = {"us_per_layer": round(tot_ms * 1e3, 2), "bytes_per_layer": tot_b,
                  "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  "us": {k: round(v[0] * 1e3, 2) for k, v in parts.items()},
-                 "note": "each projection's GEMV (+ its split-K epilogue kernel where the plan splits) timed alone, "
-                         "cold weights; inside the decode step the row kernels prefetch the head of each weight "
+                 "note": "each projection's GEMV (+ its split-K epilogue kernel where the plan splits) timed alone in a "
+                         "HIP graph of 32 launches over the layers' (cold) weights; inside the decode step the row kernels prefetch the head of each weight "
                          "stream into L2 (profiles/r02_* has the in-step durations)"}
     # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     # runs, FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes): only known for the

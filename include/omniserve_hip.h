@@ -145,6 +145,19 @@ int omni_kv4_decode_attention_partial(const void* q_f16, const void* k_f16, cons
 int omni_attn_merge_quant_fuse_sum(void* out_i8, const void* part_ml_f32, const void* part_o_f32, int nsplit,
                                    void* sum_f16, void* scale_f16, int batch, int num_heads, void* stream);
 
+/* The same split for the LServe decode attention (retrieval / streaming heads, optional page list; KV4 pages when both
+ * scale pointers are NULL, per-tensor KV8 pages otherwise): partials only, finished by omni_attn_merge_quant_fuse_sum. */
+int omni_kv_decode_attention_fine_grained_partial(
+    const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride, int64_t kv_stride,
+    const void* kv_scale_quant_orig_f32, const void* kv_scale_orig_quant_f32,
+    const void* retrieval_kv_pointers_i64, const void* streaming_kv_pointers_i64,
+    const void* retrieval_head_flags_i32, const void* head_rank_table_i32, const void* lengths_i32,
+    const void* dynamic_sparse_page_idx_i32, int num_dynamic_pages, int tokens_per_sub_chunk, int batch,
+    int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads, int num_retrieval_kv_heads,
+    int num_streaming_kv_heads, int head_dim, int tokens_per_block, int sink_tokens, int local_tokens,
+    int sink_blocks, int local_blocks, int max_context, const void* rope_cos_sin_f32, int rope_max_pos,
+    void* workspace, size_t workspace_bytes, int* nsplit_out, void* stream);
+
 /* Greedy-sampling helper of the decode runner (not a reference kernel: the reference's sampler is torch code,
  * omniserve/modeling/layers/sampler.py): out_i64[r] = index of the first maximum of logits fp16 [rows, cols]
  * (torch.argmax semantics).  workspace >= omni_argmax_workspace_bytes(rows). */

@@ -48,6 +48,8 @@ PROTOTYPES = {
     "omni_prefill_attention": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp] + [_i] * 6 + [_vp, _vp, _vp]),
     "omni_kv4_decode_attention_partial": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp] + [_i] * 7 + [_vp, _i, _vp, _sz, _c.POINTER(_i), _vp]),
     "omni_attn_merge_quant_fuse_sum": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "omni_kv_decode_attention_fine_grained_partial": (_i, [_vp, _vp, _vp, _i64, _i64] + [_vp] * 8 + [_i] * 16 +
+                                                      [_vp, _i, _vp, _sz, _c.POINTER(_i), _vp]),
     "omni_select_topk_pages": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "omni_argmax_workspace_bytes": (_sz, [_i]),
     "omni_argmax_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _sz, _vp]),

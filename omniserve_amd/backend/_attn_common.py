@@ -157,8 +157,10 @@ def decode_attention_fine_grained(q, k, v, retrieval_kv_pointers, streaming_kv_p
                                   sink_block_num, local_block_num, num_retrieval_kv_heads, num_streaming_kv_heads,
                                   timestep, rotary_embedding_dim, rotary_base, rope_scale, neox, int4, zeros,
                                   tokens_per_sub_chunk, what, kv_scale_quant_orig=None, kv_scale_orig_quant=None,
-                                  per_tensor=False):
-    """per_tensor=True: the KV8 family (both scale tensors fp32 [2] on the device)."""
+                                  per_tensor=False, merge_quant=None):
+    """per_tensor=True: the KV8 family (both scale tensors fp32 [2] on the device).
+    merge_quant = (out_i8 [B, Hq*D], input_sum fp16 [B], scale fp16 [B]): fused extension -- the flash-decoding merge is
+    done by the per-token quantiser that follows upstream (invoke_quant[_fuse_sum]); returns None."""
     _lib.require_cuda(q, k, v, lengths, retrieval_head_flags, head_rank_table)
     B, Hq, D = q.shape
     Hkv = k.shape[1]
@@ -197,6 +199,24 @@ def decode_attention_fine_grained(q, k, v, retrieval_kv_pointers, streaming_kv_p
     need = _lib.lib().omni_kv4_decode_workspace_bytes(
         B, Hq, D, max(max_ctx, ndyn * int(tokens_per_block), int(sink_token_num) + int(local_token_num)))
     ws = _lib.workspace(need, q.device, "attn")
+    if merge_quant is not None:
+        import ctypes
+        out_i8, input_sum, scale = merge_quant
+        _lib.require_cuda(out_i8, input_sum, scale)
+        ns = ctypes.c_int(0)
+        rc = _lib.lib().omni_kv_decode_attention_fine_grained_partial(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0),
+            kv_scale_quant_orig.data_ptr() if per_tensor else None, kv_scale_orig_quant.data_ptr() if per_tensor else None,
+            rp, sp, retrieval_head_flags.data_ptr(), head_rank_table.data_ptr(), lengths.data_ptr(), dyn_ptr, ndyn,
+            int(tokens_per_sub_chunk), B, rb, sb, Hq, Hkv, int(num_retrieval_kv_heads), int(num_streaming_kv_heads), D,
+            int(tokens_per_block), int(sink_token_num), int(local_token_num), int(sink_block_num), int(local_block_num),
+            max_ctx, table.data_ptr(), table.shape[0], ws.data_ptr(), ws.numel(), ctypes.byref(ns), _lib.current_stream())
+        _lib.check(rc, what + " (partials)")
+        ml_bytes = B * Hq * ns.value * 2 * 4
+        rc = _lib.lib().omni_attn_merge_quant_fuse_sum(out_i8.data_ptr(), ws.data_ptr(), ws.data_ptr() + ml_bytes, ns.value,
+                                                       input_sum.data_ptr(), scale.data_ptr(), B, Hq, _lib.current_stream())
+        _lib.check(rc, what + " (merge + quant)")
+        return None
     out = torch.empty((B, Hq, D), dtype=q.dtype, device=q.device)
     if per_tensor:
         rc = _lib.lib().omni_kv8_decode_attention_per_tensor(

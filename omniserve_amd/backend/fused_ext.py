@@ -98,6 +98,28 @@ def set_weight_policy(policy):
     _lib.lib().omni_gemm_set_weight_policy(int(policy))
 
 
+def sparse_decode_attention_quant(out_i8, input_sum, scale, q, k, v, retrieval_kv_pointers, streaming_kv_pointers,
+                                  retrieval_head_flags, head_rank_table, dynamic_sparse_page_idxes, lengths,
+                                  tokens_per_block, size_per_retrieval_token, size_per_streaming_token, sink_token_num,
+                                  local_token_num, sink_block_num, local_block_num, num_retrieval_kv_heads,
+                                  num_streaming_kv_heads, timestep, rotary_base, rotary_embedding_scale,
+                                  tokens_per_sub_chunk, kv_scale_quant_orig=None, kv_scale_orig_quant=None):
+    """LServe decode attention (fused_attention_fine_grained_sparse / fused_attention_per_tensor_sparse
+    .single_query_attention; per-tensor KV8 when the two scale tensors are given) followed by the per-token
+    quantisation of its [B, Hq*Dh] output (fused_kernels.invoke_quant[_fuse_sum]), with the flash-decoding merge done by
+    the quantiser: one launch less and no fp16 round trip; codes and scales bit-identical to the two-call sequence."""
+    from ._attn_common import decode_attention_fine_grained
+    per_tensor = kv_scale_quant_orig is not None
+    D = q.shape[-1]
+    decode_attention_fine_grained(
+        q, k, v, retrieval_kv_pointers, streaming_kv_pointers, retrieval_head_flags, head_rank_table,
+        dynamic_sparse_page_idxes, lengths, tokens_per_block, size_per_retrieval_token, size_per_streaming_token,
+        sink_token_num, local_token_num, sink_block_num, local_block_num, num_retrieval_kv_heads, num_streaming_kv_heads,
+        int(timestep), D, rotary_base, 1.0 / float(rotary_embedding_scale), True, not per_tensor, not per_tensor,
+        tokens_per_sub_chunk, "fused_ext.sparse_decode_attention_quant", kv_scale_quant_orig=kv_scale_quant_orig,
+        kv_scale_orig_quant=kv_scale_orig_quant, per_tensor=per_tensor, merge_quant=(out_i8, input_sum, scale))
+
+
 def argmax(out, logits):
     """out int64 [rows] = torch.argmax(logits fp16 [rows, cols], dim=-1) (first maximum); greedy-sampling helper of the
     decode runner -- the reference's sampler is torch code, this is not one of its kernels."""

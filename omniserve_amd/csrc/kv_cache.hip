@@ -1126,8 +1126,10 @@ static int decode_fg_common(
     int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads, int num_retrieval_kv_heads,
     int num_streaming_kv_heads, int head_dim, int tokens_per_block, int sink_tokens, int local_tokens,
     int sink_blocks, int local_blocks, int max_context, const void* rope_cos_sin_f32, int rope_max_pos,
-    void* workspace, size_t workspace_bytes, void* stream, const float* kv_qo, const float* kv_oq) {
-  if (!out_f16 || !q_f16 || !k_f16 || !v_f16 || !lengths_i32 || !rope_cos_sin_f32 || !workspace) return OMNI_EINVAL;
+    void* workspace, size_t workspace_bytes, void* stream, const float* kv_qo, const float* kv_oq,
+    bool partials_only = false, int* nsplit_out = nullptr) {
+  if ((!out_f16 && !partials_only) || !q_f16 || !k_f16 || !v_f16 || !lengths_i32 || !rope_cos_sin_f32 || !workspace)
+    return OMNI_EINVAL;
   if (head_dim != DH || batch < 1 || num_heads < 1 || num_kv_heads < 1 || num_heads % num_kv_heads != 0 ||
       tokens_per_block < 16 || (tokens_per_block & (tokens_per_block - 1)) != 0 || max_context < 1 ||
       rope_max_pos < 1)
@@ -1186,9 +1188,35 @@ static int decode_fg_common(
     default: OMNI_LAUNCH_FG(4); break;
   }
 #undef OMNI_LAUNCH_FG
-  hipLaunchKernelGGL(kv4_decode_merge_kernel, dim3(batch * num_heads), dim3(128), 0, st, (half_t*)out_f16, a.part_ml,
-                     a.part_o, pl.nsplit);
+  if (!partials_only)
+    hipLaunchKernelGGL(kv4_decode_merge_kernel, dim3(batch * num_heads), dim3(128), 0, st, (half_t*)out_f16, a.part_ml,
+                       a.part_o, pl.nsplit);
+  if (nsplit_out) *nsplit_out = pl.nsplit;
   return omni_launch_status();
+}
+
+// Fused extension (LServe decode): the fine-grained / per-tensor decode attention without its merge step
+// (partials as omni_kv4_decode_attention_partial leaves them); omni_attn_merge_quant_fuse_sum finishes.
+// kv_scale_*_f32 == NULL: KV4 pages (fine_grained), else per-tensor KV8 pages.
+extern "C" int omni_kv_decode_attention_fine_grained_partial(
+    const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride, int64_t kv_stride,
+    const void* kv_scale_quant_orig_f32, const void* kv_scale_orig_quant_f32,
+    const void* retrieval_kv_pointers_i64, const void* streaming_kv_pointers_i64,
+    const void* retrieval_head_flags_i32, const void* head_rank_table_i32, const void* lengths_i32,
+    const void* dynamic_sparse_page_idx_i32, int num_dynamic_pages, int tokens_per_sub_chunk, int batch,
+    int retrieval_blocks, int streaming_blocks, int num_heads, int num_kv_heads, int num_retrieval_kv_heads,
+    int num_streaming_kv_heads, int head_dim, int tokens_per_block, int sink_tokens, int local_tokens,
+    int sink_blocks, int local_blocks, int max_context, const void* rope_cos_sin_f32, int rope_max_pos,
+    void* workspace, size_t workspace_bytes, int* nsplit_out, void* stream) {
+  if (!nsplit_out || ((kv_scale_quant_orig_f32 == nullptr) != (kv_scale_orig_quant_f32 == nullptr))) return OMNI_EINVAL;
+  return decode_fg_common(nullptr, q_f16, k_f16, v_f16, q_stride, kv_stride, retrieval_kv_pointers_i64,
+                          streaming_kv_pointers_i64, retrieval_head_flags_i32, head_rank_table_i32, lengths_i32,
+                          dynamic_sparse_page_idx_i32, num_dynamic_pages, tokens_per_sub_chunk, batch,
+                          retrieval_blocks, streaming_blocks, num_heads, num_kv_heads, num_retrieval_kv_heads,
+                          num_streaming_kv_heads, head_dim, tokens_per_block, sink_tokens, local_tokens, sink_blocks,
+                          local_blocks, max_context, rope_cos_sin_f32, rope_max_pos, workspace, workspace_bytes,
+                          stream, (const float*)kv_scale_quant_orig_f32, (const float*)kv_scale_orig_quant_f32, true,
+                          nsplit_out);
 }
 
 OMNI_CLK_READER(omni_debug_clocks_kv)

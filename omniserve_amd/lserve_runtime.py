@@ -67,7 +67,8 @@ class LServeDecodeRunner:
         # L2 weight prefetch riding on the row kernels (see omniserve_amd/runtime.py; a hint, results unaffected)
         import os
         if prefetch_mb is None:
-            prefetch_mb = float(os.environ.get("OMNI_PREFETCH_MB", "40")) if self.fused else 0.0
+            # off by default here: at batch 1 with W8A8 weights it measured 4-5 % SLOWER (profiles/r02_*)
+            prefetch_mb = float(os.environ.get("OMNI_LSERVE_PREFETCH_MB", "0")) if self.fused else 0.0
         self.prefetch_bytes = int(float(prefetch_mb) * (1 << 20)) if self.fused else 0
         if kv_format not in ("kv8", "kv4"):
             raise ValueError("kv_format must be 'kv8' (per_tensor) or 'kv4' (fine_grained)")
@@ -214,7 +215,14 @@ class LServeDecodeRunner:
             common = (self.tpb, size_r, size_s, self.sink, self.local, self.sink_blocks, self.local_blocks, self.nr,
                       self.ns, hist + 1, d, c.rope_theta, 1.0, True, not self.kv8, not self.kv8, self.sub, self.nr * d,
                       2048)
-            if self.kv8:
+            if self.fused:      # merge of the KV splits fused into the per-token quantiser (one launch less)
+                self._arm(L["o"])
+                fused_ext.sparse_decode_attention_quant(
+                    self.q_attn, sm, sc, q, k, v, self.retr_tables[li], self.strm_tables[li], self.flags, self.rank,
+                    self.page_idx[li], self.lengths, self.tpb, size_r, size_s, self.sink, self.local, self.sink_blocks,
+                    self.local_blocks, self.nr, self.ns, hist + 1, c.rope_theta, 1.0, self.sub,
+                    self.kv_qo if self.kv8 else None, self.kv_oq if self.kv8 else None)
+            elif self.kv8:
                 out = attn.single_query_attention(q, k, v, self.kv_qo, self.kv_oq, self.retr_tables[li],
                                                   self.strm_tables[li], self.flags, self.rank, self.page_idx[li],
                                                   self.lengths, None, self.max_context, *common)
@@ -222,8 +230,8 @@ class LServeDecodeRunner:
                 out = attn.single_query_attention(q, k, v, self.retr_tables[li], self.strm_tables[li], self.flags,
                                                   self.rank, self.page_idx[li], self.lengths, None, self.max_context,
                                                   *common)
-            self._arm(L["o"])
-            fused_kernels.invoke_quant(self.q_attn, out.view(B, Hq * d), sc)
+            if not self.fused:
+                fused_kernels.invoke_quant(self.q_attn, out.view(B, Hq * d), sc)
             L["o"].forward(self.q_attn, sc, self.proj_buf)
             self._arm(L["gate_up"])
             if self.fused:
