@@ -46,8 +46,8 @@ INT8_PEAK_TOPS = 5000.0     # dense int8 MFMA
 # (M, N, K, group) -> HBM bytes per launch of the decode GEMV measured with rocprofv3 --pmc (separate FETCH_SIZE /
 # WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide streaming reads on gfx950).  Taken
 # from the committed profile, NOT re-measured by the run that prints it (PMC collection wraps the process).
-PMC_TRAFFIC_BYTES = {(16, 28672, 4096, -1): 60415000}
-PMC_TRAFFIC_SOURCE = "profiles/r01_d_pmc_gemv_traffic_and_gemm_mfma.md (PMC pass of an earlier run of this kernel, not this run)"
+PMC_TRAFFIC_BYTES = {(16, 28672, 4096, -1): 60430000}
+PMC_TRAFFIC_SOURCE = "profiles/r02_b_pmc_traffic_four_gemvs.md (separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes over this kernel, not this run)"
 
 
 def event_time_ms(fn, iters, warm=3):

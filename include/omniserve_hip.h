@@ -132,6 +132,16 @@ int omni_splitk_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, 
                                               const void* weight_f16, void* sum_f16, void* scale_f16,
                                               float eps, int tokens, int hidden, void* stream);
 
+/* The same deferral for the W8A8 GEMM of the LServe models (llama_w8a8_unpad.py:382-427: o_proj / down_proj followed
+ * by the residual add and rms_norm_general): slabs from omni_w8a8_gemm_partial, epilogue h(f32(acc) * (wscales[n] *
+ * ascales[m])) applied by the consumer. */
+int omni_w8a8_gemm_partial(const void* in_feats, const void* weight, void* slab_i32, size_t slab_bytes, int M, int N,
+                           int K, int* sk_out, void* stream);
+int omni_splitk_w8_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const void* slab_i32, int sk,
+                                                 const void* wscales_f16, const void* ascales_in_f16,
+                                                 const void* weight_f16, void* sum_f16, void* scale_f16, float eps,
+                                                 int tokens, int hidden, void* stream);
+
 /* Decode attention with the flash-decoding merge fused into the following activation quantisation
  * (llama_w4a8_unpad.py:354): omni_kv4_decode_attention_partial = omni_kv4_decode_attention without its
  * merge step (*nsplit_out = S, partials stay in `workspace`: f32 [B,Hq,S,2] then f32 [B,Hq,S,128]);

@@ -56,6 +56,34 @@ def splitk_add_rms_norm_general_fuse_sum(out, residual, slab, sk, wscales, ascal
     _lib.check(rc, "fused_ext.splitk_add_rms_norm_general_fuse_sum")
 
 
+def gemm_partial_w8a8(in_feats, weight, slab):
+    """Decode-shape W8A8 GEMM without its epilogue (int32 partial sums slab[sk][M][N], returns sk); pair with
+    splitk_w8_add_rms_norm_general_fuse_sum."""
+    import ctypes
+    _lib.require_cuda(in_feats, weight, slab)
+    M, K = in_feats.shape
+    N = weight.shape[0]
+    sk = ctypes.c_int(0)
+    rc = _lib.lib().omni_w8a8_gemm_partial(in_feats.data_ptr(), weight.data_ptr(), slab.data_ptr(),
+                                           slab.numel() * slab.element_size(), M, N, K, ctypes.byref(sk),
+                                           _lib.current_stream())
+    _lib.check(rc, "fused_ext.gemm_partial_w8a8")
+    return sk.value
+
+
+def splitk_w8_add_rms_norm_general_fuse_sum(out, residual, slab, sk, wscales, ascales_in, weight, input_sum, scaling,
+                                            epsilon):
+    """residual += fp16(W8A8 GEMM epilogue(sum of sk slabs)); then norm + quant (+sum) of it."""
+    _lib.require_cuda(out, residual, slab, wscales, ascales_in, weight, input_sum, scaling)
+    hidden = residual.shape[-1]
+    tokens = residual.numel() // hidden
+    rc = _lib.lib().omni_splitk_w8_add_rms_norm_general_fuse_sum(
+        out.data_ptr(), residual.data_ptr(), slab.data_ptr(), int(sk), wscales.data_ptr(), ascales_in.data_ptr(),
+        weight.data_ptr(), input_sum.data_ptr(), scaling.data_ptr(), float(epsilon), tokens, hidden,
+        _lib.current_stream())
+    _lib.check(rc, "fused_ext.splitk_w8_add_rms_norm_general_fuse_sum")
+
+
 def decode_attention_quant_fuse_sum(out_i8, q, k, v, kv_pointers, lengths, tokens_per_block, timestep,
                                     rotary_base, input_sum, scale):
     """single_query_attention (KV4 + zeros, neox RoPE) followed by invoke_quant_fuse_sum of its

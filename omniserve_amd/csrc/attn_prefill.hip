@@ -8,15 +8,18 @@
 // sequence and q head, GQA by head index division; mask = causal (bottom-right aligned) and, for heads with
 // head_mask_type < 0, additionally (k_pos < sink  OR  q_pos - k_pos < local).
 //
-// Structure (flash-attention, online softmax, matrix cores): a workgroup of 4 waves owns 128 query rows (32 per
-// wave = two 16-row MFMA blocks) of one q head and walks the keys 64 at a time.  The K and V tiles are staged
-// once per workgroup in LDS (double buffered: the next tile travels global -> VGPR during the MFMAs and is
-// written to the other buffer at the end of the iteration, one barrier per tile), so a key row fetched from
-// L2 serves 128 queries.  S^T = K Q^T (A = K rows from LDS, XOR-swizzled 16-B slots: conflict-free
-// ds_read_b128; B = Q held in registers) leaves a lane with 4+4 keys of ONE query row per 32 keys -- exactly
-// the B-operand layout of the second product O^T = V^T P^T, whose A operand (V transposed) is read from the
-// V tile with ds_read_b64_tr_b16.  Probabilities never leave registers; row statistics reduce over the 4 lanes
-// that share a query row.  Tiles that need no masking skip the per-element predicate (workgroup-uniform).
+// Structure (flash-attention, online softmax, matrix cores): a workgroup of 8 waves owns 128 query rows (16 per
+// wave = one 16-row MFMA block; ~120 VGPRs per wave, so two workgroups = 4 waves per SIMD cover the softmax VALU
+// work of one another) of one q head and walks the keys 64 at a time.  The K and V tiles are staged once per
+// workgroup in LDS, double buffered: the next tile is issued as LDS-DMA pieces (global_load_lds, 1 KiB per wave
+// instruction, no VGPR staging) into the other buffer before the MFMAs of the current one, and the single barrier
+// per tile carries their vmcnt(0); a key row fetched from L2 serves 128 queries.  S^T = K Q^T (A = K rows from
+// LDS, XOR-swizzled 16-B slots -- applied on the global side of the DMA -- : conflict-free ds_read_b128; B = Q
+// held in registers) leaves a lane with 4+4 keys of ONE query row per 32 keys -- exactly the B-operand layout of
+// the second product O^T = V^T P^T, whose A operand (V transposed) is read from the V tile with
+// ds_read_b64_tr_b16.  Probabilities never leave registers; row statistics reduce over the 4 lanes that share a
+// query row.  Tiles that need no masking skip the per-element predicate (workgroup-uniform).  With q_tiles > 0 the
+// grid is 1-D and XCD-aware (all q heads of a kv head, and all their query tiles, on one XCD's L2).
 #include "common.h"
 
 namespace omni {

@@ -320,7 +320,9 @@ struct SrcAdd {  // residual += delta (fp16 add), in place
     *reinterpret_cast<v8h*>(res + i) = o;
   }
 };
-struct SrcSlabAddChn {  // residual += h(per-channel GEMM epilogue(sum of split-K slabs)), in place
+// ZP = true: the per-channel W4A8 epilogue ((acc*sw)*sa) - (sz*asum); ZP = false: the W8A8 / per-group one acc*(sw*sa)
+template <bool ZP>
+struct SrcSlabAddT {  // residual += h(GEMM epilogue(sum of split-K slabs)), in place
   static constexpr bool BATCH = false;   // 76 registers per vector: fetched per valid vector (hidden <= 4096: one)
   struct Raw { v4i s0, s1; v8h a, sw, sz; };
   half_t* res;
@@ -332,18 +334,18 @@ struct SrcSlabAddChn {  // residual += h(per-channel GEMM epilogue(sum of split-
   const half_t* ascales;  // [M] scales / sums of the GEMM's int8 input
   const half_t* asum;
   float sa, as;
-  __device__ __forceinline__ SrcSlabAddChn at_row(int m) const {
-    SrcSlabAddChn r = *this;
+  __device__ __forceinline__ SrcSlabAddT at_row(int m) const {
+    SrcSlabAddT r = *this;
     r.res = res + (size_t)m * stride;
     r.slab = slab + (size_t)m * stride;
     r.sa = (float)ascales[m];
-    r.as = (float)asum[m];
+    if constexpr (ZP) r.as = (float)asum[m];
     return r;
   }
   __device__ __forceinline__ void fetch(int i, Raw& r) const {
     r.a = *reinterpret_cast<const v8h*>(res + i);
     r.sw = *reinterpret_cast<const v8h*>(wscales + i);
-    r.sz = *reinterpret_cast<const v8h*>(wsz + i);
+    if constexpr (ZP) r.sz = *reinterpret_cast<const v8h*>(wsz + i);
     v4i s0 = (v4i){0, 0, 0, 0}, s1 = s0;
     {  // up to 8 slabs: all loads in flight at once (slabs beyond sk re-read slab 0 and are dropped)
       v4i t0[8], t1[8];
@@ -370,16 +372,24 @@ struct SrcSlabAddChn {  // residual += h(per-channel GEMM epilogue(sum of split-
 #pragma unroll
     for (int e = 0; e < VT; ++e) {
       const int acc = e < 4 ? r.s0[e] : r.s1[e - 4];
-      float t = (float)acc * (float)r.sw[e];
-      t = t * sa;
-      const float c = (float)r.sz[e] * as;
-      const half_t ep = (half_t)(t - c);                       // = the GEMM's fp16 output
+      half_t ep;                                               // = the GEMM's fp16 output (qgemm_kernel.h: epilogue<>)
+      if constexpr (ZP) {
+        float t = (float)acc * (float)r.sw[e];
+        t = t * sa;
+        const float c = (float)r.sz[e] * as;
+        ep = (half_t)(t - c);
+      } else {
+        const float sc = (float)r.sw[e] * sa;
+        ep = (half_t)((float)acc * sc);
+      }
       o[e] = (half_t)((float)r.a[e] + (float)ep);
       x[e] = (float)o[e];
     }
     *reinterpret_cast<v8h*>(res + i) = o;
   }
 };
+typedef SrcSlabAddT<true> SrcSlabAddChn;
+typedef SrcSlabAddT<false> SrcSlabAddW8;
 struct SrcSilu {  // h(h(silu(gate)) * up) of a [2d] row
   static constexpr bool BATCH = true;
   struct Raw { v8h a, b; };
@@ -1006,6 +1016,28 @@ extern "C" int omni_splitk_add_rms_norm_general_fuse_sum(void* out_i8, void* res
   const bool v2_batched = false;
   #undef KQ_
   #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, true, SrcSlabAddChn>
+  OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8, src,
+                 (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
+  return omni_launch_status();
+}
+
+// The same for the W8A8 GEMM (omni_w8a8_gemm_partial): epilogue h(f32(acc) * (wscales[n] * ascales[m])), no zero term.
+extern "C" int omni_splitk_w8_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const void* slab_i32, int sk,
+                                                            const void* wscales_f16, const void* ascales_in_f16,
+                                                            const void* weight_f16, void* sum_f16, void* scale_f16,
+                                                            float eps, int tokens, int hidden, void* stream) {
+  if (!out_i8 || !residual_f16 || !slab_i32 || !wscales_f16 || !ascales_in_f16 || !weight_f16 || !sum_f16 ||
+      !scale_f16 || tokens < 0 || hidden < 1 || sk < 1)
+    return OMNI_EINVAL;
+  const int nv = norm_block(hidden, true);
+  if (!v2_ok(hidden, nv)) return OMNI_EINVAL;
+  if (tokens == 0) return OMNI_OK;
+  SrcSlabAddW8 src{(half_t*)residual_f16, (const int32_t*)slab_i32, (size_t)tokens * hidden, sk, hidden,
+                   (const half_t*)wscales_f16, (const half_t*)nullptr, (const half_t*)ascales_in_f16,
+                   (const half_t*)nullptr, 0.f, 0.f};
+  const bool v2_batched = false;
+  #undef KQ_
+  #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, true, SrcSlabAddW8>
   OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8, src,
                  (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
   return omni_launch_status();

@@ -449,28 +449,33 @@ struct GemvCfg {
 //     without the slab round trip of a grid-level split.
 // NT: weight loads carry the non-temporal hint (weights streamed once from HBM, the default); false = plain loads,
 // for weights a preceding row kernel has prefetched into the L2s (omni_prefetch_arm_gemm, omni_gemm_set_weight_policy).
-template <int MB, int MODE, bool TO_SLAB, int KW = 1, bool NT = true>
-__global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_gemv_kernel(GemmArgs p) {
+// MZ = 2 (M = 65..128): the workgroup carries BOTH 64-row tiles of its channel group -- waves (kw, half) -- so the two
+// reads of a weight byte are issued side by side by waves of one CU (the second is served by L1 / the in-flight line in
+// L2) instead of by two workgroups somewhere on the chip at different times.
+template <int MB, int MODE, bool TO_SLAB, int KW = 1, bool NT = true, int MZ = 1>
+__global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), 1) void w4a8_gemv_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
   constexpr int WAVES = GemvCfg<MB, MODE>::WAVES;
   static_assert(KW == 1 || WAVES == 1, "in-workgroup K split is for single-wave tiles");
   static_assert(KW <= GemvCfg<MB, MODE>::MAX_KW, "LDS budget");
   static_assert(KW == 1 || KW == 2 || KW == 4, "KW");
+  static_assert(MZ == 1 || (MZ == 2 && WAVES == 1), "row-tile pairs are for single-wave tiles");
   constexpr int NTHREADS = 64 * WAVES;                   // threads sharing one staged activation tile
   constexpr int WL = GemvCfg<MB, MODE>::WL;
   constexpr int RING = GemvCfg<MB, MODE>::RING;
   constexpr int RK = RING * KSTEP;                       // k per round
   constexpr int APT = (MT * RK / 16) / NTHREADS;          // 16-B activation pieces per thread per round
   static_assert((MT * RK / 16) % NTHREADS == 0, "activation round must tile the workgroup");
-  __shared__ __attribute__((aligned(16))) uint8_t lds_all[KW][2][MT * RK];
+  __shared__ __attribute__((aligned(16))) uint8_t lds_all[KW * MZ][2][MT * RK];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int kw = KW > 1 ? wave : 0;                       // K part of this wave
-  const int tid = KW > 1 ? lane : threadIdx.x;            // index inside the staging group
-  uint8_t (*lds)[MT * RK] = lds_all[kw];
-  const int ng = KW > 1 ? blockIdx.x : blockIdx.x * WAVES + wave;
-  const int m0 = blockIdx.z * MT;                        // row tile (grid.z > 1 only for M > 64)
+  const int half = MZ > 1 ? wave / KW : 0;                // row tile of this wave inside the workgroup
+  const int kw = (KW > 1 || MZ > 1) ? wave % KW : 0;      // K part of this wave
+  const int tid = (KW > 1 || MZ > 1) ? lane : threadIdx.x;   // index inside the staging group
+  uint8_t (*lds)[MT * RK] = lds_all[kw + KW * half];
+  const int ng = (KW > 1 || MZ > 1) ? blockIdx.x : blockIdx.x * WAVES + wave;
+  const int m0 = (blockIdx.z * MZ + half) * MT;          // row tile (M > 64: grid.z = 2, or both tiles in the workgroup)
   const bool wave_active = (ng * 64) < p.N;
   const int kpart = p.kslice / KW;                        // host: kslice % (64 * KW) == 0 when KW > 1
   const int k_begin = blockIdx.y * p.kslice + kw * kpart;
@@ -695,7 +700,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_
   if constexpr (KW > 1) {
     // every wave used only its own buffers so far: park the partials there, then meet
     static_assert(MB * 4 * 64 * 16 <= 2 * MT * RK, "partials must fit the wave's staging buffers");
-    v4i* mine = reinterpret_cast<v4i*>(&lds_all[kw][0][0]);
+    v4i* mine = reinterpret_cast<v4i*>(&lds_all[kw + KW * half][0][0]);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -713,7 +718,8 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW), 1) void w4a8_
       if constexpr (KW > 1) {
         a4 = (v4i){0, 0, 0, 0};
 #pragma unroll
-        for (int w = 0; w < KW; ++w) a4 += reinterpret_cast<const v4i*>(&lds_all[w][0][0])[(mb * 4 + ab) * 64 + lane];
+        for (int w = 0; w < KW; ++w)
+          a4 += reinterpret_cast<const v4i*>(&lds_all[w + KW * half][0][0])[(mb * 4 + ab) * 64 + lane];
       }
       if (m >= p.M) continue;
       const int n = chan(ab);
@@ -785,7 +791,7 @@ struct GemmPlan {
 // Tuning hook (tests / bench sweeps): waves<=0 and sk<=0 restore the heuristic.
 extern "C" void omni_gemm_set_plan_override(int waves, int sk);
 extern "C" void omni_gemm_get_plan(int M, int N, int K, int kalign, int* mb, int* waves, int* sk);
-GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred = false);
+GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred = false, bool w8 = false);
 
 template <int MODE, int MB, int WAVES>
 static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
@@ -819,6 +825,12 @@ static void launch_gemv_kernel_nt(const GemmArgs& a, const GemmPlan& pl, hipStre
       return;
     }
   }
+  if constexpr (MB == 4) {
+    if (pl.kw == 2 && pl.mz == 2) {   // both 64-row tiles of a channel group in one workgroup (4 waves, 128 KiB of LDS)
+      hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 2, NT, 2>), dim3(grid.x, grid.y, 1), dim3(256), 0, st, a);
+      return;
+    }
+  }
   if constexpr (MB == 2 || MB == 4) {
     if (pl.kw == 2) {
       hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 2, NT>), grid, dim3(128), 0, st, a);
@@ -849,7 +861,7 @@ template <int MODE>
 static int launch_gemm(GemmArgs a, void* ws, size_t ws_bytes, hipStream_t st) {
   if (a.M < 1 || a.N % 64 != 0 || a.K % 64 != 0 || a.K < 64) return OMNI_EINVAL;
   if (MODE == MODE_GRP && a.K % 128 != 0) return OMNI_EINVAL;
-  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64);
+  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64, false, MODE == MODE_W8);
   if (pl.sk > 1) {
     const size_t need = (size_t)pl.sk * a.M * a.N * sizeof(int32_t);
     if (ws == nullptr || ws_bytes < need) return OMNI_ENOMEM;
@@ -878,7 +890,7 @@ template <int MODE>
 static int launch_gemm_partial(GemmArgs a, void* slab, size_t slab_bytes, int* sk_out, hipStream_t st) {
   if (a.M < 1 || a.M > 128 || a.N % 64 != 0 || a.K % 64 != 0 || a.K < 64 || !slab || !sk_out) return OMNI_EINVAL;
   if (MODE == MODE_GRP && a.K % 128 != 0) return OMNI_EINVAL;
-  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64, true);
+  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64, true, MODE == MODE_W8);
   if (slab_bytes < (size_t)pl.sk * a.M * a.N * sizeof(int32_t)) return OMNI_ENOMEM;
   a.slab = static_cast<int32_t*>(slab);
   a.kslice = pl.kslice;

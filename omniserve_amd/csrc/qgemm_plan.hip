@@ -15,7 +15,7 @@ PrefetchArgs take_armed_prefetch() {
   return pf;
 }
 
-GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred) {
+GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
   GemmPlan pl;
   pl.kw = 1;
   pl.mz = 1;
@@ -40,13 +40,15 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred) {
     while (kw > 1 && (K % (kw * kalign)) != 0) kw >>= 1;
     auto part = [&](int s) { return K / (s * kw); };
     auto fits = [&](int s) { return ok(s) && ((K / s) % (kw * kalign)) == 0; };
+    // W8A8 rows are twice the bytes per k: the deferred (slab-only) plan halves the k per wave (same bytes per wave)
+    const int part_target = (deferred && w8) ? 256 : 512;
     if (!deferred && part(1) <= 1024) {
       sk = 1;
     } else {
       int best = 0;
       for (int s = 1; s <= 64; ++s) {
         if (!fits(s) || part(s) < 256) continue;
-        if (part(s) <= 512) { best = s; break; }
+        if (part(s) <= part_target) { best = s; break; }
         best = s;   // largest usable split so far
       }
       sk = best > 0 ? best : 1;
@@ -89,7 +91,7 @@ extern "C" void omni_gemm_set_plan_override(int waves, int sk) {
 }
 
 extern "C" void omni_gemm_get_plan(int M, int N, int K, int kalign, int* mb, int* waves, int* sk) {
-  omni::GemmPlan pl = omni::plan_gemm(M, N, K, kalign, false);
+  omni::GemmPlan pl = omni::plan_gemm(M, N, K, kalign, false, false);
   if (mb) *mb = pl.mb;
   if (waves) *waves = pl.waves;
   if (sk) *sk = pl.sk;
@@ -103,8 +105,10 @@ extern "C" size_t omni_gemm_workspace_bytes(int M, int N, int K) {
   for (int kalign = 64; kalign <= 128; kalign *= 2) {
     if (K % kalign != 0) continue;
     for (int deferred = 0; deferred < 2; ++deferred) {
-      const omni::GemmPlan pl = omni::plan_gemm(M, N, K, kalign, deferred != 0);
-      if (pl.sk > sk) sk = pl.sk;
+      for (int w8 = 0; w8 < 2; ++w8) {
+        const omni::GemmPlan pl = omni::plan_gemm(M, N, K, kalign, deferred != 0, w8 != 0);
+        if (pl.sk > sk) sk = pl.sk;
+      }
     }
   }
   return (size_t)sk * M * N * sizeof(int32_t);
@@ -119,7 +123,7 @@ extern "C" int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, i
   g_armed_prefetch = PrefetchArgs{};
   if (!weight || blocks <= 0 || budget_bytes <= 0) return OMNI_OK;          // disarm
   if (mode < 0 || mode > 2 || M < 1 || M > 128 || N % 64 != 0 || K % 64 != 0 || K < 64) return OMNI_EINVAL;
-  const GemmPlan pl = plan_gemm(M, N, K, mode == MODE_GRP ? 128 : 64, deferred != 0);
+  const GemmPlan pl = plan_gemm(M, N, K, mode == MODE_GRP ? 128 : 64, deferred != 0, mode == MODE_W8);
   PrefetchArgs pf{};
   pf.base = static_cast<const uint8_t*>(weight);
   const int groups_per_wg = pl.waves;                                       // 64-channel groups per workgroup

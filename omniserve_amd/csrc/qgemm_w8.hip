@@ -13,3 +13,13 @@ extern "C" int omni_w8a8_gemm(const void* in_feats, const void* weight, const vo
   a.out = (half_t*)out_feats; a.M = M; a.N = N; a.K = K; a.out_stride = out_row_stride;
   return launch_gemm<MODE_W8>(a, workspace, workspace_bytes, (hipStream_t)stream);
 }
+
+// Fused extension: split-K partial sums only (see omni_splitk_w8_add_rms_norm_general_fuse_sum).
+extern "C" int omni_w8a8_gemm_partial(const void* in_feats, const void* weight, void* slab_i32, size_t slab_bytes, int M,
+                                      int N, int K, int* sk_out, void* stream) {
+  if (!in_feats || !weight) return OMNI_EINVAL;
+  GemmArgs a{};
+  a.A = (const int8_t*)in_feats; a.W = (const uint8_t*)weight;
+  a.M = M; a.N = N; a.K = K; a.out_stride = N;
+  return launch_gemm_partial<MODE_W8>(a, slab_i32, slab_bytes, sk_out, (hipStream_t)stream);
+}

@@ -153,6 +153,10 @@ class LServeDecodeRunner:
         self.q_attn = torch.empty((B, Hq * d), dtype=i8, device=device)
         self.act_scale = torch.empty((B,), dtype=f16, device=device)
         self.act_sum = torch.empty((B,), dtype=f16, device=device)    # by-product of the fused entry points, unused
+        self.act_scale2 = torch.empty((B,), dtype=f16, device=device)  # scales written by the quant-type kernels
+        # fused: o_proj / down_proj leave int32 split-K slabs; the next add+norm kernel applies the GEMM epilogue
+        self.defer = self.fused and os.environ.get("OMNI_LSERVE_DEFER", "1") != "0"
+        self.slab = torch.empty((16 << 20,), dtype=torch.uint8, device=device) if self.defer else None
         self.qkv_buf = torch.empty((B, qkv_n), dtype=f16, device=device)
         self.proj_buf = torch.empty((B, c.hidden), dtype=f16, device=device)
         self.gate_up_buf = torch.empty((B, 2 * c.inter), dtype=f16, device=device)
@@ -169,9 +173,9 @@ class LServeDecodeRunner:
         self.graphs = {}
         self.steps_done = 0
 
-    def _arm(self, lin):
+    def _arm(self, lin, deferred=False):
         if self.prefetch_bytes > 0:
-            fused_ext.prefetch_arm_gemm(lin.weight, self.B, lin.n, lin.k, 2, False, self.prefetch_bytes, 240)
+            fused_ext.prefetch_arm_gemm(lin.weight, self.B, lin.n, lin.k, 2, deferred, self.prefetch_bytes, 240)
 
     # one decode step; `select` = this step refreshes the page selection (every `interval`-th step upstream)
     def _eager_step(self, hist: int, select: bool):
@@ -181,14 +185,21 @@ class LServeDecodeRunner:
         Hq, Hk, d = c.heads, c.kv_heads, c.head_dim
         self.lengths.add_(1)
         torch.index_select(self.embed, 0, self.tokens, out=self.x)
-        sc = self.act_scale
+        sc = self.act_scale                      # scales written by the norm kernels
+        sq = self.act_scale2 if self.fused else sc   # ... by the quantisers (kept apart: a deferred epilogue reads them)
+        pending = None                           # (sk, linear) of a down_proj whose epilogue is deferred
+        nl = len(self.layers)
         attn = fused_attention_per_tensor_sparse if self.kv8 else fused_attention_fine_grained_sparse
         size_r, size_s = self.nr * self.row, self.ns * self.row
         total_pages = hist // self.tpb + 1
         sm = self.act_sum
         for li, L in enumerate(self.layers):
             self._arm(L["qkv"])
-            if self.fused and li > 0:     # residual += down_proj(previous layer), then norm + quant
+            if pending is not None:       # residual += down_proj(previous layer) [deferred epilogue], norm + quant
+                fused_ext.splitk_w8_add_rms_norm_general_fuse_sum(self.q_hidden, self.x, self.slab, pending[0],
+                                                                  pending[1].dequant_scale, sq, L["ln1"], sm, sc, c.eps)
+                pending = None
+            elif self.fused and li > 0:   # residual += down_proj(previous layer), then norm + quant
                 fused_ext.add_rms_norm_general_fuse_sum(self.q_hidden, self.x, self.proj_buf, L["ln1"], sm, sc, c.eps)
             else:
                 layernorm_ops.rms_norm_general(self.q_hidden, self.x, L["ln1"], sc, c.eps, True)
@@ -216,9 +227,9 @@ class LServeDecodeRunner:
                       self.ns, hist + 1, d, c.rope_theta, 1.0, True, not self.kv8, not self.kv8, self.sub, self.nr * d,
                       2048)
             if self.fused:      # merge of the KV splits fused into the per-token quantiser (one launch less)
-                self._arm(L["o"])
+                self._arm(L["o"], self.defer)
                 fused_ext.sparse_decode_attention_quant(
-                    self.q_attn, sm, sc, q, k, v, self.retr_tables[li], self.strm_tables[li], self.flags, self.rank,
+                    self.q_attn, sm, sq, q, k, v, self.retr_tables[li], self.strm_tables[li], self.flags, self.rank,
                     self.page_idx[li], self.lengths, self.tpb, size_r, size_s, self.sink, self.local, self.sink_blocks,
                     self.local_blocks, self.nr, self.ns, hist + 1, c.rope_theta, 1.0, self.sub,
                     self.kv_qo if self.kv8 else None, self.kv_oq if self.kv8 else None)
@@ -231,24 +242,33 @@ class LServeDecodeRunner:
                                                   self.rank, self.page_idx[li], self.lengths, None, self.max_context,
                                                   *common)
             if not self.fused:
-                fused_kernels.invoke_quant(self.q_attn, out.view(B, Hq * d), sc)
-            L["o"].forward(self.q_attn, sc, self.proj_buf)
+                fused_kernels.invoke_quant(self.q_attn, out.view(B, Hq * d), sq)
+            if self.defer:
+                sk = fused_ext.gemm_partial_w8a8(self.q_attn, L["o"].weight, self.slab)
+            else:
+                L["o"].forward(self.q_attn, sq, self.proj_buf)
             self._arm(L["gate_up"])
-            if self.fused:
+            if self.defer:
+                fused_ext.splitk_w8_add_rms_norm_general_fuse_sum(self.q_hidden, self.x, self.slab, sk,
+                                                                  L["o"].dequant_scale, sq, L["ln2"], sm, sc, c.eps)
+            elif self.fused:
                 fused_ext.add_rms_norm_general_fuse_sum(self.q_hidden, self.x, self.proj_buf, L["ln2"], sm, sc, c.eps)
             else:
                 self.x.add_(self.proj_buf)
                 layernorm_ops.rms_norm_general(self.q_hidden, self.x, L["ln2"], sc, c.eps, True)
             L["gate_up"].forward(self.q_hidden, sc, self.gate_up_buf)
-            self._arm(L["down"])
+            self._arm(L["down"], self.defer and li < nl - 1)
             if self.fused:
-                fused_ext.silu_mul_quant_fuse_sum(self.q_inter, self.gate_up_buf, sm, sc)
+                fused_ext.silu_mul_quant_fuse_sum(self.q_inter, self.gate_up_buf, sm, sq)
             else:
                 activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
-                fused_kernels.invoke_quant(self.q_inter, self.mlp_act, sc)
-            L["down"].forward(self.q_inter, sc, self.proj_buf)
-            if not self.fused or li == len(self.layers) - 1:
-                self.x.add_(self.proj_buf)
+                fused_kernels.invoke_quant(self.q_inter, self.mlp_act, sq)
+            if self.defer and li < nl - 1:
+                pending = (fused_ext.gemm_partial_w8a8(self.q_inter, L["down"].weight, self.slab), L["down"])
+            else:
+                L["down"].forward(self.q_inter, sq, self.proj_buf)
+                if not self.fused or li == nl - 1:
+                    self.x.add_(self.proj_buf)
         layernorm_ops.rms_norm(self.normed, self.x, self.final_norm, c.eps, False)
         logits = torch.matmul(self.normed, self.lm_head.t())
         fused_ext.argmax(self.tokens, logits)

@@ -160,6 +160,46 @@ def test_deferred_splitk_epilogue_matches_gemm_then_add_norm():
     assert_f16_equal(sm2, smo, "sum")
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (16, 4096, 14336), (3, 2048, 4096), (33, 4096, 4096)])
+def test_deferred_splitk_w8_epilogue_matches_gemm_then_add_norm(M, N, K):
+    """o_proj / down_proj of the fused LServe runner (W8A8): partial GEMM + slab-consuming add+norm must equal the
+    reference sequence w8a8_gemm -> residual add -> rms_norm_general bit for bit (llama_w8a8_unpad.py:382-427)."""
+    import omniserve_backend.layernorm_ops as ln
+    import omniserve_backend.qgemm_w8a8 as gemm
+    from omniserve_amd.backend import fused_ext
+    from oracle import w4a8
+    rng = np.random.default_rng(M + K)
+    w = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+    sw = rng.uniform(0.0002, 0.0014, size=(N,)).astype(np.float16)
+    a, sa, _ = oe.quant_per_token(_x(M, K, 5, 1.0), False)
+    resid = _x(M, N, 6, 2.0)
+    g = (1.0 + 0.1 * np.random.default_rng(1).standard_normal(N)).astype(np.float16)
+    w_d, sw_d, a_d, sa_d, g_d = map(to_dev, (w, sw, a, sa, g))
+    # reference sequence
+    proj = torch.empty((M, N), dtype=torch.float16, device=dev())
+    gemm.w8a8_gemm_forward_cuda(a_d, w_d, sw_d, sa_d, proj)
+    x1 = to_dev(resid); x1.add_(proj)
+    q1 = torch.empty((M, N), dtype=torch.int8, device=dev()); sc1 = torch.empty((M,), dtype=torch.float16, device=dev())
+    ln.rms_norm_general(q1, x1, g_d, sc1, 1e-5, True)
+    # deferred epilogue
+    slab = torch.empty((64 << 20,), dtype=torch.uint8, device=dev())
+    sk = fused_ext.gemm_partial_w8a8(a_d, w_d, slab)
+    x2 = to_dev(resid)
+    q2 = torch.empty_like(q1); sc2 = torch.empty_like(sc1); sm2 = torch.empty_like(sc1)
+    fused_ext.splitk_w8_add_rms_norm_general_fuse_sum(q2, x2, slab, sk, sw_d, sa_d, g_d, sm2, sc2, 1e-5)
+    torch.cuda.synchronize()
+    assert sk >= 1
+    assert torch.equal(x1.view(torch.int16), x2.view(torch.int16))
+    assert torch.equal(q1, q2) and torch.equal(sc1.view(torch.int16), sc2.view(torch.int16))
+    # and against the oracle
+    want = w4a8.gemm_w8a8(a, w, sw, sa)
+    xs = (resid.astype(np.float32) + want.astype(np.float32)).astype(np.float16)
+    qo, so, smo = oe.rms_norm_general(xs, g, 1e-5, True)
+    assert np.array_equal(q2.cpu().numpy(), qo)
+    assert_f16_equal(sc2, so, "scale")
+    assert_f16_equal(sm2, smo, "sum")
+
+
 def test_argmax_matches_torch():
     """Greedy-sampling helper (fused_ext.argmax): first maximum, -0 == +0, NaN wins, ragged and unaligned shapes."""
     from omniserve_amd.backend import fused_ext
