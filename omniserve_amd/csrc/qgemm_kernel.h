@@ -431,16 +431,28 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
 //     two 64-row tiles per channel group (grid.z).
 //   * no control flow inside a round, so every wait is a counted s_waitcnt vmcnt(N).
 // ------------------------------------------------------------------------------------------
+#ifndef OMNI_GEMV_RING_MB4
+#define OMNI_GEMV_RING_MB4 4
+#endif
+#ifndef OMNI_GEMV_AR_MB4
+#define OMNI_GEMV_AR_MB4 2      // k-steps per activation round of the 64-row tile: 2 = 8-KiB rounds, four K parts per
+#endif                          // workgroup, two waves per SIMD (measured 10-15 % faster at M = 64 than 4 = 16-KiB rounds, two parts)
+#ifndef OMNI_GEMV_ABLATE
+#define OMNI_GEMV_ABLATE 0      // timing experiments (wrong results): 1 no activation reloads, 2 a quarter of the MFMAs,
+#endif                          // 4 no weight reloads, 8 no LDS publication of the next activation round
 template <int MB, int MODE>
 struct GemvCfg {
   static constexpr int WL = (MODE == MODE_W8) ? 4 : 2;
-  static constexpr int RING = (MODE == MODE_W8) ? 4 : (MB <= 2 ? 8 : 4);
+  // AR = k-steps per activation round (one LDS buffer), RING = k-steps of weights in flight per wave (a multiple of AR:
+  // the 64-row tile keeps 16-KiB activation rounds but a deeper weight ring -- bytes in flight per wave are what bounds it)
+  static constexpr int AR = (MODE == MODE_W8) ? 4 : (MB <= 2 ? 8 : OMNI_GEMV_AR_MB4);
+  static constexpr int RING = (MODE == MODE_W8) ? 4 : (MB <= 2 ? 8 : OMNI_GEMV_RING_MB4);
   // single-wave tiles of up to 64 rows (no barrier; K is split over the workgroup's KW waves instead).  M = 65..128
   // runs as two 64-row tiles per channel group (grid.z = 2): the second read of the packed weights is served by
   // L2 / MALL.  (Round 1 had a 128-row tile here -- four channel groups per workgroup sharing a 32-KiB activation
   // round, 128 accumulator registers per wave spilling into AGPRs, an 8-KiB weight ring: 0.6 TB/s; removed.)
   static constexpr int WAVES = 1;
-  static constexpr int MAX_KW = MB == 1 ? 4 : 2;   // LDS: KW x 2 buffers x MT x RK <= 64 KiB
+  static constexpr int MAX_KW = (MB == 1 || (MB == 4 && MODE != MODE_W8 && OMNI_GEMV_AR_MB4 == 2)) ? 4 : 2;   // LDS: KW x 2 buffers x MT x RK <= 64 KiB
 };
 
 //   * KW > 1 (single 64-channel group per workgroup only): KW waves split the workgroup's K-slice,
@@ -453,7 +465,7 @@ struct GemvCfg {
 // reads of a weight byte are issued side by side by waves of one CU (the second is served by L1 / the in-flight line in
 // L2) instead of by two workgroups somewhere on the chip at different times.
 template <int MB, int MODE, bool TO_SLAB, int KW = 1, bool NT = true, int MZ = 1>
-__global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), 1) void w4a8_gemv_kernel(GemmArgs p) {
+__global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 4 && KW == 4 && MZ == 1) ? 2 : 1)) void w4a8_gemv_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
   constexpr int WAVES = GemvCfg<MB, MODE>::WAVES;
   static_assert(KW == 1 || WAVES == 1, "in-workgroup K split is for single-wave tiles");
@@ -463,7 +475,10 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), 1) void 
   constexpr int NTHREADS = 64 * WAVES;                   // threads sharing one staged activation tile
   constexpr int WL = GemvCfg<MB, MODE>::WL;
   constexpr int RING = GemvCfg<MB, MODE>::RING;
-  constexpr int RK = RING * KSTEP;                       // k per round
+  constexpr int AR = GemvCfg<MB, MODE>::AR;
+  constexpr int SUB = RING / AR;                         // activation rounds per ring round
+  static_assert(RING % AR == 0 && (SUB == 1 || SUB % 2 == 0), "ring = whole activation rounds, buffer parity static");
+  constexpr int RK = AR * KSTEP;                         // k per activation round
   constexpr int APT = (MT * RK / 16) / NTHREADS;          // 16-B activation pieces per thread per round
   static_assert((MT * RK / 16) % NTHREADS == 0, "activation round must tile the workgroup");
   __shared__ __attribute__((aligned(16))) uint8_t lds_all[KW * MZ][2][MT * RK];
@@ -611,9 +626,13 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), 1) void 
     for (int mb = 0; mb < MB; ++mb) {
       const int pos = (MODE == MODE_W8) ? (lane >> 4) : (((lane >> 4) + s) & 3);
       const v4i bf = *reinterpret_cast<const v4i*>(abuf + ((s * MT + mb * 16 + (lane & 15)) * 4 + pos) * 16);
+#if (OMNI_GEMV_ABLATE & 2)      // timing experiment: one MFMA per row block instead of four (wrong results)
+      acc[mb][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[0] ^ wa[1] ^ wa[2] ^ wa[3], bf, acc[mb][0], 0, 0, 0);
+#else
 #pragma unroll
       for (int ab = 0; ab < 4; ++ab)
         acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf, acc[mb][ab], 0, 0, 0);
+#endif
     }
   };
 
@@ -635,31 +654,52 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), 1) void 
     if constexpr (WAVES > 1) __syncthreads();
     // ---- steady state ---------------------------------------------------------------------------
     for (int r = 0; r + 1 < rounds; ++r) {
-      load_a(k_begin + (r + 1) * RK);
-      const uint8_t* abuf = lds[r & 1];
 #pragma unroll
-      for (int s = 0; s < RING; ++s) {
-        v4i wa[4];
-        unpack(wq[s], gs[s], gz[s], wa);
-        const int kn = k_begin + (r + 1) * RK + s * KSTEP;
+      for (int sub = 0; sub < SUB; ++sub) {
+#if !(OMNI_GEMV_ABLATE & 1)
+        load_a(k_begin + ((r * SUB + sub) + 1) * RK);
+#endif
+        const int par = SUB == 1 ? (r & 1) : (sub & 1);
+        const uint8_t* abuf = lds[par];
 #pragma unroll
-        for (int j = 0; j < WL; ++j) wq[s][j] = load_w(kn, j);
-        if constexpr (MODE == MODE_GRP) {
-          gs[s] = load_gp(p.s2s, kn);
-          gz[s] = load_gp(p.s2z, kn);
+        for (int s = 0; s < AR; ++s) {
+          const int slot = sub * AR + s;
+          v4i wa[4];
+          unpack(wq[slot], gs[slot], gz[slot], wa);
+          const int kn = k_begin + ((r + 1) * RING + slot) * KSTEP;
+#if !(OMNI_GEMV_ABLATE & 4)
+#pragma unroll
+          for (int j = 0; j < WL; ++j) wq[slot][j] = load_w(kn, j);
+#endif
+          if constexpr (MODE == MODE_GRP) {
+            gs[slot] = load_gp(p.s2s, kn);
+            gz[slot] = load_gp(p.s2z, kn);
+          }
+          mma_step(wa, abuf, s);
         }
-        mma_step(wa, abuf, s);
+#if !(OMNI_GEMV_ABLATE & 8)
+        store_a(par ^ 1);
+#endif
+        if constexpr (WAVES > 1) __syncthreads();
       }
-      store_a((r + 1) & 1);
-      if constexpr (WAVES > 1) __syncthreads();
     }
     {  // last round: drain the ring
-      const uint8_t* abuf = lds[(rounds - 1) & 1];
 #pragma unroll
-      for (int s = 0; s < RING; ++s) {
-        v4i wa[4];
-        unpack(wq[s], gs[s], gz[s], wa);
-        mma_step(wa, abuf, s);
+      for (int sub = 0; sub < SUB; ++sub) {
+        if (sub + 1 < SUB) load_a(k_begin + (((rounds - 1) * SUB + sub) + 1) * RK);
+        const int par = SUB == 1 ? ((rounds - 1) & 1) : (sub & 1);
+        const uint8_t* abuf = lds[par];
+#pragma unroll
+        for (int s = 0; s < AR; ++s) {
+          const int slot = sub * AR + s;
+          v4i wa[4];
+          unpack(wq[slot], gs[slot], gz[slot], wa);
+          mma_step(wa, abuf, s);
+        }
+        if (sub + 1 < SUB) {
+          store_a(par ^ 1);
+          if constexpr (WAVES > 1) __syncthreads();
+        }
       }
     }
   }
@@ -822,6 +862,16 @@ static void launch_gemv_kernel_nt(const GemmArgs& a, const GemmPlan& pl, hipStre
     }
     if (pl.kw == 2) {
       hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, TO_SLAB, 2, NT>), grid, dim3(128), 0, st, a);
+      return;
+    }
+  }
+  if constexpr (MB == 4 && GemvCfg<MB, MODE>::MAX_KW == 4) {
+    if (pl.kw == 4 && pl.mz == 2) {
+      hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 4, NT, 2>), dim3(grid.x, grid.y, 1), dim3(512), 0, st, a);
+      return;
+    }
+    if (pl.kw == 4) {
+      hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 4, NT>), grid, dim3(256), 0, st, a);
       return;
     }
   }

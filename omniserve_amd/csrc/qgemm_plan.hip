@@ -63,18 +63,28 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
     // M > 32 (64-row tiles: 20-us kernels, the 5-us slab epilogue is cheap next to them) keeps splitting, down to
     // 512 k per wave, until ~1.5 workgroups per CU are in flight: at bs = 64 the Llama-3-8B qkv / o projections ran
     // on 96 / 64 workgroups at 0.6 TB/s (profiles/r02_*).
-    int kw = 2;
+    int kw = (pl.mb == 4 && !w8 && OMNI_GEMV_AR_MB4 == 2) ? 4 : 2;
     while (kw > 1 && (K % (kw * kalign)) != 0) kw >>= 1;
     auto fits = [&](int s) { return ok(s) && ((K / s) % (kw * kalign)) == 0; };
-    int best = 1;
-    for (int s = 1; s <= 64; ++s) {
-      if (!fits(s) || K / (s * kw) < 512) continue;
-      best = s;
-      if (K / (s * kw) <= 2048 && (pl.mb < 4 || ngroups * s * pl.mz >= 384)) break;
+    // a part should be whole ring rounds (the remainder runs one unpipelined step at a time)
+    const int ring_k = 64 * (w8 ? 4 : (pl.mb == 4 ? OMNI_GEMV_RING_MB4 : 8));
+    int best = 0;
+    for (int strict = 1; strict >= 0 && best == 0; --strict) {
+      for (int s = 1; s <= 64; ++s) {
+        const int part = K / (s * kw);
+        if (!fits(s) || part < (kw == 4 ? 256 : 512) || (strict && (part % ring_k) != 0)) continue;
+        best = s;
+        if (kw == 4) {   // 64-row tile, four K parts per workgroup: <= 1024 k per wave and >= 768 waves (measured, r02_e)
+          if (part <= 1024 && ngroups * s * pl.mz * kw >= 768) break;
+        } else if (part <= 2048 && (pl.mb < 4 || ngroups * s * pl.mz >= 384)) {
+          break;
+        }
+      }
     }
+    if (best == 0) best = 1;
     sk = best;
     if (g_override_sk > 0 && ok(g_override_sk)) sk = g_override_sk;
-    if (g_override_waves == 1 || g_override_waves == 2) kw = g_override_waves;
+    if (g_override_waves == 1 || g_override_waves == 2 || (g_override_waves == 4 && kw == 4)) kw = g_override_waves;
     while (kw > 1 && ((K / sk) % (kw * kalign)) != 0) kw >>= 1;
     pl.kw = kw;
   }
