@@ -354,13 +354,14 @@ class DecodeRunner:
             self.tokens.copy_(torch.argmax(logits, dim=-1))
 
     # ---- prefill (context stage) ---------------------------------------------------------------------------
-    def prefill(self, prompt_len=None):
+    def prefill(self, prompt_len=None, tokens=None):
         """One context-stage pass over `prompt_len` tokens per sequence in the order of the reference's decoder
         layer at prefill shape (llama_w4a8_unpad.py:406-438 with M = B * prompt_len; ctx_update_kv.py:96-135;
         ctx_attn_func.py:68-73): norm+quant -> qkv GEMM -> RoPE in place + KV4 page write -> varlen causal
         attention -> quant -> o GEMM -> add -> norm+quant -> gate_up GEMM -> silu*mul -> quant -> down GEMM -> add.
         Fills the KV pools for positions [0, prompt_len) and leaves the first generated token in self.tokens
-        (self.lengths = prompt_len), i.e. the qserve_benchmark.py protocol's prefill step.  Eager launches."""
+        (self.lengths = prompt_len), i.e. the qserve_benchmark.py protocol's prefill step.  Eager launches.
+        `tokens`: the B * prompt_len prompt token ids, sequence after sequence (default: random ids)."""
         import omniserve_backend.fused_attention_fine_grained_dense as fgd
         from .backend.prefill_attn import flash_attn_varlen_func
         c, B, dev = self.cfg, self.B, self.device
@@ -384,7 +385,10 @@ class DecodeRunner:
             self._prefill_bufs = buf
         x, qh, qi, qa, qkv, proj, gu = buf["x"], buf["qh"], buf["qi"], buf["qa"], buf["qkv"], buf["proj"], buf["gu"]
         sB, mB, sA, mA = buf["s1"], buf["m1"], buf["s2"], buf["m2"]
-        tokens = torch.randint(0, c.vocab, (T,), device=dev, generator=self.gen)
+        if tokens is None:
+            tokens = torch.randint(0, c.vocab, (T,), device=dev, generator=self.gen)
+        elif tokens.numel() != T:
+            raise ValueError("prefill expects %d prompt tokens, got %d" % (T, tokens.numel()))
         torch.index_select(self.embed, 0, tokens, out=x)
         lens = torch.full((B,), L, dtype=torch.int32, device=dev)
         cu = torch.arange(0, B + 1, dtype=torch.int32, device=dev) * L

@@ -213,6 +213,14 @@ def reference_over_mirror():
     fake = OracleLib()
     saved = (_lib._lib, _lib.require_cuda, _lib.current_stream, _attn_common.rope_table, torch.cuda.current_device,
              torch.Tensor.cuda)
+    saved_factories = {n: getattr(torch, n) for n in ("zeros", "empty", "ones", "tensor", "full")}
+
+    def on_host(fn):      # the reference's layers allocate with device="cuda" (w4a8_linear.py:44-100): host memory here
+        def wrapped(*a, **k):
+            if isinstance(k.get("device"), int) or str(k.get("device", "")).startswith("cuda"):
+                k["device"] = "cpu"
+            return fn(*a, **k)
+        return wrapped
     real_rope = rope_mod.rope_table
 
     def recording_rope(max_pos, dim, base, scale, device):
@@ -226,8 +234,12 @@ def reference_over_mirror():
     if not torch.cuda.is_available():
         torch.cuda.current_device = lambda: 0
         torch.Tensor.cuda = lambda self, *a, **k: self        # from_linear moves the weight to the GPU (w4a8_linear.py:286)
+        for n, fn in saved_factories.items():
+            setattr(torch, n, on_host(fn))
     try:
         yield fake
     finally:
+        for n, fn in saved_factories.items():
+            setattr(torch, n, fn)
         (_lib._lib, _lib.require_cuda, _lib.current_stream, _attn_common.rope_table, torch.cuda.current_device,
          torch.Tensor.cuda) = saved
