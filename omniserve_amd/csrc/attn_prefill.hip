@@ -30,6 +30,10 @@ constexpr int PKT = 64;               // keys per tile
 #define OMNI_PREFILL_PQB 1
 #endif
 constexpr int PQB = OMNI_PREFILL_PQB;   // 16-row query blocks per wave
+#ifndef OMNI_PREFILL_ABLATE_DMA
+#define OMNI_PREFILL_ABLATE_DMA 0     // timing experiment (wrong results): no tile DMA after the first tile
+#endif
+
 #ifndef OMNI_PREFILL_WAVES
 #define OMNI_PREFILL_WAVES (8 / OMNI_PREFILL_PQB)
 #endif
@@ -64,7 +68,7 @@ struct PrefillArgs {
 #ifndef OMNI_PREFILL_MIN_BLOCKS
 #define OMNI_PREFILL_MIN_BLOCKS 2
 #endif
-__global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) __attribute__((amdgpu_waves_per_eu(4 / PQB, 4 / PQB)))   // 128 VGPRs (PQB = 1) or 256 (PQB = 2)
+__global__ __launch_bounds__(64 * PWAVES, OMNI_PREFILL_MIN_BLOCKS) __attribute__((amdgpu_waves_per_eu(4 / PQB, 4 / PQB), amdgpu_num_vgpr(512 / (4 / PQB))))   // 128 VGPRs (PQB = 1) or 256 (PQB = 2)
 void prefill_attn_kernel(PrefillArgs p) {
   // four separate LDS objects and a loop body instantiated per buffer parity (static indices): with one array and a
   // runtime buffer index the compiler cannot tell the DMA target from the tile being read and puts vmcnt(0) -- the
@@ -131,18 +135,25 @@ void prefill_attn_kernel(PrefillArgs p) {
   // and fetches the logical slot  l%16 ^ (row & 15)  of a K row  (conflict-free ds_read_b128 of the A operand)
   //                           or  l%16 ^ 2*(row & 7) of a V row  (conflict-free ds_read_b64_tr_b16: the 8 rows a
   // 32-lane group touches then sit in 8 disjoint 8-bank groups although the row pitch is 256 B).
-  const int sslot = lane & 15;
-  const half_t* kbase = p.k + (size_t)hk * PDH;
-  const half_t* vbase = p.v + (size_t)hk * PDH;
+  // Addresses are rebuilt per piece from a row index (v_add, v_min), ONE v_mad_u64_u32 (row x 32-bit token stride in
+  // bytes + the uniform base) and the swizzle (2 ops): keeping eight 64-bit per-lane pointers alive across the tile
+  // loop instead gets them spilled, and the reload's vmcnt(0) then serialises the DMA issue.
+  const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k + (size_t)k_begin * p.k_stride + (size_t)hk * PDH);
+  const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v + (size_t)k_begin * p.v_stride + (size_t)hk * PDH);
+  const uint32_t kstride_b = (uint32_t)(p.k_stride * 2), vstride_b = (uint32_t)(p.v_stride * 2);   // host: < 2^32
+#define PREFILL_DMA16(src_, dst_) lds_dma16((src_), (dst_))
 #define PREFILL_DMA_TILE(kb_, kt_, vt_)                                                                           \
   do {                                                                                                            \
+    int ln_ = lane;                                                                                               \
+    asm volatile("" : "+v"(ln_));   /* opaque per tile: the per-piece lane constants must not be hoisted */         \
+    const int ss_ = ln_ & 15, lr_ = ln_ >> 4;                                                                      \
     _Pragma("unroll") for (int i_ = 0; i_ < PPT; ++i_) {                                                          \
-      const int row_ = 4 * PPT * wave + 4 * i_ + (lane >> 4);                                                     \
-      const int kr_ = (kb_) + row_ < len_k ? (kb_) + row_ : (len_k - 1);                                          \
-      const size_t o_ = (size_t)(k_begin + kr_);                                                                  \
-      lds_dma16(kbase + o_ * p.k_stride + ((sslot ^ (row_ & 15)) * 8), (kt_) + (4 * PPT * wave + 4 * i_) * PKROW); \
-      lds_dma16(vbase + o_ * p.v_stride + ((sslot ^ (2 * (row_ & 7))) * 8),                                       \
-                (vt_) + (4 * PPT * wave + 4 * i_) * PVROW);                                                       \
+      const int row_ = 4 * PPT * wave + 4 * i_ + lr_;                                                             \
+      const uint32_t kr_ = (uint32_t)((kb_) + row_ < len_k ? (kb_) + row_ : (len_k - 1));                         \
+      PREFILL_DMA16(kbase + ((uint64_t)kr_ * kstride_b + (uint32_t)((ss_ ^ (row_ & 15)) << 4)),                   \
+                    (kt_) + (4 * PPT * wave + 4 * i_) * PKROW);                                                   \
+      PREFILL_DMA16(vbase + ((uint64_t)kr_ * vstride_b + (uint32_t)((ss_ ^ (2 * (row_ & 7))) << 4)),              \
+                    (vt_) + (4 * PPT * wave + 4 * i_) * PVROW);                                                   \
     }                                                                                                             \
   } while (0)
   auto next_tile = [&](int kb) {     // first tile >= kb that is not skipped (or >= k_hi)
@@ -187,7 +198,11 @@ void prefill_attn_kernel(PrefillArgs p) {
     // softmax and the P.V phase below (whose reads are batched by hand) cover the flight time.
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
+#if OMNI_PREFILL_ABLATE_DMA == 2     // timing experiment (wrong results): every tile re-fetches the first tile (L2-hot)
+    if (kb_next < k_hi) PREFILL_DMA_TILE(0, B ? ktile0 : ktile1, B ? vtile0 : vtile1);
+#elif !OMNI_PREFILL_ABLATE_DMA
     if (kb_next < k_hi) PREFILL_DMA_TILE(kb_next, B ? ktile0 : ktile1, B ? vtile0 : vtile1);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // does any (row, key) pair of this workgroup's tile need the mask?  (workgroup-uniform)
     bool full = (kb + PKT <= len_k) && (q_first + PQROWS <= len_q);
@@ -320,7 +335,8 @@ extern "C" int omni_prefill_attention(void* out_f16, const void* q_f16, const vo
                                       const void* head_mask_type_i32, const void* streaming_info_i32, void* stream) {
   if (!out_f16 || !q_f16 || !k_f16 || !v_f16 || !cu_seqlens_q_i32 || !cu_seqlens_k_i32) return OMNI_EINVAL;
   if (head_dim != PDH || batch < 1 || num_heads < 1 || num_kv_heads < 1 || num_heads % num_kv_heads != 0 ||
-      max_seqlen_q < 1 || q_stride % 8 != 0 || k_stride % 8 != 0 || v_stride % 8 != 0)
+      max_seqlen_q < 1 || q_stride % 8 != 0 || k_stride % 8 != 0 || v_stride % 8 != 0 || k_stride < 0 || v_stride < 0 ||
+      k_stride >= (1LL << 31) || v_stride >= (1LL << 31))
     return OMNI_EINVAL;
   if ((head_mask_type_i32 == nullptr) != (streaming_info_i32 == nullptr)) return OMNI_EINVAL;
   PrefillArgs a;
