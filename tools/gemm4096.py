@@ -6,6 +6,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omniserve_amd import _lib  # noqa: E402
+
+if os.environ.get("OMNI_TUNE_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["OMNI_TUNE_LIB"])
 from bench import event_time_ms  # noqa: E402
 from omniserve_amd.backend import qgemm_w4a8_per_chn  # noqa: E402
 
