@@ -30,6 +30,9 @@ constexpr int PKT = 64;               // keys per tile
 #define OMNI_PREFILL_PQB 1
 #endif
 constexpr int PQB = OMNI_PREFILL_PQB;   // 16-row query blocks per wave
+#ifndef OMNI_PREFILL_MFMA32
+#define OMNI_PREFILL_MFMA32 0          // 1: the 32-row form (prefill_attn32_kernel)
+#endif
 #ifndef OMNI_PREFILL_ABLATE_DMA
 #define OMNI_PREFILL_ABLATE_DMA 0     // timing experiment (wrong results): no tile DMA after the first tile
 #endif
@@ -324,6 +327,255 @@ void prefill_attn_kernel(PrefillArgs p) {
 
 #undef PREFILL_DMA_TILE
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 32-row form (v_mfma_f32_32x32x16_f16).  Same tiles, same LDS-DMA staging, same online softmax; what changes is the
+// shape of a wave's work: 32 query rows x 64 keys per tile instead of 16 x 64.
+//   * S^T = K Q^T per 32-key block: A = K rows from LDS (lane l: key l%32, 16 B of dims 16s + 8*(l/32)), B = Q in
+//     registers (lane l: query l%32, the same dims).  D: lane l holds ONE query (column l%32) and the 16 keys
+//     (r&3) + 8*(r>>2) + 4*(l/32) of the block: the row maximum is 31 in-lane max + one permlane32 swap.
+//   * P^T is the B operand of O^T = V^T P^T as it stands: a k-step of the second product may enumerate its 16 keys in any
+//     order as long as A agrees, so k-step j of a block takes the lane's own values r = 8j .. 8j+7 (keys 16j + 4*(l/32) +
+//     {0..3} and + 8) -- no cross-lane exchange, just cvt_pk.  A = V^T: two ds_read_b64_tr_b16 per operand (rows
+//     16j + 4*(l/32) + {0..3}, and + 8), each 16-lane group transposing a [4 keys][16 dims] block.
+//   * per wave and tile: 32 MFMAs of 32 cycles for 2048 scores (the 16-row form: 2 x 32 MFMAs of 16 cycles), the K and V
+//     operands are read from LDS once per 32 rows instead of once per 16, and the bookkeeping per row (maximum, rescale,
+//     addresses, DMA issue) is amortised over twice the flops.
+// V tile swizzle of this kernel: physical 64-B block = logical block ^ (row & 3) (the four rows a 32-lane half of a
+// transposed read touches sit in four different bank quarters); K tile swizzle as above (slot ^ (row & 15)).
+#ifndef OMNI_PREFILL32_WAVES
+#define OMNI_PREFILL32_WAVES 4
+#endif
+constexpr int P32W = OMNI_PREFILL32_WAVES;
+constexpr int P32ROWS = 32 * P32W;                       // query rows per workgroup
+constexpr int P32PPT = (PKT * 16) / (64 * P32W);         // 1-KiB DMA pieces of a K (or V) tile per wave
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(64 * P32W, 8 / P32W) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void prefill_attn32_kernel(PrefillArgs p) {
+  __shared__ __attribute__((aligned(16))) uint8_t ktile0[PKTILE];
+  __shared__ __attribute__((aligned(16))) uint8_t ktile1[PKTILE];
+  __shared__ __attribute__((aligned(16))) uint8_t vtile0[PVTILE];
+  __shared__ __attribute__((aligned(16))) uint8_t vtile1[PVTILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l32 = lane & 31, hi = lane >> 5, l15 = lane & 15, grp = lane >> 4;
+  int b = blockIdx.z, h = blockIdx.y, qt = gridDim.x - 1 - blockIdx.x;
+  if (p.q_tiles > 0) {      // 1-D grid, XCD-aware order (see prefill_attn_kernel)
+    const int hpx = p.num_heads >> 3;
+    const int wid = blockIdx.x, xcd = wid & 7, slot = wid >> 3;
+    h = xcd * hpx + slot % hpx;
+    const int rest = slot / hpx;
+    qt = p.q_tiles - 1 - rest % p.q_tiles;
+    b = rest / p.q_tiles;
+  }
+  const int hk = h / (p.num_heads / p.num_kv_heads);
+  const int q_begin = p.cu_q[b], len_q = p.cu_q[b + 1] - q_begin;
+  const int k_begin = p.cu_k[b], len_k = p.cu_k[b + 1] - k_begin;
+  const int q_first = qt * P32ROWS;
+  if (q_first >= len_q) return;
+  const int q_last = min(q_first + P32ROWS, len_q) - 1;
+  const int off = len_k - len_q;
+  const bool streaming = p.head_mask_type != nullptr && p.head_mask_type[h] < 0;
+  const int sink = streaming ? p.streaming_info[2 * h] : 0;
+  const int local = streaming ? p.streaming_info[2 * h + 1] : 0;
+  const float scale2 = 0.08838834764831845f * 1.4426950408889634f;
+  const int qrow = q_first + wave * 32 + l32;               // this lane's query row (lanes l and l + 32 share it)
+
+  // B operand of S^T: Q[qrow][16s + 8*hi + (0..7)], s = 0..7
+  v8h qb[8];
+  {
+    const int qr_c = qrow < len_q ? qrow : (len_q - 1);
+    const half_t* qp = p.q + (size_t)(q_begin + qr_c) * p.q_stride + (size_t)h * PDH + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qb[s] = *reinterpret_cast<const v8h*>(qp + 16 * s);
+  }
+  v16f oacc[4];      // O^T: dims 32*c + (r&3) + 8*(r>>2) + 4*hi of query l32
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[c][r] = 0.0f;
+  float m_run = -1e30f, l_run = 0.0f;
+
+  const int k_hi = p.causal ? min(len_k, q_last + off + 1) : len_k;
+  const int win_lo = streaming ? q_first + off - local + 1 : 0;
+  auto skipped = [&](int kb) { return streaming && kb >= sink && kb + PKT <= win_lo; };
+  auto next_tile = [&](int kb) {
+    while (kb < k_hi && skipped(kb)) kb += PKT;
+    return kb;
+  };
+  const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k + (size_t)k_begin * p.k_stride + (size_t)hk * PDH);
+  const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v + (size_t)k_begin * p.v_stride + (size_t)hk * PDH);
+  const uint32_t kstride_b = (uint32_t)(p.k_stride * 2), vstride_b = (uint32_t)(p.v_stride * 2);
+#define PREFILL32_DMA_TILE(kb_, kt_, vt_)                                                                         \
+  do {                                                                                                            \
+    int ln_ = lane;                                                                                               \
+    asm volatile("" : "+v"(ln_));                                                                                 \
+    const int ss_ = ln_ & 15, lr_ = ln_ >> 4;                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < P32PPT; ++i_) {                                                       \
+      const int row_ = 4 * P32PPT * wave + 4 * i_ + lr_;                                                          \
+      const uint32_t kr_ = (uint32_t)((kb_) + row_ < len_k ? (kb_) + row_ : (len_k - 1));                         \
+      lds_dma16_untracked(kbase + ((uint64_t)kr_ * kstride_b + (uint32_t)((ss_ ^ (row_ & 15)) << 4)),                       \
+                (kt_) + (4 * P32PPT * wave + 4 * i_) * PKROW);                                                    \
+      lds_dma16_untracked(vbase + ((uint64_t)kr_ * vstride_b + (uint32_t)((ss_ ^ ((row_ & 3) << 2)) << 4)),                 \
+                (vt_) + (4 * P32PPT * wave + 4 * i_) * PVROW);                                                    \
+    }                                                                                                             \
+  } while (0)
+
+  // LDS addresses.  K operand (key 32u + l32, logical 16-B slot 2s + hi): physical slot (2s + hi) ^ l15.
+  int kaddr[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) kaddr[s] = l32 * PKROW + (((2 * s + hi) ^ l15) << 4);
+  // V^T operand: row 4*hi + (l15 >> 2) (+ 16j + 32u, + 8 by immediates), dims 32c + 16*(grp & 1) + 4*(l15 & 3);
+  // (row & 3) = l15 >> 2, so the physical 64-B block of logical block c is c ^ (l15 >> 2)
+  int vaddr[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    vaddr[c] = (4 * hi + (l15 >> 2)) * PVROW + ((c ^ (l15 >> 2)) << 6) + 32 * (grp & 1) + 8 * (l15 & 3);
+
+  // (the tile DMAs of this kernel are hidden from hipcc -- inline asm -- and waited for by hand: while it knows of a DMA in
+  //  flight it puts a full lgkmcnt(0) in front of every consumer of a ds_read, which breaks the read pipelines below)
+  int kb = next_tile(0);
+  if (kb < k_hi) PREFILL32_DMA_TILE(kb, ktile0, vtile0);
+  lds_dma_wait_all();
+  __syncthreads();
+  auto tile_step = [&](auto parity, auto fulltag) {
+    constexpr int B = decltype(parity)::value;
+    constexpr bool FULL = decltype(fulltag)::value;
+    const int kb_next = next_tile(kb + PKT);
+    const uint8_t* kt = B ? ktile1 : ktile0;
+    const uint8_t* vt = B ? vtile1 : vtile0;
+    // ---- S^T: two 32-key blocks x 8 dim steps ---------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(1);
+    v16f st[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[u][r] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const v8h a = *reinterpret_cast<const v8h*>(kt + 32 * u * PKROW + kaddr[s]);
+        st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qb[s], st[u], 0, 0, 0);
+      }
+    }
+    // operand reads four MFMAs (128 cycles) ahead
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+    if (kb_next < k_hi) PREFILL32_DMA_TILE(kb_next, B ? ktile0 : ktile1, B ? vtile0 : vtile1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- online softmax: this lane's 32 scores of query l32 ------------------------------------------------------
+    float tmax = -1e30f;
+    bool okv[2][16];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (FULL) {
+          okv[u][r] = true;
+          tmax = __builtin_fmaxf(tmax, st[u][r]);
+        } else {
+          const int key = kb + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int qpos = qrow + off;
+          int ok = (int)(key < len_k) & (int)(qrow < len_q);
+          ok &= (int)(!p.causal) | (int)(key <= qpos);
+          ok &= (int)(!streaming) | (int)(key < sink) | (int)(qpos - key < local);
+          okv[u][r] = ok != 0;
+          tmax = __builtin_fmaxf(tmax, ok ? st[u][r] : -1e30f);
+        }
+      }
+    {      // the other 32 keys of the row live in lane l ^ 32
+      unsigned x = __builtin_bit_cast(unsigned, tmax);
+      auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+      tmax = __builtin_fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+    }
+    const float m_new = __builtin_fmaxf(m_run, tmax * scale2);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.0f;
+    v8h pb[2][2];      // [block][k-step]: the lane's own values r = 8j .. 8j + 7
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][r], scale2, -m_new));
+        if constexpr (!FULL) pe = okv[u][r] ? pe : 0.0f;
+        pb[u][r >> 3][r & 7] = (half_t)pe;
+        psum += pe;
+      }
+    l_run = l_run * alpha + psum;
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[c][r] *= alpha;
+    }
+    m_run = m_new;
+    // ---- O^T += V^T P^T: 4 k-steps (block u, step j) x 4 dim blocks ---------------------------------------------------
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int uj = 0; uj < 4; ++uj) {
+      const int u = uj >> 1, j = uj & 1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint8_t* src = vt + (32 * u + 16 * j) * PVROW + vaddr[c];
+        const pv4hp lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src));
+        const pv4hp hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src + 8 * PVROW));
+        const v8h a = {(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
+                       (half_t)hi4[0], (half_t)hi4[1], (half_t)hi4[2], (half_t)hi4[3]};
+        oacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[u][j], oacc[c], 0, 0, 0);
+      }
+    }
+    // the transposed reads run three operands ahead of the MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    __builtin_amdgcn_s_setprio(0);
+    lds_dma_wait_all();       // this wave's pieces of the next tile have landed; the barrier covers everybody's
+    __syncthreads();
+    kb = kb_next;
+  };
+  auto is_full = [&](int kb_) {
+    bool full = (kb_ + PKT <= len_k) && (q_first + P32ROWS <= len_q);
+    if (p.causal) full = full && (kb_ + PKT - 1 <= q_first + off);
+    if (streaming) full = full && ((kb_ + PKT <= sink) || (q_last + off - kb_ < local));
+    return full;
+  };
+  while (kb < k_hi) {
+    if (is_full(kb)) tile_step(IntTag<0>{}, IntTag<1>{}); else tile_step(IntTag<0>{}, IntTag<0>{});
+    if (kb >= k_hi) break;
+    if (is_full(kb)) tile_step(IntTag<1>{}, IntTag<1>{}); else tile_step(IntTag<1>{}, IntTag<0>{});
+  }
+  // ---- finish: the row sum lives in two lanes; normalise, store (4 consecutive dims per register quad) ---------------
+  {
+    unsigned x = __builtin_bit_cast(unsigned, l_run);
+    auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    l_run = __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
+  }
+  if (qrow >= len_q) return;
+  const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+  half_t* op = p.out + ((size_t)(q_begin + qrow) * p.num_heads + h) * PDH + 4 * hi;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
+      const v4h_t o = {(half_t)(oacc[c][4 * g + 0] * inv), (half_t)(oacc[c][4 * g + 1] * inv),
+                       (half_t)(oacc[c][4 * g + 2] * inv), (half_t)(oacc[c][4 * g + 3] * inv)};
+      *reinterpret_cast<v4h_t*>(op + 32 * c + 8 * g) = o;
+    }
+}
+#undef PREFILL32_DMA_TILE
+
 }  // namespace omni
 
 using namespace omni;
@@ -345,13 +597,22 @@ extern "C" int omni_prefill_attention(void* out_f16, const void* q_f16, const vo
   a.cu_q = (const int*)cu_seqlens_q_i32; a.cu_k = (const int*)cu_seqlens_k_i32;
   a.head_mask_type = (const int*)head_mask_type_i32; a.streaming_info = (const int*)streaming_info_i32;
   a.num_heads = num_heads; a.num_kv_heads = num_kv_heads; a.causal = causal;
-  const int q_tiles = (max_seqlen_q + PQROWS - 1) / PQROWS;
+#if OMNI_PREFILL_MFMA32
+  constexpr int rows_per_wg = P32ROWS;
+#else
+  constexpr int rows_per_wg = PQROWS;
+#endif
+  const int q_tiles = (max_seqlen_q + rows_per_wg - 1) / rows_per_wg;
   dim3 grid(q_tiles, num_heads, batch);
   a.q_tiles = 0;
   if (num_heads % 8 == 0 && (long long)q_tiles * num_heads * batch < (1LL << 31)) {
     a.q_tiles = q_tiles;
     grid = dim3((unsigned)((long long)q_tiles * num_heads * batch), 1, 1);
   }
+#if OMNI_PREFILL_MFMA32
+  hipLaunchKernelGGL(prefill_attn32_kernel, grid, dim3(64 * P32W), 0, (hipStream_t)stream, a);
+#else
   hipLaunchKernelGGL(prefill_attn_kernel, grid, dim3(64 * PWAVES), 0, (hipStream_t)stream, a);
+#endif
   return omni_launch_status();
 }
