@@ -137,6 +137,10 @@ int omni_splitk_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, 
  * ascales[m])) applied by the consumer. */
 int omni_w8a8_gemm_partial(const void* in_feats, const void* weight, void* slab_i32, size_t slab_bytes, int M, int N,
                            int K, int* sk_out, void* stream);
+/* ... and for the per-group W4A8 GEMM (same epilogue formula as W8A8: w4a8_per_group/gemm_cuda.cu:620-627), so that the
+ * g128 models get the deferred o_proj / down_proj epilogue as well */
+int omni_w4a8_per_group_gemm_partial(const void* in_feats, const void* qweight, const void* zeros, const void* scales_i8,
+                                     void* slab_i32, size_t slab_bytes, int M, int N, int K, int* sk_out, void* stream);
 int omni_splitk_w8_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const void* slab_i32, int sk,
                                                  const void* wscales_f16, const void* ascales_in_f16,
                                                  const void* weight_f16, void* sum_f16, void* scale_f16, float eps,

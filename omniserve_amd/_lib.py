@@ -40,6 +40,7 @@ PROTOTYPES = {
     "omni_w4a8_per_chn_gemm_partial": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _c.POINTER(_i), _vp]),
     "omni_splitk_add_rms_norm_general_fuse_sum": (_i, [_vp, _vp, _vp, _i] + [_vp] * 7 + [_f, _i, _i, _vp]),
     "omni_w8a8_gemm_partial": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _c.POINTER(_i), _vp]),
+    "omni_w4a8_per_group_gemm_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _c.POINTER(_i), _vp]),
     "omni_splitk_w8_add_rms_norm_general_fuse_sum": (_i, [_vp, _vp, _vp, _i] + [_vp] * 5 + [_f, _i, _i, _vp]),
     "omni_compute_padding_offsets": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "omni_kv4_prefill_write": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _i, _i, _vp]),

@@ -71,6 +71,22 @@ def gemm_partial_w8a8(in_feats, weight, slab):
     return sk.value
 
 
+def gemm_partial_per_group(in_feats, qweight, s2_zeros, s2_scales, slab):
+    """Decode-shape g128 W4A8 GEMM without its epilogue (int32 slabs, returns sk); the epilogue formula is the W8A8 one, so
+    the consumer is splitk_w8_add_rms_norm_general_fuse_sum."""
+    import ctypes
+    _lib.require_cuda(in_feats, qweight, s2_zeros, s2_scales, slab)
+    M, K = in_feats.shape
+    N = qweight.shape[0]
+    sk = ctypes.c_int(0)
+    rc = _lib.lib().omni_w4a8_per_group_gemm_partial(in_feats.data_ptr(), qweight.data_ptr(), s2_zeros.data_ptr(),
+                                                     s2_scales.data_ptr(), slab.data_ptr(),
+                                                     slab.numel() * slab.element_size(), M, N, K, ctypes.byref(sk),
+                                                     _lib.current_stream())
+    _lib.check(rc, "fused_ext.gemm_partial_per_group")
+    return sk.value
+
+
 def splitk_w8_add_rms_norm_general_fuse_sum(out, residual, slab, sk, wscales, ascales_in, weight, input_sum, scaling,
                                             epsilon):
     """residual += fp16(W8A8 GEMM epilogue(sum of sk slabs)); then norm + quant (+sum) of it."""

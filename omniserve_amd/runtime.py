@@ -136,8 +136,8 @@ class DecodeRunner:
         # down_proj into the following add+norm kernel.  All bit-identical to the reference sequence
         # (SURVEY.md 8f.1).
         self.fused = 2 if fused is True else int(fused)
-        if (cfg.group_size != -1 or self.tp_size > 1) and self.fused > 1:
-            self.fused = 1   # the deferred epilogue exists for the per-channel GEMM only; TP all-reduces fp16
+        if self.tp_size > 1 and self.fused > 1:
+            self.fused = 1   # tensor parallel: the all-reduce needs the fp16 projection, no deferred epilogue
         # L2 weight prefetch riding on the row kernels (fused extension; a hint, results are unaffected): MiB of the
         # next GEMV's weights each row kernel pulls into the L2s (0 = off), with how many extra workgroups, and
         # whether the GEMVs then use plain instead of non-temporal weight loads.  Defaults: on with the fused
@@ -217,7 +217,8 @@ class DecodeRunner:
         self.act_sum = torch.empty((B,), dtype=f16, device=device)
         self.act_scale2 = torch.empty((B,), dtype=f16, device=device)  # written by quant kernels
         self.act_sum2 = torch.empty((B,), dtype=f16, device=device)
-        self.slab = torch.empty((16 << 20,), dtype=torch.uint8, device=device)  # deferred split-K partial sums
+        need = max(int(_lib.lib().omni_gemm_workspace_bytes(B, c.hidden, k)) for k in (hl * c.head_dim, il))
+        self.slab = torch.empty((max(need, 1 << 20),), dtype=torch.uint8, device=device)  # deferred split-K partial sums
         self.qkv_buf = torch.empty((B, qkv_n), dtype=f16, device=device)
         self.proj_buf = torch.empty((B, c.hidden), dtype=f16, device=device)
         self.gate_up_buf = torch.empty((B, 2 * il), dtype=f16, device=device)
@@ -269,6 +270,21 @@ class DecodeRunner:
         self.graph.replay()
         self.steps_done += 1
 
+    def _partial(self, x_i8, lin):
+        """o_proj / down_proj without its epilogue: int32 split-K slabs in self.slab, returns the slab count."""
+        if lin.group == -1:
+            return fused_ext.gemm_partial_per_chn(x_i8, lin.qweight, self.slab)
+        return fused_ext.gemm_partial_per_group(x_i8, lin.qweight, lin.s2_zeros, lin.s2_scales, self.slab)
+
+    def _consume(self, q_out, sk, lin, a_scale, a_sum, gamma, out_sum, out_scale):
+        """residual += epilogue(sum of the slabs); norm + quant of it (the GEMM epilogue lives in this row kernel)."""
+        if lin.group == -1:
+            fused_ext.splitk_add_rms_norm_general_fuse_sum(q_out, self.x, self.slab, sk, lin.s1_scales, a_scale,
+                                                           lin.s1_szeros, a_sum, gamma, out_sum, out_scale, self.cfg.eps)
+        else:
+            fused_ext.splitk_w8_add_rms_norm_general_fuse_sum(q_out, self.x, self.slab, sk, lin.s1_scales, a_scale, gamma,
+                                                              out_sum, out_scale, self.cfg.eps)
+
     def _arm(self, lin, deferred=False):
         """The next row kernel prefetches the head of `lin`'s weight stream into the L2s (no-op when disabled)."""
         if self.prefetch_bytes > 0:
@@ -298,8 +314,7 @@ class DecodeRunner:
             self._arm(L["qkv"])
             if pending is not None:     # residual += down_proj(prev layer) [deferred epilogue], norm + quant
                 sk, lin = pending
-                fused_ext.splitk_add_rms_norm_general_fuse_sum(qa_h, self.x, self.slab, sk, lin.s1_scales, sA,
-                                                               lin.s1_szeros, mA, L["ln1"], mB, sB, c.eps)
+                self._consume(qa_h, sk, lin, sA, mA, L["ln1"], mB, sB)
                 pending = None
             elif self.fused and li > 0:
                 fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln1"], mB, sB, c.eps)
@@ -319,10 +334,9 @@ class DecodeRunner:
                     self.max_context, d, c.rope_theta, True, True, True)
                 fused_kernels.invoke_quant_fuse_sum(self._q_attn, attn.view(B, hq * d), mA, sA)
             if self.fused >= 2:
-                sk = fused_ext.gemm_partial_per_chn(self._q_attn, L["o"].qweight, self.slab)
+                sk = self._partial(self._q_attn, L["o"])
                 self._arm(L["gate_up"])
-                fused_ext.splitk_add_rms_norm_general_fuse_sum(qa_h, self.x, self.slab, sk, L["o"].s1_scales, sA,
-                                                               L["o"].s1_szeros, mA, L["ln2"], mB, sB, c.eps)
+                self._consume(qa_h, sk, L["o"], sA, mA, L["ln2"], mB, sB)
             else:
                 L["o"].forward(self._q_attn, sA, mA, self.proj_buf)
                 self._all_reduce(self.proj_buf)
@@ -340,7 +354,7 @@ class DecodeRunner:
                 activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
                 fused_kernels.invoke_quant_fuse_sum(qa_i, self.mlp_act, mA, sA)
             if self.fused >= 2 and li < nl - 1:
-                pending = (fused_ext.gemm_partial_per_chn(qa_i, L["down"].qweight, self.slab), L["down"])
+                pending = (self._partial(qa_i, L["down"]), L["down"])
             else:
                 L["down"].forward(qa_i, sA, mA, self.proj_buf)
                 self._all_reduce(self.proj_buf)

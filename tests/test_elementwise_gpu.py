@@ -200,6 +200,42 @@ def test_deferred_splitk_w8_epilogue_matches_gemm_then_add_norm(M, N, K):
     assert_f16_equal(sm2, smo, "sum")
 
 
+@pytest.mark.parametrize("M,N,K", [(16, 4096, 4096), (64, 4096, 14336), (5, 1024, 2048)])
+def test_deferred_splitk_per_group_epilogue_matches_gemm_then_add_norm(M, N, K):
+    """g128 W4A8: partial GEMM + slab-consuming add+norm == per-group GEMM -> residual add -> rms_norm_general_fuse_sum, bit for bit
+    (the per-group epilogue h(f32(acc) * (s1[n] * s_a[m])) is the one the W8A8 consumer applies)."""
+    import omniserve_backend.layernorm_ops as ln
+    import omniserve_backend.qgemm_w4a8_per_group as gemm
+    from omniserve_amd.backend import fused_ext
+    from oracle import w4a8
+    u, z, s2, s1 = w4a8.synth_per_group(N, K, seed=M + 1)
+    qw, s1h, s2s, s2z = w4a8.pack_per_group(u, z, s2, s1)
+    a, sa, _ = oe.quant_per_token(_x(M, K, 5, 1.0), False)
+    resid = _x(M, N, 6, 2.0)
+    g = (1.0 + 0.1 * np.random.default_rng(1).standard_normal(N)).astype(np.float16)
+    qw_d, s1_d, s2s_d, s2z_d, a_d, sa_d, g_d = map(to_dev, (qw, s1h, s2s, s2z, a, sa, g))
+    proj = torch.empty((M, N), dtype=torch.float16, device=dev())
+    gemm.gemm_forward_cuda(a_d, qw_d, s2z_d, s2s_d, s1_d, sa_d, proj)
+    x1 = to_dev(resid); x1.add_(proj)
+    q1 = torch.empty((M, N), dtype=torch.int8, device=dev()); sc1 = torch.empty((M,), dtype=torch.float16, device=dev()); sm1 = sc1.clone()
+    ln.rms_norm_general_fuse_sum(q1, x1, g_d, sm1, sc1, 1e-5, True)
+    slab = torch.empty((64 << 20,), dtype=torch.uint8, device=dev())
+    sk = fused_ext.gemm_partial_per_group(a_d, qw_d, s2z_d, s2s_d, slab)
+    x2 = to_dev(resid)
+    q2 = torch.empty_like(q1); sc2 = torch.empty_like(sc1); sm2 = torch.empty_like(sc1)
+    fused_ext.splitk_w8_add_rms_norm_general_fuse_sum(q2, x2, slab, sk, s1_d, sa_d, g_d, sm2, sc2, 1e-5)
+    torch.cuda.synchronize()
+    assert sk >= 1
+    assert torch.equal(x1.view(torch.int16), x2.view(torch.int16))
+    assert torch.equal(q1, q2) and torch.equal(sc1.view(torch.int16), sc2.view(torch.int16))
+    assert torch.equal(sm1.view(torch.int16), sm2.view(torch.int16))
+    want = w4a8.gemm_per_group(a, qw, s2z, s2s, s1h, sa)
+    xs = (resid.astype(np.float32) + want.astype(np.float32)).astype(np.float16)
+    qo, so, smo = oe.rms_norm_general(xs, g, 1e-5, True)
+    assert np.array_equal(q2.cpu().numpy(), qo)
+    assert_f16_equal(sm2, smo, "sum")
+
+
 def test_argmax_matches_torch():
     """Greedy-sampling helper (fused_ext.argmax): first maximum, -0 == +0, NaN wins, ragged and unaligned shapes."""
     from omniserve_amd.backend import fused_ext

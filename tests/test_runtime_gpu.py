@@ -7,10 +7,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(fused, graph, steps=3):
+def _run(fused, graph, steps=3, group_size=-1, batch=5):
     from omniserve_amd.runtime import DecodeRunner, LlamaConfig
     dev = torch.device("cuda:0")
-    r = DecodeRunner(LlamaConfig.tiny(), batch=5, context=70, max_new=8, device=dev, seed=7, use_graph=graph, fused=fused)
+    cfg = LlamaConfig.tiny()
+    cfg.group_size = group_size
+    r = DecodeRunner(cfg, batch=batch, context=70, max_new=8, device=dev, seed=7, use_graph=graph, fused=fused)
+    assert r.fused == int(fused)
     toks = []
     for _ in range(steps):
         r.step()
@@ -19,10 +22,12 @@ def _run(fused, graph, steps=3):
     return torch.stack(toks).cpu(), r.x.clone().cpu(), [p.clone().cpu() for p in r.pools[0]]
 
 
-def test_fusion_levels_and_graph_agree_bitwise():
-    ref_t, ref_x, ref_p = _run(0, False)
+@pytest.mark.parametrize("group_size,batch", [(-1, 5), (128, 5), (128, 40)])
+def test_fusion_levels_and_graph_agree_bitwise(group_size, batch):
+    """(g128 at level 2 = the per-group partial GEMM + the slab-consuming norm; batch 40 = the 64-row GEMV tile)"""
+    ref_t, ref_x, ref_p = _run(0, False, group_size=group_size, batch=batch)
     for fused, graph in [(1, False), (2, False), (2, True)]:
-        t, x, pools = _run(fused, graph)
+        t, x, pools = _run(fused, graph, group_size=group_size, batch=batch)
         assert torch.equal(t, ref_t), (fused, graph)
         assert torch.equal(x.view(torch.int16), ref_x.view(torch.int16)), (fused, graph)
         for a, b in zip(pools, ref_p):
