@@ -136,8 +136,10 @@ class DecodeRunner:
         # down_proj into the following add+norm kernel.  All bit-identical to the reference sequence
         # (SURVEY.md 8f.1).
         self.fused = 2 if fused is True else int(fused)
-        if self.tp_size > 1 and self.fused > 1:
-            self.fused = 1   # tensor parallel: the all-reduce needs the fp16 projection, no deferred epilogue
+        if (self.tp_size > 1 or batch > 128) and self.fused > 1:
+            # tensor parallel: the all-reduce needs the fp16 projection; batch > 128: the projections run through the
+            # prefill tile, which has no slab-only form -- no deferred epilogue in either case
+            self.fused = 1
         # L2 weight prefetch riding on the row kernels (fused extension; a hint, results are unaffected): MiB of the
         # next GEMV's weights each row kernel pulls into the L2s (0 = off), with how many extra workgroups, and
         # whether the GEMVs then use plain instead of non-temporal weight loads.  Defaults: on with the fused
