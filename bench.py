@@ -47,6 +47,11 @@ INT8_PEAK_TOPS = 5000.0     # dense int8 MFMA
 # WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide streaming reads on gfx950).  Taken
 # from the committed profile, NOT re-measured by the run that prints it (PMC collection wraps the process).
 PMC_TRAFFIC_BYTES = {(16, 28672, 4096, -1): 60430000}
+# The same kernel INSIDE the captured decode step (rocprofv3 --kernel-trace of this command, profiles/r02_g_*): the preceding
+# row kernel has pulled the head of its weight stream into L2, so the launch is shorter than the isolated one timed below.
+# Reported next to the isolated figure (which is what `achieved` / `frac` are computed from), not instead of it.
+IN_STEP_US = {(16, 28672, 4096, -1): 9.7}
+IN_STEP_SOURCE = "profiles/r02_g_decode_by_kernel_final.md (rocprofv3 of `bench.py --steps 32 --warmup 4 --no-extras`, 1184 launches, prefetch 40 MiB)"
 PMC_TRAFFIC_SOURCE = "profiles/r02_b_pmc_traffic_four_gemvs.md (separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes over this kernel, not this run)"
 
 
@@ -134,7 +139,11 @@ def roofline_gate_up(runner):
             # access pattern measures 5.7-5.9 TB/s, tools/stream_probe.hip); the launch costs ~1.6 us of the ~12.5 us
             "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
             "traffic_source": PMC_TRAFFIC_SOURCE if traffic else None,
-            "bytes_per_launch": alg, "us_per_launch": round(ms * 1e3, 2), "gemv_aggregate": aggregate}
+            "bytes_per_launch": alg, "us_per_launch": round(ms * 1e3, 2), "gemv_aggregate": aggregate,
+            "how_timed": "isolated: HIP graph of one launch per layer (cold weights, no L2 prefetch), HIP events on the launch "
+                         "stream; rocprofv3 of the whole command mixes these launches with the shorter in-step ones",
+            "in_step_us_per_launch": IN_STEP_US.get((B, N, K, lin0.group)),
+            "in_step_source": IN_STEP_SOURCE if (B, N, K, lin0.group) in IN_STEP_US else None}
 
 
 def gemm_4096(device):
