@@ -248,6 +248,8 @@ int omni_prefill_attention(void* out_f16, const void* q_f16, const void* k_f16, 
                            const void* cu_seqlens_q_i32, const void* cu_seqlens_k_i32, int batch,
                            int max_seqlen_q, int num_heads, int num_kv_heads, int head_dim, int causal,
                            const void* head_mask_type_i32, const void* streaming_info_i32, void* stream);
+/* Tuning / test hook: 0 = 16 query rows per wave (16x16x32 MFMA, default), 1 = 32 rows per wave (32x32x16 MFMA). */
+void omni_prefill_set_variant(int variant);
 
 /* ----------------------------------------------------------------------------------------------
  * LServe dynamic sparsity: K statistics in the page tail and the page selector.

@@ -31,7 +31,7 @@ constexpr int PKT = 64;               // keys per tile
 #endif
 constexpr int PQB = OMNI_PREFILL_PQB;   // 16-row query blocks per wave
 #ifndef OMNI_PREFILL_MFMA32
-#define OMNI_PREFILL_MFMA32 0          // 1: the 32-row form (prefill_attn32_kernel)
+#define OMNI_PREFILL_MFMA32 0          // default kernel: 0 = 16-row form, 1 = 32-row form (prefill_attn32_kernel); omni_prefill_set_variant overrides
 #endif
 #ifndef OMNI_PREFILL_ABLATE_DMA
 #define OMNI_PREFILL_ABLATE_DMA 0     // timing experiment (wrong results): no tile DMA after the first tile
@@ -580,6 +580,10 @@ void prefill_attn32_kernel(PrefillArgs p) {
 
 using namespace omni;
 
+static int g_prefill_variant = OMNI_PREFILL_MFMA32;
+// Tuning / test hook: 0 = the 16-row form (default), 1 = the 32-row form.  Same results within the attention tolerance.
+extern "C" void omni_prefill_set_variant(int variant) { g_prefill_variant = variant == 1 ? 1 : 0; }
+
 extern "C" int omni_prefill_attention(void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16,
                                       int64_t q_stride, int64_t k_stride, int64_t v_stride,
                                       const void* cu_seqlens_q_i32, const void* cu_seqlens_k_i32, int batch,
@@ -597,11 +601,8 @@ extern "C" int omni_prefill_attention(void* out_f16, const void* q_f16, const vo
   a.cu_q = (const int*)cu_seqlens_q_i32; a.cu_k = (const int*)cu_seqlens_k_i32;
   a.head_mask_type = (const int*)head_mask_type_i32; a.streaming_info = (const int*)streaming_info_i32;
   a.num_heads = num_heads; a.num_kv_heads = num_kv_heads; a.causal = causal;
-#if OMNI_PREFILL_MFMA32
-  constexpr int rows_per_wg = P32ROWS;
-#else
-  constexpr int rows_per_wg = PQROWS;
-#endif
+  const bool form32 = g_prefill_variant == 1;
+  const int rows_per_wg = form32 ? P32ROWS : PQROWS;
   const int q_tiles = (max_seqlen_q + rows_per_wg - 1) / rows_per_wg;
   dim3 grid(q_tiles, num_heads, batch);
   a.q_tiles = 0;
@@ -609,10 +610,7 @@ extern "C" int omni_prefill_attention(void* out_f16, const void* q_f16, const vo
     a.q_tiles = q_tiles;
     grid = dim3((unsigned)((long long)q_tiles * num_heads * batch), 1, 1);
   }
-#if OMNI_PREFILL_MFMA32
-  hipLaunchKernelGGL(prefill_attn32_kernel, grid, dim3(64 * P32W), 0, (hipStream_t)stream, a);
-#else
-  hipLaunchKernelGGL(prefill_attn_kernel, grid, dim3(64 * PWAVES), 0, (hipStream_t)stream, a);
-#endif
+  if (form32) hipLaunchKernelGGL(prefill_attn32_kernel, grid, dim3(64 * P32W), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(prefill_attn_kernel, grid, dim3(64 * PWAVES), 0, (hipStream_t)stream, a);
   return omni_launch_status();
 }

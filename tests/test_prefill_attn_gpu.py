@@ -10,6 +10,16 @@ from tests.util import dev, to_dev
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["rows16", "rows32"])
+def kernel_form(request):
+    """Every case runs on both forms of the kernel: 16 query rows per wave (16x16x32 MFMA, the default) and 32 rows per wave
+    (32x32x16 MFMA, csrc/attn_prefill.hip: prefill_attn32_kernel)."""
+    from omniserve_amd import _lib
+    _lib.lib().omni_prefill_set_variant(request.param)
+    yield request.param
+    _lib.lib().omni_prefill_set_variant(0)
+
+
 def _case(seq_lens, Hq, Hk, seed, streaming=None, strided=True):
     import block_sparse_attn as bsa
     rng = np.random.default_rng(seed)
