@@ -9,6 +9,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omniserve_amd import _lib  # noqa: E402
+
+if os.environ.get("OMNI_TUNE_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["OMNI_TUNE_LIB"])
 from omniserve_amd.runtime import DecodeRunner, LlamaConfig  # noqa: E402
 
 dev = torch.device("cuda:0")
