@@ -108,6 +108,54 @@ int omni_rms_norm_general_fuse_sum(void* out_i8, const void* in_f16, const void*
  *   (kernels/csrc/activation_kernels.cu:10-30,84-97): in fp16 [tokens, 2d] -> out [tokens, d]. */
 int omni_silu_and_mul(void* out_f16, const void* in_f16, int tokens, int d, void* stream);
 
+/* ---- Overloads of the same three modules that the Llama W4A8 / W8A8 model code does not call --------
+ * (csrc/offpath.hip).  `float scale` arguments bound to `at::Half` parameters upstream are rounded to fp16
+ * inside.  Rows: hidden (d) % 8 == 0; the three norms additionally need hidden <= 16256 and, where the
+ * reference launches min(hidden,1024) threads without rounding to 32, hidden % 32 == 0 below 1024. */
+
+/* Replaces fused_kernels.invoke_quant(out, input, at::Half scale) and
+ *   invoke_quant_fuse_sum(out, input, at::Half input_sum, at::Half scale) (its scalar input_sum is unused)
+ *   (kernels/csrc/fused_kernels.cu:88-93,136-141,202-216,238-253): q = rni_sat(x / scale). */
+int omni_quant_static(void* out_i8, const void* in_f16, float scale, int tokens, int hidden, void* stream);
+
+/* Replaces fused_kernels.invoke_dequant (fused_kernels.cu:45-55,184-200): out = h(f32(acc) * scale);
+ *   row strides in elements (in % 4 == 0, out % 8 == 0). */
+int omni_dequant(void* out_f16, const void* in_i32, float scale, int tokens, int hidden, long long in_stride,
+                 long long out_stride, void* stream);
+
+/* Replaces fused_kernels.invoke_dequant_add_residual, both overloads (fused_kernels.cu:24-43,145-182):
+ *   out = h(fma(f32(acc), s, f32(residual))), s = token_scale_f16[token] if given, else `scale`. */
+int omni_dequant_add_residual(void* out_f16, const void* in_i32, const void* residual_f16,
+                              const void* token_scale_f16, float scale, int tokens, int hidden, void* stream);
+
+/* Replaces layernorm_ops.rms_norm(use_quant = true) (layernorm_kernels.cu:335-365,411-430):
+ *   q = rni_sat((x * rsqrt(mean(x^2) + eps)) * w). */
+int omni_rms_norm_quant(void* out_i8, const void* in_f16, const void* weight_f16, float eps, int tokens, int hidden,
+                        void* stream);
+
+/* Replaces layernorm_ops.rms_norm_general(use_per_token_quant = false) (layernorm_kernels.cu:58-196,455-466):
+ *   y as in omni_rms_norm_general, q = rni_sat(f32(h(y)) * f32(scaling_f16[0])). */
+int omni_rms_norm_general_static(void* out_i8, const void* in_f16, const void* weight_f16, const void* scaling_f16,
+                                 float eps, int tokens, int hidden, void* stream);
+
+/* Replaces layernorm_ops.invoke_dequant_add_residual_rms_norm_quant, both overloads
+ *   (layernorm_kernels.cu:370-409,515-561): residual <- h(diff), diff = fma(f32(acc), s, f32(residual));
+ *   q = rni_sat((f32(h(diff)) * rsqrt(mean(diff^2) + eps)) * gamma); s per token if token_scale_f16 is given. */
+int omni_dequant_add_residual_rms_norm_quant(void* out_i8, const void* in_i32, void* residual_f16,
+                                             const void* gamma_f16, const void* token_scale_f16, float scale,
+                                             float eps, int tokens, int hidden, void* stream);
+
+/* Replaces activation_ops.gelu_new (kind 0) / gelu_fast (kind 1) (activation_kernels.cu:186-213), fp16. */
+int omni_gelu(void* out_f16, const void* in_f16, int kind, int tokens, int d, void* stream);
+
+/* Replaces activation_ops.invoke_dequant_silu_and_mul_quant, both overloads (activation_kernels.cu:31-82,100-131):
+ *   t = silu(f32(gate) * scale_gate) * (f32(up) * scale_up), in int32 [tokens, 2d].
+ *   token_scale_f32 == NULL (and tmp_f32 == NULL): q = rni_sat(t / scale_out);
+ *   otherwise tmp_f32 [tokens, d] = t, token_scale_f32[token] = amax/127, q = rni_sat((127/amax) * t). */
+int omni_dequant_silu_and_mul_quant(void* out_i8, const void* in_i32, float scale_gate, float scale_up,
+                                    float scale_out, void* token_scale_f32, void* tmp_f32, int tokens, int d,
+                                    void* stream);
+
 /* ---- Fused extensions (opt-in, NOT part of the reference API) --------------
  * Bit-identical to the two reference calls they replace; they exist because at MI355X speeds a
  * decode step is bound by the number of dependent kernels, not by bytes. */

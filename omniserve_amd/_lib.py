@@ -35,6 +35,14 @@ PROTOTYPES = {
     "omni_rms_norm_general": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "omni_rms_norm_general_fuse_sum": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "omni_silu_and_mul": (_i, [_vp, _vp, _i, _i, _vp]),
+    "omni_quant_static": (_i, [_vp, _vp, _f, _i, _i, _vp]),
+    "omni_dequant": (_i, [_vp, _vp, _f, _i, _i, _c.c_longlong, _c.c_longlong, _vp]),
+    "omni_dequant_add_residual": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "omni_rms_norm_quant": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp]),
+    "omni_rms_norm_general_static": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "omni_dequant_add_residual_rms_norm_quant": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp]),
+    "omni_gelu": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "omni_dequant_silu_and_mul_quant": (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _i, _i, _vp]),
     "omni_add_rms_norm_general_fuse_sum": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "omni_silu_mul_quant_fuse_sum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "omni_w4a8_per_chn_gemm_partial": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _c.POINTER(_i), _vp]),

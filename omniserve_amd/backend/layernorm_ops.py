@@ -1,4 +1,6 @@
-"""Mirror of omniserve_backend.layernorm_ops (kernels/csrc/layernorm.cpp:52-77)."""
+"""Mirror of omniserve_backend.layernorm_ops (kernels/csrc/layernorm.cpp:17-77): every function and overload."""
+import torch
+
 from .. import _lib
 
 
@@ -8,23 +10,28 @@ def _shape(input):
 
 
 def rms_norm(out, input, weight, epsilon, use_quant=False):
-    if use_quant:
-        raise NotImplementedError("rms_norm(use_quant=True) is not on the W4A8 path")
+    """fp16 out (layernorm_kernels.cu:335-365), or with use_quant int8 out = rni_sat((x * rstd) * w)."""
     _lib.require_cuda(out, input, weight)
     tokens, hidden = _shape(input)
-    rc = _lib.lib().omni_rms_norm(out.data_ptr(), input.data_ptr(), weight.data_ptr(), float(epsilon),
-                                  tokens, hidden, _lib.current_stream())
+    fn = _lib.lib().omni_rms_norm_quant if use_quant else _lib.lib().omni_rms_norm
+    if use_quant and out.dtype != torch.int8:
+        raise RuntimeError("rms_norm(use_quant=True): int8 output expected")
+    if use_quant and tokens == 0:
+        return
+    rc = fn(out.data_ptr(), input.data_ptr(), weight.data_ptr(), float(epsilon), tokens, hidden, _lib.current_stream())
     _lib.check(rc, "layernorm_ops.rms_norm")
 
 
 def rms_norm_general(out, input, weight, scaling, epsilon, use_per_token_quant=False):
-    if not use_per_token_quant:
-        raise NotImplementedError("rms_norm_general: per-tensor scaling is not on the W4A8 path")
+    """Per token: scaling [tokens] is written (layernorm_kernels.cu:443-454); per tensor: scaling [1] is read,
+    q = rni_sat(y * scaling) (:455-466)."""
     _lib.require_cuda(out, input, weight, scaling)
     tokens, hidden = _shape(input)
-    rc = _lib.lib().omni_rms_norm_general(out.data_ptr(), input.data_ptr(), weight.data_ptr(),
-                                          scaling.data_ptr(), float(epsilon), tokens, hidden,
-                                          _lib.current_stream())
+    fn = _lib.lib().omni_rms_norm_general if use_per_token_quant else _lib.lib().omni_rms_norm_general_static
+    if tokens == 0 and not use_per_token_quant:
+        return
+    rc = fn(out.data_ptr(), input.data_ptr(), weight.data_ptr(), scaling.data_ptr(), float(epsilon), tokens, hidden,
+            _lib.current_stream())
     _lib.check(rc, "layernorm_ops.rms_norm_general")
 
 
@@ -38,3 +45,26 @@ def rms_norm_general_fuse_sum(out, input, weight, input_sum, scaling, epsilon, u
                                                    input_sum.data_ptr(), scaling.data_ptr(),
                                                    float(epsilon), tokens, hidden, _lib.current_stream())
     _lib.check(rc, "layernorm_ops.rms_norm_general_fuse_sum")
+
+
+def invoke_dequant_add_residual_rms_norm_quant(out, input, residual, gamma, scale, epsilon):
+    """residual += int32 input * scale (in place); out int8 = rni_sat(rms_norm(residual) * gamma)
+    (layernorm_kernels.cu:370-409, launches :515-561); `scale` a float or a [tokens] fp16 tensor."""
+    _lib.require_cuda(out, input, residual, gamma)
+    if not (input.is_contiguous() and out.is_contiguous() and residual.is_contiguous()):
+        raise RuntimeError("invoke_dequant_add_residual_rms_norm_quant: tensors must be contiguous")
+    if input.dtype != torch.int32 or residual.dtype != torch.float16 or out.dtype != torch.int8:
+        raise RuntimeError("invoke_dequant_add_residual_rms_norm_quant: int32 input, fp16 residual, int8 out expected")
+    tokens, hidden = _shape(input)
+    per_token = torch.is_tensor(scale)
+    if per_token:
+        _lib.require_cuda(scale)
+        if scale.dtype != torch.float16 or scale.numel() < tokens:
+            raise RuntimeError("invoke_dequant_add_residual_rms_norm_quant: scale must be fp16 [tokens]")
+    if tokens == 0:
+        return
+    rc = _lib.lib().omni_dequant_add_residual_rms_norm_quant(
+        out.data_ptr(), input.data_ptr(), residual.data_ptr(), gamma.data_ptr(),
+        scale.data_ptr() if per_token else None, 0.0 if per_token else float(scale), float(epsilon), tokens, hidden,
+        _lib.current_stream())
+    _lib.check(rc, "layernorm_ops.invoke_dequant_add_residual_rms_norm_quant")

@@ -169,3 +169,144 @@ def silu_and_mul(x_h):
     e = np.exp((-a).astype(F32)).astype(F32)
     s = (a / (F32(1.0) + e).astype(F32)).astype(F32).astype(F16).astype(F32)
     return (s * b).astype(F32).astype(F16)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Overloads the Llama W4A8 / W8A8 paths never call (SURVEY.md 8b lists them as part of the module surface):
+# static (per-tensor) scales, int32 -> fp16 dequantisation, the T5-style fused residual norm, GELU.
+# nvcc contracts `a * b + c` into one FMA (default -fmad=true); `_fma32` models that with a float64 product and
+# sum (exact for these operand widths, then one rounding to float32).  Divisions / rsqrt / exp / tanh are IEEE
+# here, approximate under the reference's --use_fast_math: compare with a tolerance where they are involved.
+# ------------------------------------------------------------------------------------------------------------
+def _fma32(a, b, c):
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(F32)
+
+
+def _h(scale) -> np.float32:
+    """A Python float bound to an `at::Half` parameter: rounded to fp16 once (pybind11 caster)."""
+    return F32(F16(scale))
+
+
+def quant_static(x_h, scale: float):
+    """invoke_quant / invoke_quant_fuse_sum, `at::Half scale` overloads (fused_kernels.cu:88-93,136-141,202-216,
+    238-253): q = rni_sat(f32(x) / f32(scale)); the scalar `input_sum` of the fuse_sum overload is unused."""
+    x = np.asarray(x_h, dtype=F16).astype(F32)
+    return rni_sat_s8((x / _h(scale)).astype(F32))
+
+
+def dequant(x_i32, scale: float):
+    """invoke_dequant (fused_kernels.cu:45-55,184-200): out = h(f32(acc) * f32(scale))."""
+    return (np.asarray(x_i32, np.int32).astype(F32) * _h(scale)).astype(F32).astype(F16)
+
+
+def dequant_add_residual(x_i32, residual_h, scale):
+    """invoke_dequant_add_residual (fused_kernels.cu:24-43,145-182): out = h(fma(f32(acc), f32(scale), f32(res)));
+    `scale` is a Python float (at::Half) or a [tokens] fp16 array (per-token)."""
+    acc = np.asarray(x_i32, np.int32).astype(F32)
+    res = np.asarray(residual_h, F16).astype(F32)
+    s = np.asarray(scale, F16).astype(F32).reshape(-1, 1) if np.ndim(scale) else _h(scale)
+    return _fma32(acc, s, res).astype(F16)
+
+
+def rms_norm_quant(x_h, weight_h, eps: float):
+    """rms_norm_kernel<half, int8_t, true> (layernorm_kernels.cu:335-365): q = rni_sat((x * rstd) * f32(w)),
+    both products in f32; block = min(hidden, 1024)."""
+    x = np.asarray(x_h, dtype=F16).astype(F32)
+    w = np.asarray(weight_h, dtype=F16).astype(F32)
+    tokens, hidden = x.shape
+    nt = min(hidden, 1024)
+    assert nt % 32 == 0
+    pvar = _thread_partials((x * x).astype(F32), nt, lambda a, c: (a + c).astype(F32), 0.0)   # x*x is exact in f32
+    var = ref_tree_sum(pvar)
+    rstd = (F32(1.0) / np.sqrt(((var / F32(hidden)).astype(F32) + F32(eps)).astype(F32))).astype(F32)
+    return rni_sat_s8(((x * rstd[:, None]).astype(F32) * w[None, :]).astype(F32))
+
+
+def rms_norm_general_static(x_h, gamma_h, scale_h, eps: float):
+    """generalLayerNorm<half, at::Half>, per-tensor path (layernorm_kernels.cu:58-196, launch :455-466):
+    y = h(((x - mean) * rstd) * gamma) [mean subtracted in the output only], q = rni_sat(f32(y) * f32(scale[0]))."""
+    x = np.asarray(x_h, dtype=F16).astype(F32)
+    g = np.asarray(gamma_h, dtype=F16).astype(F32)
+    tokens, hidden = x.shape
+    nt = ((min(hidden, 1024) + 31) // 32) * 32
+    psum = _thread_partials(x, nt, lambda a, c: (a + c).astype(F32), 0.0)
+    mean = (ref_tree_sum(psum) / F32(hidden)).astype(F32)
+    pvar = _thread_partials((x * x).astype(F32), nt, lambda a, c: (a + c).astype(F32), 0.0)
+    var = ref_tree_sum(pvar)
+    rstd = (F32(1.0) / np.sqrt(((var / F32(hidden)).astype(F32) + F32(eps)).astype(F32))).astype(F32)
+    y = ((x - mean[:, None]).astype(F32) * rstd[:, None]).astype(F32)
+    yh = (y * g[None, :]).astype(F32).astype(F16)
+    s = np.asarray(scale_h, F16).reshape(-1)[0].astype(F32)
+    return rni_sat_s8((yh.astype(F32) * s).astype(F32))
+
+
+def dequant_add_residual_rms_norm_quant(x_i32, residual_h, gamma_h, scale, eps: float):
+    """invoke_dequant_add_residual_rms_norm_quant (layernorm_kernels.cu:370-409, launches :515-561):
+    diff = fma(f32(acc), f32(scale), f32(res)) kept in f32 for the variance (per-thread fma(diff, diff, sum), block
+    tree), residual <- h(diff) in place, q = rni_sat((f32(h(diff)) * rstd) * f32(gamma)); no mean subtraction.
+    Returns (q, new residual).  block = min(hidden, 1024)."""
+    acc = np.asarray(x_i32, np.int32).astype(F32)
+    res = np.asarray(residual_h, F16).astype(F32)
+    g = np.asarray(gamma_h, dtype=F16).astype(F32)
+    tokens, hidden = acc.shape
+    nt = min(hidden, 1024)
+    assert nt % 32 == 0
+    s = np.asarray(scale, F16).astype(F32).reshape(-1, 1) if np.ndim(scale) else _h(scale)
+    diff = _fma32(acc, s, res)
+    new_res = diff.astype(F16)
+    pvar = _thread_partials(diff, nt, lambda a, c: _fma32(c, c, a), 0.0)
+    var = ref_tree_sum(pvar)
+    rstd = (F32(1.0) / np.sqrt(((var / F32(hidden)).astype(F32) + F32(eps)).astype(F32))).astype(F32)
+    q = rni_sat_s8(((new_res.astype(F32) * rstd[:, None]).astype(F32) * g[None, :]).astype(F32))
+    return q, new_res
+
+
+def _hmul(a, b):
+    with np.errstate(over="ignore"):            # fp16 overflow to inf is the reference's behaviour too
+        return (a.astype(F32) * b.astype(F32)).astype(F32).astype(F16)
+
+
+def _hadd(a, b):
+    with np.errstate(over="ignore"):
+        return (a.astype(F32) + b.astype(F32)).astype(F32).astype(F16)
+
+
+def gelu_new(x_h):
+    """gelu_new_kernel<c10::Half> (activation_kernels.cu:186-190): every c10::Half operator computes in f32 and
+    rounds to fp16."""
+    x = np.asarray(x_h, F16)
+    x3 = _hmul(_hmul(x, x), x).astype(F32)
+    inner = _hadd(x, (F32(0.044715) * x3).astype(F32).astype(F16))
+    u = (F32(0.79788456) * inner.astype(F32)).astype(F32).astype(F16)
+    t = np.tanh(u.astype(F32)).astype(F32).astype(F16)
+    return _hmul(_hmul(np.full_like(x, 0.5), x), _hadd(np.full_like(x, 1.0), t))
+
+
+def gelu_fast(x_h):
+    """gelu_fast_kernel<c10::Half> (activation_kernels.cu:192-198)."""
+    x = np.asarray(x_h, F16)
+    f = x.astype(F32)
+    a = (f * F32(0.79788456)).astype(F32).astype(F16)
+    b = (F32(0.044715) * f).astype(F32).astype(F16)
+    d = _hadd(np.full_like(x, 1.0), _hmul(b, x))
+    t = np.tanh(_hmul(a, d).astype(F32)).astype(F32).astype(F16)
+    return _hmul(_hmul(np.full_like(x, 0.5), x), _hadd(np.full_like(x, 1.0), t))
+
+
+def dequant_silu_and_mul_quant(x_i32, scale_gate: float, scale_up: float, scale_out=None):
+    """invoke_dequant_silu_and_mul_quant (activation_kernels.cu:31-86,100-131), float scales.
+    t = silu(f32(gate) * scale_gate) * (f32(up) * scale_up) in f32.
+    scale_out given (static): q = rni_sat(t / scale_out) -> q.
+    scale_out None (per token): tmp = t, scale = amax/127 (f32), q = rni_sat((127/amax) * tmp) -> (q, scale, tmp)."""
+    acc = np.asarray(x_i32, np.int32)
+    d = acc.shape[-1] // 2
+    x = (acc[..., :d].astype(F32) * F32(scale_gate)).astype(F32)
+    y = (acc[..., d:].astype(F32) * F32(scale_up)).astype(F32)
+    e = np.exp((-x).astype(F32)).astype(F32)
+    t = ((x / (F32(1.0) + e).astype(F32)).astype(F32) * y).astype(F32)
+    if scale_out is not None:
+        return rni_sat_s8((t / F32(scale_out)).astype(F32))
+    amax = np.abs(t).max(axis=-1).astype(F32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = rni_sat_s8(((F32(127.0) / amax).astype(F32)[..., None] * t).astype(F32))
+    return q, (amax / F32(127.0)).astype(F32), t

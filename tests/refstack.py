@@ -157,6 +157,62 @@ class OracleLib:
         _arr(out, (tokens, d), F16)[:] = oe.silu_and_mul(_arr(x, (tokens, 2 * d), F16))
         return 0
 
+    # ---- overloads off the Llama path (csrc/offpath.hip) ---------------------------------------------------------------
+    def omni_quant_static(self, out, x, scale, tokens, hidden, stream):
+        self.calls.append("omni_quant_static")
+        _arr(out, (tokens, hidden), np.int8)[:] = oe.quant_static(_arr(x, (tokens, hidden), F16), scale)
+        return 0
+
+    def omni_dequant(self, out, x, scale, tokens, hidden, in_stride, out_stride, stream):
+        self.calls.append("omni_dequant")
+        _rows(out, tokens, hidden, out_stride, F16)[:] = oe.dequant(_rows(x, tokens, hidden, in_stride, np.int32), scale)
+        return 0
+
+    def omni_dequant_add_residual(self, out, x, res, tok_scale, scale, tokens, hidden, stream):
+        self.calls.append("omni_dequant_add_residual")
+        sc = _arr(tok_scale, (tokens,), F16) if tok_scale else scale
+        _arr(out, (tokens, hidden), F16)[:] = oe.dequant_add_residual(_arr(x, (tokens, hidden), np.int32),
+                                                                      _arr(res, (tokens, hidden), F16), sc)
+        return 0
+
+    def omni_rms_norm_quant(self, out, x, w, eps, tokens, hidden, stream):
+        self.calls.append("omni_rms_norm_quant")
+        _arr(out, (tokens, hidden), np.int8)[:] = oe.rms_norm_quant(_arr(x, (tokens, hidden), F16), _arr(w, (hidden,), F16), eps)
+        return 0
+
+    def omni_rms_norm_general_static(self, out, x, w, scaling, eps, tokens, hidden, stream):
+        self.calls.append("omni_rms_norm_general_static")
+        _arr(out, (tokens, hidden), np.int8)[:] = oe.rms_norm_general_static(
+            _arr(x, (tokens, hidden), F16), _arr(w, (hidden,), F16), _arr(scaling, (1,), F16), eps)
+        return 0
+
+    def omni_dequant_add_residual_rms_norm_quant(self, out, x, res, gamma, tok_scale, scale, eps, tokens, hidden, stream):
+        self.calls.append("omni_dequant_add_residual_rms_norm_quant")
+        sc = _arr(tok_scale, (tokens,), F16) if tok_scale else scale
+        r = _arr(res, (tokens, hidden), F16)
+        q, nr = oe.dequant_add_residual_rms_norm_quant(_arr(x, (tokens, hidden), np.int32), r.copy(),
+                                                       _arr(gamma, (hidden,), F16), sc, eps)
+        _arr(out, (tokens, hidden), np.int8)[:] = q
+        r[:] = nr
+        return 0
+
+    def omni_gelu(self, out, x, kind, tokens, d, stream):
+        self.calls.append("omni_gelu")
+        _arr(out, (tokens, d), F16)[:] = (oe.gelu_fast if kind else oe.gelu_new)(_arr(x, (tokens, d), F16))
+        return 0
+
+    def omni_dequant_silu_and_mul_quant(self, out, x, sg, su, so, tok_scale, tmp, tokens, d, stream):
+        self.calls.append("omni_dequant_silu_and_mul_quant")
+        acc = _arr(x, (tokens, 2 * d), np.int32)
+        if tok_scale:
+            q, s, t = oe.dequant_silu_and_mul_quant(acc, sg, su)
+            _arr(tok_scale, (tokens,), np.float32)[:] = s
+            _arr(tmp, (tokens, d), np.float32)[:] = t
+        else:
+            q = oe.dequant_silu_and_mul_quant(acc, sg, su, so)
+        _arr(out, (tokens, d), np.int8)[:] = q
+        return 0
+
     # ---- KV4 cache -------------------------------------------------------------------------------------------------------
     def omni_compute_padding_offsets(self, out, cu, batch, max_len, total, stream):
         self.calls.append("omni_compute_padding_offsets")

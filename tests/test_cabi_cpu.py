@@ -31,6 +31,18 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     # null pointers / bad shapes must return -EINVAL before any launch
     assert h.omni_w4a8_per_chn_gemm(None, None, None, None, None, None, None, 16, 64, 64, 64, None, 0, None) == -22
     assert h.omni_quant(None, None, None, 4, 128, None) == -22
+    # the off-path overloads (csrc/offpath.hip): null pointers, rows that are not a multiple of 8, over-long norm rows
+    assert h.omni_quant_static(None, None, 0.5, 4, 128, None) == -22
+    assert h.omni_quant_static(1, 1, 0.5, 4, 100, None) == -22
+    assert h.omni_dequant(1, 1, 0.5, 4, 128, 64, 128, None) == -22          # row stride shorter than the row
+    assert h.omni_dequant_add_residual(1, 1, None, None, 0.5, 4, 128, None) == -22
+    assert h.omni_rms_norm_quant(1, 1, 1, 1e-6, 4, 16384, None) == -22      # does not fit the LDS copy of the row
+    assert h.omni_rms_norm_quant(1, 1, 1, 1e-6, 4, 200, None) == -22        # partial virtual warp
+    assert h.omni_rms_norm_general_static(1, 1, 1, None, 1e-6, 4, 128, None) == -22
+    assert h.omni_dequant_add_residual_rms_norm_quant(1, 1, None, 1, None, 0.5, 1e-6, 4, 128, None) == -22
+    assert h.omni_gelu(1, 1, 2, 4, 128, None) == -22                        # kind is 0 (new) or 1 (fast)
+    assert h.omni_dequant_silu_and_mul_quant(1, 1, 1.0, 1.0, 1.0, 1, None, 4, 128, None) == -22   # scale without tmp
+    assert h.omni_quant_static(1, 1, 0.5, 0, 128, None) == 0                # nothing to do: no launch
     assert h.omni_gemm_workspace_bytes(16, 4096, 4096) > 0
     assert h.omni_gemm_workspace_bytes(4096, 4096, 4096) == 0
 
@@ -40,9 +52,12 @@ REFERENCE_API = {
     "qgemm_w4a8_per_chn": {"gemm_forward_cuda": 7},
     "qgemm_w4a8_per_group": {"gemm_forward_cuda": 7},
     "qgemm_w8a8": {"w8a8_gemm_forward_cuda": 5},
-    "fused_kernels": {"invoke_quant": 3, "invoke_quant_fuse_sum": 4},
-    "layernorm_ops": {"rms_norm": 5, "rms_norm_general": 6, "rms_norm_general_fuse_sum": 7},
-    "activation_ops": {"silu_and_mul": 2},
+    "fused_kernels": {"invoke_quant": 3, "invoke_quant_fuse_sum": 4, "invoke_dequant": 3,
+                      "invoke_dequant_add_residual": 4},
+    "layernorm_ops": {"rms_norm": 5, "rms_norm_general": 6, "rms_norm_general_fuse_sum": 7,
+                      "invoke_dequant_add_residual_rms_norm_quant": 6},
+    # invoke_dequant_silu_and_mul_quant: 5 (float scale_out) or 6 (tensor scale_out, tmp) positional arguments
+    "activation_ops": {"silu_and_mul": 2, "gelu_new": 2, "gelu_fast": 2, "invoke_dequant_silu_and_mul_quant": 6},
     "fused_attention_pure_dense": {"single_query_attention": 15, "apply_bias_rope_update_kv_cache": 15,
                                    "compute_padding_offsets": 3},
     "fused_attention_fine_grained_dense": {"apply_bias_rope_update_kv_cache": 27, "compute_padding_offsets": 3,

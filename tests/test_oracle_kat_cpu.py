@@ -163,3 +163,75 @@ def test_prefill_attention_oracle_lambda_mask():        # causal & (d
             p = np.exp(s - s.max()); p /= p.sum()
             want = p @ v[keys, 0].astype(np.float64)
             assert np.abs(out[i, h].astype(np.float64) - want).max() < 2e-3
+
+
+# ---- the overloads off the Llama path (oracle/elementwise.py, second half) ----------------------------------------------
+def test_fma32_is_a_single_rounding():       # nvcc contracts a*b+c (fused_kernels.cu:35-36, layernorm_kernels.cu:384-391)
+    from fractions import Fraction
+    rng = np.random.default_rng(0)
+    a = rng.integers(-2 ** 22, 2 ** 22, 4000).astype(F32)
+    b = rng.standard_normal(4000).astype(F16).astype(F32) * F32(2.0 ** -10)
+    c = rng.standard_normal(4000).astype(F16).astype(F32)
+    r = oe._fma32(a, b, c)
+    two_step = ((a * b).astype(F32) + c).astype(F32)
+    assert (r != two_step).any()             # the cases below do discriminate FMA from multiply-then-add
+    for i in np.flatnonzero(r != two_step)[:50]:
+        exact = Fraction(float(a[i])) * Fraction(float(b[i])) + Fraction(float(c[i]))
+        err = abs(Fraction(float(r[i])) - exact)
+        for nb in (np.nextafter(r[i], F32(np.inf)), np.nextafter(r[i], F32(-np.inf))):
+            assert err <= abs(Fraction(float(nb)) - exact)      # r is the f32 nearest to the exact value
+
+
+def test_static_quantiser_divides_by_the_fp16_rounded_scale():       # fused_kernels.cu:88-93 + the at::Half caster
+    x = np.array([[0.25, 0.75, 1.25, -0.75, 100.0, -100.0, 0.0, 0.125]], F16)
+    assert oe.quant_static(x, 0.5).tolist() == [[0, 2, 2, -2, 127, -128, 0, 0]]      # ties to even, saturation
+    # 0.1 is not an fp16 number: h(0.1) = 0.0999755859375, and 3.25 / h(0.1) = 32.5079 -> 33 while 3.25 / 0.1 = 32.5 -> 32
+    assert oe.quant_static(np.array([[3.25]], F16), 0.1).tolist() == [[33]]
+
+
+def test_dequant_overloads_known_answers():        # fused_kernels.cu:24-55
+    acc = np.array([[1024, -3, 7, 0]], np.int32)
+    assert oe.dequant(acc, 0.5).tolist() == [[512.0, -1.5, 3.5, 0.0]]
+    res = np.array([[1.0, 1.0, -3.5, 2.0]], F16)
+    assert oe.dequant_add_residual(acc, res, 0.5).tolist() == [[513.0, -0.5, 0.0, 2.0]]
+    tok = np.array([0.25], F16)
+    assert oe.dequant_add_residual(acc, res, tok).tolist() == [[257.0, 0.25, -1.75, 2.0]]
+
+
+def test_t5_style_fused_norm_does_not_subtract_the_mean():          # layernorm_kernels.cu:370-409
+    acc = np.full((1, 32), 1000, np.int32)
+    res = np.full((1, 32), 0.0234375, F16)                  # 1000 * 2^-10 + 3 * 2^-7 = 1.0 exactly
+    q, new_res = oe.dequant_add_residual_rms_norm_quant(acc, res, np.full((32,), 100.0, F16), 2.0 ** -10, 1e-6)
+    assert (new_res == F16(1.0)).all()
+    assert (q == 100).all()             # a mean-subtracting norm would give 0 on a constant row
+
+
+def test_static_norms_known_answers():              # layernorm_kernels.cu:58-196 (per tensor), :335-365 (use_quant)
+    x = np.tile(np.array([1.0, 3.0], F16), 16)[None, :]
+    q = oe.rms_norm_general_static(x, np.ones((32,), F16), np.array([100.0], F16), 0.0)
+    # mean 2, mean(x^2) 5: y = +-1/sqrt(5) = +-0.44721 -> fp16 0.447265625 -> * 100 = 44.73 -> 45
+    assert q[0].tolist() == [-45, 45] * 16
+    q = oe.rms_norm_quant(x, np.full((32,), 10.0, F16), 0.0)
+    assert q[0].tolist() == [4, 13] * 16        # 10/sqrt(5) = 4.47, 30/sqrt(5) = 13.42: no mean subtraction here
+
+
+def test_gelu_in_half_arithmetic_known_answers():          # activation_kernels.cu:186-198
+    x = np.array([0.0, 1.0, -1.0, 8.0, -8.0], F16)
+    for fn in (oe.gelu_new, oe.gelu_fast):
+        y = fn(x)
+        assert y[0] == 0 and y[3] == F16(8.0) and y[4] == 0
+        # x = 1: inner 1.044921875, u = 0.83349609375, tanh 0.68235 -> fp16 0.68212890625; 1 + t = 1.68212890625 is a
+        # tie between two fp16 numbers -> even: 1.681640625; times 0.5.  x = -1: 1 - t = 0.31787109375 is exact.
+        assert float(y[1]) == 0.8408203125 and float(y[2]) == -0.158935546875
+    big = oe.gelu_new(np.array([65504.0], F16))         # x*x overflows to inf in fp16, tanh(inf) = 1: still x
+    assert float(big[0]) == 65504.0
+
+
+def test_dequant_silu_quant_known_answers():            # activation_kernels.cu:31-82
+    acc = np.array([[0, 20000, -20000, 40000, 10000, 10000, 10000, -10000]], np.int32)      # gate | up, d = 4
+    q, scale, tmp = oe.dequant_silu_and_mul_quant(acc, 1e-4, 1e-4)
+    g, u = acc[0, :4] * 1e-4, acc[0, 4:] * 1e-4
+    want = g / (1 + np.exp(-g)) * u
+    assert np.allclose(tmp[0], want, rtol=1e-6) and np.isclose(scale[0], np.abs(want).max() / 127, rtol=1e-6)
+    assert q[0].tolist() == [0, int(np.rint(want[1] / scale[0])), int(np.rint(want[2] / scale[0])), -127]
+    assert oe.dequant_silu_and_mul_quant(acc, 1e-4, 1e-4, 0.01)[0].tolist() == [0, 127, -24, -128]

@@ -15,13 +15,10 @@ REF = "/root/reference/omniserve"
 # Mixtral / MoE and the fp16 model are out of scope: their files are not scanned
 SKIP_FILES = {"mixtral_w4a8_unpad.py", "llama_w16a16_unpad.py", "w4a8_moe_linear.py"}
 THIRD_PARTY = {"block_sparse_attn", "flash_attn.flash_attn_interface", "flash_attn"}
-# Ops of the static-scale SmoothQuant W8A8 path and the GPT-style activations: defined by the reference's extension,
-# called only from classes no QServe / LServe Llama model instantiates (activation.py:100-157 DequantSiluAndMulQuant /
-# NewGELU / FastGELU, layernorm.py:104-155 DequantAddResidualI8RMSNormQuant; SURVEY.md section 2 marks them unused).
-# The mirror deliberately does not define them; everything else must bind.
-OUT_OF_PATH = {("omniserve_backend.activation_ops", "gelu_new"), ("omniserve_backend.activation_ops", "gelu_fast"),
-               ("omniserve_backend.activation_ops", "invoke_dequant_silu_and_mul_quant"),
-               ("omniserve_backend.layernorm_ops", "invoke_dequant_add_residual_rms_norm_quant")}
+# Nothing is exempt: the static-scale SmoothQuant W8A8 ops and the GPT-style activations (activation.py:100-157
+# DequantSiluAndMulQuant / NewGELU / FastGELU, layernorm.py:104-155 DequantAddResidualI8RMSNormQuant), which no QServe /
+# LServe Llama model instantiates, are mirrored too (omniserve_amd/csrc/offpath.hip).
+OUT_OF_PATH = set()
 
 
 def _call_sites():

@@ -77,6 +77,75 @@ def test_reference_w8a8_linear_over_the_mirror():
         assert np.array_equal(_bits(out), want.view(np.uint16))
 
 
+def test_reference_static_scale_and_gelu_modules_over_the_mirror():
+    """The modules no Llama model instantiates (activation.py:84-157, layernorm.py:19-43,104-155): their calls bind to
+    the mirror's overloads and land on the right C-ABI entry with the right operands."""
+    with refstack.reference_over_mirror() as lib:
+        from omniserve.modeling.layers.activation import DequantSiluAndMulQuant, FastGELU, NewGELU
+        from omniserve.modeling.layers.layernorm import DequantAddResidualI8RMSNormQuant, RMSNorm, RMSNormGeneral
+        g = torch.Generator().manual_seed(9)
+        T, H = 5, 256
+        acc = torch.randint(-50000, 50000, (T, H), generator=g, dtype=torch.int32)
+        res = torch.randn((T, H), generator=g).half()
+        # dequant + residual + T5-style norm + static quant: per-tensor and per-token dequant scale
+        for per_token in (False, True):
+            lib.calls.clear()
+            m = DequantAddResidualI8RMSNormQuant(H, dequant_scale=0.0003, use_per_token_dequant=per_token, eps=1e-6)
+            m.weight.data = (20.0 * (1.0 + 0.1 * torch.randn((H,), generator=g))).half()
+            tok = (0.5 + torch.rand((T,), generator=g)).half() if per_token else None
+            r = res.clone()
+            r_out, q = m(r, acc, tok)
+            assert lib.calls == ["omni_dequant_add_residual_rms_norm_quant"] and r_out is r
+            sc = (tok * m.dequant_scale.item()).numpy() if per_token else float(m.dequant_scale.item())
+            want_q, want_r = oe.dequant_add_residual_rms_norm_quant(acc.numpy(), res.numpy(), m.weight.data.numpy(), sc, 1e-6)
+            assert np.array_equal(q.numpy(), want_q) and np.array_equal(_bits(r), want_r.view(np.uint16))
+            xf = acc.double().numpy() * (np.asarray(sc, np.float64).reshape(-1, 1) if per_token else sc) + res.double().numpy()
+            y = xf / np.sqrt((xf * xf).mean(1, keepdims=True) + 1e-6) * m.weight.data.double().numpy()
+            assert np.abs(q.numpy() - np.clip(np.rint(y), -128, 127)).max() <= 1          # textbook, within a code
+        # int32 gate/up -> silu*mul -> int8, static and per-token output scale
+        gu = torch.randint(-40000, 40000, (T, 2 * H), generator=g, dtype=torch.int32)
+        for per_token in (True, False):
+            lib.calls.clear()
+            m = DequantSiluAndMulQuant(dequant_scale=1e-4, quant_scale=0.05, use_per_token_quant=per_token)
+            outs = m(gu)
+            assert lib.calls == ["omni_dequant_silu_and_mul_quant"]
+            sg = float(m.dequant_scale.item())
+            if per_token:
+                q, s, _ = oe.dequant_silu_and_mul_quant(gu.numpy(), sg, sg)
+                assert np.array_equal(outs[0].numpy(), q) and np.array_equal(outs[1].numpy(), s)
+            else:
+                assert np.array_equal(outs[0].numpy(), oe.dequant_silu_and_mul_quant(gu.numpy(), sg, sg, float(m.quant_scale.item())))
+            x64, y64 = gu[:, :H].double().numpy() * sg, gu[:, H:].double().numpy() * sg
+            t = x64 / (1 + np.exp(-x64)) * y64
+            deq = outs[0].double().numpy() * (outs[1].double().numpy()[:, None] if per_token else float(m.quant_scale.item()))
+            step = outs[1].max().item() if per_token else float(m.quant_scale.item())
+            inside = np.abs(t) < 127 * step if not per_token else np.ones_like(t, bool)      # the static scale saturates
+            assert np.abs(deq - t)[inside].max() <= 0.51 * step + 1e-6
+            assert np.all(np.abs(outs[0].numpy().astype(np.int32)[~inside]) >= 127)
+        # GELUs
+        x = (2.0 * torch.randn((T, H), generator=g)).half()
+        for mod, fn in ((NewGELU(), oe.gelu_new), (FastGELU(), oe.gelu_fast)):
+            lib.calls.clear()
+            out = mod(x)
+            assert lib.calls == ["omni_gelu"]
+            assert np.array_equal(_bits(out), fn(x.numpy()).view(np.uint16))
+            assert np.abs(out.float().numpy() - torch.nn.functional.gelu(x.float(), approximate="tanh").numpy()).max() < 4e-3
+        # rms_norm(use_quant=True) and the per-tensor general norm
+        lib.calls.clear()
+        n1 = RMSNorm(H, eps=1e-5, use_quant=True)
+        n1.weight.data = (20.0 * (1.0 + 0.1 * torch.randn((H,), generator=g))).half()
+        q = n1(x)
+        assert lib.calls == ["omni_rms_norm_quant"] and q.dtype == torch.int8
+        assert np.array_equal(q.numpy(), oe.rms_norm_quant(x.numpy(), n1.weight.data.numpy(), 1e-5))
+        lib.calls.clear()
+        n2 = RMSNormGeneral(H, act_sum=False, eps=1e-5, use_per_token_quant=False)
+        n2.weight.data = (1.0 + 0.1 * torch.randn((H,), generator=g)).half()
+        qb, scaling = torch.empty((T, H), dtype=torch.int8), torch.tensor([21.0], dtype=torch.float16)
+        n2(x, qb, scaling)
+        assert lib.calls == ["omni_rms_norm_general_static"]
+        assert np.array_equal(qb.numpy(), oe.rms_norm_general_static(x.numpy(), n2.weight.data.numpy(), scaling.numpy(), 1e-5))
+
+
 @pytest.mark.parametrize("act_sum", [True, False])
 def test_reference_norm_and_activation_modules_over_the_mirror(act_sum):
     with refstack.reference_over_mirror() as lib:
