@@ -221,8 +221,9 @@ class LServeDecodeRunner:
                     _, idx = stats[:, :, : total_pages - 1].topk(k=npick - 1, dim=-1)
                     self.page_idx[li][:, :, : npick - 1].copy_(idx)
                     self.page_idx[li][:, :, npick - 1].fill_(total_pages - 1)
-            else:
-                self.page_idx[li][:, :, -1].fill_(total_pages - 1)     # the newest page is always attended
+            # (no refresh: the cached selection is used as it is, decoding_attention.py:259-260 -- also across a page
+            #  boundary, where its last entry is then the previous page, full, and the new page is first selected at the
+            #  next refresh)
             common = (self.tpb, size_r, size_s, self.sink, self.local, self.sink_blocks, self.local_blocks, self.nr,
                       self.ns, hist + 1, d, c.rope_theta, 1.0, True, not self.kv8, not self.kv8, self.sub, self.nr * d,
                       2048)
@@ -278,7 +279,9 @@ class LServeDecodeRunner:
         count only changes every 64 tokens, and the benchmark runs far fewer steps than that."""
         bucket = (self.context0 + self.steps_done) // self.tpb
         hist = (bucket + 1) * self.tpb - 1          # largest history length with the same page count
-        select = self.steps_done % self.interval == 0
+        # decoding_attention.py:259: refresh when nothing is cached yet (first step after the context stage) or when the
+        # length INCLUDING the token being generated (model_runner.py:388-400 -> max_seq_len) is a multiple of the interval
+        select = self.steps_done == 0 or (self.context0 + self.steps_done + 1) % self.interval == 0
         if not self.use_graph:
             self._eager_step(hist, select)
             self.steps_done += 1

@@ -19,7 +19,7 @@ import torch
 
 from oracle import attention as oattn
 from oracle import elementwise as oe
-from oracle import kv4, w4a8
+from oracle import kv4, kv8, w4a8
 
 REF = "/root/reference"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,6 +74,49 @@ class _Pages:
     def scatter(self):
         for cache, idx, dst in self.map:
             dst[:] = cache.pool[idx, : self.page_bytes]
+
+
+class _FGPages:
+    """Both page pools of one layer (retrieval + streaming ring) referenced by two raw-pointer tables, gathered into an
+    oracle FineGrainedKV.  stats_sub > 0: the retrieval K pages carry min/max statistics behind data + tail
+    (cache_engine.py:84-131) and those bytes travel too; otherwise only data + tail are touched."""
+
+    def __init__(self, rp, sp, B, rb, sb, need_r, nr, ns, D, tpb, stats_sub, flags, rank, sink, local, sink_blocks,
+                 local_blocks, kv8_scales=None):
+        self.map = []
+
+        def make(heads, n, which, stats):
+            if kv8_scales is None:
+                return kv4.PagedKV4(max(n, 1), max(heads, 1), D, tpb, stats_sub_chunk=stats)
+            return kv8.PagedKV8(max(n, 1), max(heads, 1), D, kv8_scales[which], tpb, stats_sub_chunk=stats)
+
+        def gather(ptr, blocks, heads, need, stats):
+            n = int(sum(need))
+            k, v = make(heads, n, 0, stats), make(heads, n, 1, 0)
+            kt, vt = np.zeros((B, max(blocks, 1)), np.int64), np.zeros((B, max(blocks, 1)), np.int64)
+            if heads == 0 or not ptr:
+                return k, v, kt, vt
+            tab = _arr(ptr, (B, 2, blocks), np.int64)
+            nxt = 0
+            for b in range(B):
+                for j in range(int(need[b])):
+                    for which, cache, t in ((0, k, kt), (1, v, vt)):
+                        src = _arr(tab[b, which, j], (cache.page_bytes,), np.uint8)
+                        cache.pool[nxt] = src
+                        t[b, j] = nxt
+                        self.map.append((cache, nxt, src))
+                    nxt += 1
+            return k, v, kt, vt
+
+        rk, rv, rkt, rvt = gather(rp, rb, nr, need_r, stats_sub)
+        sk, sv, skt, svt = gather(sp, sb, ns, [sb] * B, 0)
+        self.fg = kv4.FineGrainedKV(rk, rv, rkt, rvt, sk, sv, skt, svt, flags, rank, sink, local, sink_blocks,
+                                    local_blocks, stats_sub)
+        self.rk, self.rkt = rk, rkt
+
+    def scatter(self):
+        for cache, idx, dst in self.map:
+            dst[:] = cache.pool[idx]
 
 
 class OracleLib:
@@ -241,6 +284,97 @@ class OracleLib:
         res = kv4.decode_attention(qa, ka, va, lens, pg.k, pg.v, pg.kt, pg.vt, self.rope[0])
         _arr(out, (B, Hq, D), F16)[:] = res
         pg.scatter()
+        return 0
+
+    # ---- LServe: fine-grained KV4 / per-tensor KV8 pools with streaming rings, statistics pooling, page selector ------------
+    def _fg_prefill(self, qkv, seq_lens, rp, sp, flags, rank, tokens, batch, rb, sb, Hq, Hkv, nr, ns, D, tpb, sink, local,
+                    sink_blocks, local_blocks, kv8_scales):
+        lens = _arr(seq_lens, (batch,), np.int32)
+        fl, rk = _arr(flags, (Hkv,), np.int32), _arr(rank, (Hkv,), np.int32)
+        pg = _FGPages(rp, sp, batch, rb, sb, [(int(n) + tpb - 1) // tpb for n in lens], nr, ns, D, tpb, 0, fl, rk, sink,
+                      local, sink_blocks, local_blocks, kv8_scales)
+        x = _arr(qkv, (tokens, (Hq + 2 * Hkv) * D), F16)
+        base, factor = self.rope
+        x[:] = kv4.prefill_write_fine_grained(x, lens, pg.fg, Hq, Hkv, D, base, factor)
+        pg.scatter()
+        return 0
+
+    def omni_kv4_prefill_write_fine_grained(self, qkv, seq_lens, pad, rp, sp, flags, rank, tokens, batch, rb, sb, Hq, Hkv,
+                                            nr, ns, D, max_seq, tpb, sink, local, sink_blocks, local_blocks, rope, rope_len,
+                                            max_pos, stream):
+        self.calls.append("omni_kv4_prefill_write_fine_grained")
+        return self._fg_prefill(qkv, seq_lens, rp, sp, flags, rank, tokens, batch, rb, sb, Hq, Hkv, nr, ns, D, tpb, sink,
+                                local, sink_blocks, local_blocks, None)
+
+    def omni_kv8_prefill_write_per_tensor(self, qkv, kv_oq, seq_lens, pad, rp, sp, flags, rank, tokens, batch, rb, sb, Hq,
+                                          Hkv, nr, ns, D, max_seq, tpb, sink, local, sink_blocks, local_blocks, rope,
+                                          rope_len, max_pos, stream):
+        self.calls.append("omni_kv8_prefill_write_per_tensor")
+        oq = _arr(kv_oq, (2,), np.float32)
+        return self._fg_prefill(qkv, seq_lens, rp, sp, flags, rank, tokens, batch, rb, sb, Hq, Hkv, nr, ns, D, tpb, sink,
+                                local, sink_blocks, local_blocks, tuple((np.float32(1.0) / oq).astype(np.float32)))
+
+    def _fg_decode(self, out, q, k, v, q_stride, kv_stride, rp, sp, flags, rank, lengths, dyn_ptr, ndyn, sub, B, rb, sb, Hq,
+                   Hkv, nr, ns, D, tpb, sink, local, sink_blocks, local_blocks, kv8_scales):
+        lens = _arr(lengths, (B,), np.int32)
+        fl, rk = _arr(flags, (Hkv,), np.int32), _arr(rank, (Hkv,), np.int32)
+        dyn = _arr(dyn_ptr, (B, Hq, ndyn), np.int32) if dyn_ptr else None
+        pg = _FGPages(rp, sp, B, rb, sb, [(int(n) - 1) // tpb + 1 for n in lens], nr, ns, D, tpb, sub if dyn is not None else 0,
+                      fl, rk, sink, local, sink_blocks, local_blocks, kv8_scales)
+        qa = _rows(q, B, Hq * D, q_stride, F16).reshape(B, Hq, D)
+        ka = _rows(k, B, Hkv * D, kv_stride, F16).reshape(B, Hkv, D)
+        va = _rows(v, B, Hkv * D, kv_stride, F16).reshape(B, Hkv, D)
+        base, factor = self.rope
+        _arr(out, (B, Hq, D), F16)[:] = kv4.decode_attention_fine_grained(qa, ka, va, lens, pg.fg, base, factor, dyn)
+        pg.scatter()
+        return 0
+
+    def omni_kv4_decode_attention_fine_grained(self, out, q, k, v, q_stride, kv_stride, rp, sp, flags, rank, lengths, dyn_ptr,
+                                               ndyn, sub, B, rb, sb, Hq, Hkv, nr, ns, D, tpb, sink, local, sink_blocks,
+                                               local_blocks, max_ctx, rope, rope_len, ws, wsb, stream):
+        self.calls.append("omni_kv4_decode_attention_fine_grained")
+        return self._fg_decode(out, q, k, v, q_stride, kv_stride, rp, sp, flags, rank, lengths, dyn_ptr, ndyn, sub, B, rb, sb,
+                               Hq, Hkv, nr, ns, D, tpb, sink, local, sink_blocks, local_blocks, None)
+
+    def omni_kv8_decode_attention_per_tensor(self, out, q, k, v, q_stride, kv_stride, kv_qo, kv_oq, rp, sp, flags, rank,
+                                             lengths, dyn_ptr, ndyn, sub, B, rb, sb, Hq, Hkv, nr, ns, D, tpb, sink, local,
+                                             sink_blocks, local_blocks, max_ctx, rope, rope_len, ws, wsb, stream):
+        self.calls.append("omni_kv8_decode_attention_per_tensor")
+        qo = _arr(kv_qo, (2,), np.float32)
+        return self._fg_decode(out, q, k, v, q_stride, kv_stride, rp, sp, flags, rank, lengths, dyn_ptr, ndyn, sub, B, rb, sb,
+                               Hq, Hkv, nr, ns, D, tpb, sink, local, sink_blocks, local_blocks, (qo[0], qo[1]))
+
+    def _retrieval_k_pool(self, kv_ptrs, batch, nblk, need, heads, D, row_bytes, tpb, sub):
+        """K pages (with statistics) of the retrieval pool as an oracle pool + index table; returns (pages, scatter)."""
+        kv8_scales = None if row_bytes == D // 2 else (1.0, 1.0)
+        pg = _FGPages(kv_ptrs, 0, batch, nblk, 0, need, heads, 0, D, tpb, sub, [1] * heads, list(range(heads)), 0, 0, 0, 0,
+                      kv8_scales)
+        return pg
+
+    def omni_kv_min_max_pool(self, x, kv_ptrs, cu_seqlens, heads_idx, batch, nblk, H_in, pool_h, D, row_bytes, max_seqlen,
+                             pooling_size, page_size, stream):
+        self.calls.append("omni_kv_min_max_pool")
+        cu = _arr(cu_seqlens, (batch + 1,), np.int32)
+        need = [(int(cu[b + 1] - cu[b]) + page_size - 1) // page_size for b in range(batch)]
+        pg = self._retrieval_k_pool(kv_ptrs, batch, nblk, need, pool_h, D, row_bytes, page_size, pooling_size)
+        keys = _arr(x, (int(cu[-1]), H_in, D), F16)
+        kv4.paged_min_max_pool(keys, cu, [int(h) for h in _arr(heads_idx, (pool_h,), np.int32)], pg.rk.pool, pg.rkt,
+                               page_size, pooling_size, row_bytes=row_bytes)
+        pg.scatter()
+        return 0
+
+    def omni_kv_page_selector(self, out, q, q_stride, kv_ptrs, flags, rank, lengths, B, nblk, Hq, Hkv, nr, D, row_bytes, tpb,
+                              sub, padded, rope, rope_len, stream):
+        self.calls.append("omni_kv_page_selector")
+        lens = _arr(lengths, (B,), np.int32)
+        need = [(int(n) - 1 + tpb - 1) // tpb for n in lens]        # pages that hold history tokens
+        pg = self._retrieval_k_pool(kv_ptrs, B, nblk, need, nr, D, row_bytes, tpb, sub)
+        qa = _rows(q, B, Hq * D, q_stride, F16).reshape(B, Hq, D)
+        base, scale = self.rope
+        want = kv4.page_selector(qa, lens, _arr(flags, (Hkv,), np.int32), _arr(rank, (Hkv,), np.int32), pg.rk.pool, pg.rkt,
+                                 Hkv, nr, tpb, sub, base, scale, row_bytes=row_bytes)
+        o = _arr(out, (B, Hq, padded), F16)          # zero-initialised by the mirror; sized on `timestep` by the caller
+        o[:, :, : want.shape[2]] = want[:, :, : padded]
         return 0
 
     def omni_prefill_attention(self, out, q, k, v, qs, ks, vs, cu_q, cu_k, batch, max_q, Hq, Hkv, D, causal, hm, si, stream):
