@@ -270,6 +270,17 @@ def lserve_leg(device, context=256000, steps=32, warmup=8):
             raise RuntimeError("non-finite activations in the LServe decode step")
         out[fmt] = {"decode_tokens_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
                     "gemm_weight_bytes_per_step": r.weight_bytes_per_step()}
+        if fmt == "kv8":
+            # the context stage of the same configuration (time to first token): all 32 layers over one `context`-token
+            # prompt -- W8A8 GEMMs, cache write, statistics pooling, dense + Lambda-masked attention -- timed once after a
+            # short warm-up prompt that sizes scratch
+            r.prefill(seq_len=2048)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r.prefill(seq_len=context)
+            torch.cuda.synchronize()
+            out[fmt]["context_stage_s"] = round(time.perf_counter() - t0, 2)
+            out[fmt]["context_stage_tokens_per_s"] = round(context / (time.perf_counter() - t0), 0)
         del r
         torch.cuda.empty_cache()
     L, Hq, Hk, D = context, cfg.heads, cfg.kv_heads, cfg.head_dim
@@ -277,7 +288,8 @@ def lserve_leg(device, context=256000, steps=32, warmup=8):
     k = torch.randn((L, Hk, D), dtype=torch.float16, device=device)
     v = torch.randn_like(k)
     cu = torch.tensor([0, L], dtype=torch.int32, device=device)
-    hm = torch.tensor([0, -1] * (Hq // 2), dtype=torch.int32, device=device)
+    g = Hq // Hk      # head classes are per KV head (ctx_attn_init.py:28-50): kv heads alternate dense / streaming
+    hm = torch.tensor(sum(([0] * g if kvh % 2 == 0 else [-1] * g for kvh in range(Hk)), []), dtype=torch.int32, device=device)
     si = torch.tensor([128, 8192] * Hq, dtype=torch.int32, device=device)
     ms = event_time_ms(lambda i: token_streaming_attn_func(q, k, v, cu, cu, hm, si, L, L), iters=2, warm=1)
     win = 128 + 8192

@@ -299,6 +299,10 @@ int omni_prefill_attention(void* out_f16, const void* q_f16, const void* k_f16, 
 /* Tuning / test hook: 0 = 16 query rows per wave (16x16x32 MFMA, default), 1 = 32 rows per wave (32x32x16 MFMA). */
 void omni_prefill_set_variant(int variant);
 
+/* Tuning hook: over how many XCDs the query tiles of one kv head are spread when streaming heads are present
+ * (head_mask_type != NULL): 1, 2, 4 or 8; 0 = the default (8).  Results do not depend on it. */
+void omni_prefill_set_xcd_split(int w);
+
 /* ----------------------------------------------------------------------------------------------
  * LServe dynamic sparsity: K statistics in the page tail and the page selector.
  * K page of a retrieval pool with H_r heads: int4 data | fp16 scale [H_r][tpb] | fp16 zero [H_r][tpb]

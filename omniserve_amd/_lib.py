@@ -54,6 +54,7 @@ PROTOTYPES = {
     "omni_kv4_prefill_write": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _i, _i, _vp]),
     "omni_kv4_decode_set_split_override": (None, [_i]),
     "omni_prefill_set_variant": (None, [_i]),
+    "omni_prefill_set_xcd_split": (None, [_i]),
     "omni_kv4_decode_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "omni_kv_min_max_pool": (_i, [_vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "omni_kv_page_selector": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp] + [_i] * 10 + [_vp, _i, _vp]),

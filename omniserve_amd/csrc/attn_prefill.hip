@@ -19,7 +19,7 @@
 // the second product O^T = V^T P^T, whose A operand (V transposed) is read from the V tile with
 // ds_read_b64_tr_b16.  Probabilities never leave registers; row statistics reduce over the 4 lanes that share a
 // query row.  Tiles that need no masking skip the per-element predicate (workgroup-uniform).  With q_tiles > 0 the
-// grid is 1-D and XCD-aware (all q heads of a kv head, and all their query tiles, on one XCD's L2).
+// grid is 1-D and XCD-aware (prefill_map_block: the q heads of a kv head share an XCD's L2; dense work balanced over XCDs).
 #include "common.h"
 
 namespace omni {
@@ -65,8 +65,47 @@ struct PrefillArgs {
   const int* streaming_info;                 // [2*Hq] (sink, local) or null
   int num_heads, num_kv_heads;
   int causal;
-  int q_tiles;                               // > 0: 1-D grid, XCD-aware order (see the kernel)
+  int q_tiles;                               // > 0: 1-D grid, XCD-aware order (prefill_map_block)
+  int xcd_split;                             // 1-D grid: XCDs that share the query tiles of one kv head (1, 2, 4 or 8)
 };
+
+// 1-D grid: workgroups are dealt round-robin to the 8 XCDs (private L2s; the dispatch is static: workgroup w runs on XCD
+// w % 8 whatever the others are doing).  All q heads of a kv head share an XCD's L2, so a K/V tile is fetched from the
+// fabric once per XCD that works on the head; the query tiles of a kv head are spread over W = xcd_split XCDs (tile t of
+// part t % W) so that every XCD gets the same amount of DENSE work when some kv heads are streaming heads (LServe: a dense
+// head costs O(L^2), a streaming head O(L * window); with whole kv heads pinned to XCDs the XCDs that drew streaming heads
+// idle for most of the launch).  kv heads are taken dense-first: sorted position pos, part j -> XCD (pos * W + j) % 8.
+// Returns false for the padding workgroups of a part that has fewer tiles.
+__device__ __forceinline__ bool prefill_map_block(const PrefillArgs& p, int& b, int& h, int& qt) {
+  const int W = p.xcd_split, Hk = p.num_kv_heads, G = p.num_heads / Hk;
+  const int P = (Hk * W) >> 3;                       // (kv head, part) pairs per XCD
+  const int R = (p.q_tiles + W - 1) / W;             // tile rows of a part
+  const int wid = blockIdx.x, xcd = wid & 7;
+  int slot = wid >> 3;
+  const int u = slot % G; slot /= G;
+  const int i = slot % P; slot /= P;
+  const int r = slot % R;
+  b = slot / R;
+  const int idx = xcd + 8 * i, pos = idx / W, j = idx - pos * W;
+  qt = p.q_tiles - 1 - (r * W + j);                  // long (late) query tiles first
+  int kvh = pos;
+  if (p.head_mask_type != nullptr) {                 // pos-th kv head in dense-first order (Hk scalar loads, once)
+    int nd = 0;
+    for (int t = 0; t < Hk; ++t) nd += p.head_mask_type[t * G] >= 0;
+    const bool want_dense = pos < nd;
+    int left = want_dense ? pos : pos - nd;
+    kvh = 0;
+    for (int t = 0; t < Hk; ++t) {
+      const bool dense = p.head_mask_type[t * G] >= 0;
+      if (dense == want_dense) {
+        if (left == 0) { kvh = t; break; }
+        --left;
+      }
+    }
+  }
+  h = kvh * G + u;
+  return qt >= 0;
+}
 
 #ifndef OMNI_PREFILL_MIN_BLOCKS
 #define OMNI_PREFILL_MIN_BLOCKS 2
@@ -83,17 +122,7 @@ void prefill_attn_kernel(PrefillArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   int b = blockIdx.z, h = blockIdx.y, qt = gridDim.x - 1 - blockIdx.x;   // long (late) query tiles are scheduled first
-  if (p.q_tiles > 0) {
-    // 1-D grid: workgroups are dealt round-robin to the 8 XCDs (private L2s).  XCD x takes q heads
-    // [x*Hq/8, (x+1)*Hq/8): all q heads of a kv head -- and every query tile of them -- share one L2, so a
-    // K/V tile is fetched from the fabric once per XCD instead of once per XCD that happens to host a sharer.
-    const int hpx = p.num_heads >> 3;
-    const int wid = blockIdx.x, xcd = wid & 7, slot = wid >> 3;
-    h = xcd * hpx + slot % hpx;
-    const int rest = slot / hpx;
-    qt = p.q_tiles - 1 - rest % p.q_tiles;
-    b = rest / p.q_tiles;
-  }
+  if (p.q_tiles > 0 && !prefill_map_block(p, b, h, qt)) return;
   const int hk = h / (p.num_heads / p.num_kv_heads);
   const int q_begin = p.cu_q[b], len_q = p.cu_q[b + 1] - q_begin;
   const int k_begin = p.cu_k[b], len_k = p.cu_k[b + 1] - k_begin;
@@ -359,14 +388,7 @@ void prefill_attn32_kernel(PrefillArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l32 = lane & 31, hi = lane >> 5, l15 = lane & 15, grp = lane >> 4;
   int b = blockIdx.z, h = blockIdx.y, qt = gridDim.x - 1 - blockIdx.x;
-  if (p.q_tiles > 0) {      // 1-D grid, XCD-aware order (see prefill_attn_kernel)
-    const int hpx = p.num_heads >> 3;
-    const int wid = blockIdx.x, xcd = wid & 7, slot = wid >> 3;
-    h = xcd * hpx + slot % hpx;
-    const int rest = slot / hpx;
-    qt = p.q_tiles - 1 - rest % p.q_tiles;
-    b = rest / p.q_tiles;
-  }
+  if (p.q_tiles > 0 && !prefill_map_block(p, b, h, qt)) return;
   const int hk = h / (p.num_heads / p.num_kv_heads);
   const int q_begin = p.cu_q[b], len_q = p.cu_q[b + 1] - q_begin;
   const int k_begin = p.cu_k[b], len_k = p.cu_k[b + 1] - k_begin;
@@ -583,6 +605,12 @@ using namespace omni;
 static int g_prefill_variant = OMNI_PREFILL_MFMA32;
 // Tuning / test hook: 0 = the 16-row form (default), 1 = the 32-row form.  Same results within the attention tolerance.
 extern "C" void omni_prefill_set_variant(int variant) { g_prefill_variant = variant == 1 ? 1 : 0; }
+#ifndef OMNI_PREFILL_XCD_SPLIT_MASKED
+#define OMNI_PREFILL_XCD_SPLIT_MASKED 8
+#endif
+static int g_prefill_xcd_split = 0;
+// Tuning hook: XCDs that share one kv head's query tiles when streaming heads are present (0 = default, else 1 / 2 / 4 / 8).
+extern "C" void omni_prefill_set_xcd_split(int w) { g_prefill_xcd_split = (w == 1 || w == 2 || w == 4 || w == 8) ? w : 0; }
 
 extern "C" int omni_prefill_attention(void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16,
                                       int64_t q_stride, int64_t k_stride, int64_t v_stride,
@@ -606,9 +634,20 @@ extern "C" int omni_prefill_attention(void* out_f16, const void* q_f16, const vo
   const int q_tiles = (max_seqlen_q + rows_per_wg - 1) / rows_per_wg;
   dim3 grid(q_tiles, num_heads, batch);
   a.q_tiles = 0;
-  if (num_heads % 8 == 0 && (long long)q_tiles * num_heads * batch < (1LL << 31)) {
-    a.q_tiles = q_tiles;
-    grid = dim3((unsigned)((long long)q_tiles * num_heads * batch), 1, 1);
+  a.xcd_split = 1;
+  {
+    // W: with streaming heads present the dense work has to be spread (see prefill_map_block): measured at 128 K tokens,
+    // 4 dense + 4 streaming kv heads, W = 1 / 2 / 4 / 8: 143 / 92 / 92 / 87 ms (122 ms with whole kv heads pinned in index
+    // order); all-dense launches keep whole kv heads on one XCD (145 vs 152 ms).  (Hk * W) must be a multiple of 8.
+    int W = head_mask_type_i32 ? (g_prefill_xcd_split > 0 ? g_prefill_xcd_split : OMNI_PREFILL_XCD_SPLIT_MASKED) : 1;
+    while ((num_kv_heads * W) % 8 != 0) W *= 2;
+    const long long rows = (q_tiles + W - 1) / W;
+    const long long wgs = 8LL * batch * rows * ((num_kv_heads * W) / 8) * (num_heads / num_kv_heads);
+    if (W <= 8 && wgs < (1LL << 31)) {
+      a.q_tiles = q_tiles;
+      a.xcd_split = W;
+      grid = dim3((unsigned)wgs, 1, 1);
+    }
   }
   if (form32) hipLaunchKernelGGL(prefill_attn32_kernel, grid, dim3(64 * P32W), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(prefill_attn_kernel, grid, dim3(64 * PWAVES), 0, (hipStream_t)stream, a);

@@ -20,8 +20,10 @@ from __future__ import annotations
 
 import torch
 
-from .backend import (activation_ops, fused_attention_fine_grained_sparse, fused_attention_per_tensor_sparse,
-                      fused_attention_selector, fused_ext, fused_kernels, layernorm_ops, qgemm_w8a8)
+from .backend import (activation_ops, fused_attention_ctx_pool, fused_attention_fine_grained_dense,
+                      fused_attention_fine_grained_sparse, fused_attention_per_tensor_dense,
+                      fused_attention_per_tensor_sparse, fused_attention_selector, fused_ext, fused_kernels, layernorm_ops,
+                      prefill_attn, qgemm_w8a8)
 from .rope import rope_table
 from .runtime import LlamaConfig
 
@@ -58,7 +60,7 @@ class LServeDecodeRunner:
 
     def __init__(self, cfg: LlamaConfig, batch: int, context: int, max_new: int, device, seed=0, kv_format="kv8",
                  streaming_ratio=0.5, sink=128, local=256, budget_tokens=4096, selector_interval=4,
-                 sub_chunk_per_block=4, use_graph=True, fused=True, prefetch_mb=None):
+                 sub_chunk_per_block=4, use_graph=True, fused=True, prefetch_mb=None, ctx_sink=128, ctx_local=8192):
         """fused: use the opt-in fused entry points (residual add + norm + quant, silu*mul + quant) -- bit-identical to the
         reference call sequence, three launches fewer per layer."""
         c = cfg
@@ -79,6 +81,7 @@ class LServeDecodeRunner:
         self.tpb = 64
         self.sub = self.tpb // sub_chunk_per_block            # tokens per sub-chunk
         self.interval = int(selector_interval)
+        self.budget_tokens = int(budget_tokens)
         self.budget_pages = min(max(3, budget_tokens // self.tpb), context // self.tpb + 1)   # <= pages of the history
         ns = int(round(Hk * streaming_ratio))
         nr = Hk - ns
@@ -91,6 +94,11 @@ class LServeDecodeRunner:
         self.flags = torch.tensor(flags, dtype=torch.int32, device=device)
         self.rank = torch.tensor(rank, dtype=torch.int32, device=device)
         self.sink, self.local = sink, local
+        # context stage (ctx_attn_init.py:28-50): 0 = dense causal head, -1 = sink + local tokens only
+        g = Hq // Hk
+        self.head_mask_type = torch.tensor([0 if flags[h // g] else -1 for h in range(Hq)], dtype=torch.int32, device=device)
+        self.streaming_info = torch.tensor([ctx_sink, ctx_local] * Hq, dtype=torch.int32, device=device)
+        self.pooling_heads_idx = torch.tensor([h for h in range(Hk) if flags[h]], dtype=torch.int32, device=device)
         self.sink_blocks = (sink + self.tpb - 1) // self.tpb
         self.local_blocks = local // self.tpb + 1              # attn_config.py:63-64
         self.row = d if self.kv8 else d // 2                   # bytes of one token row of one head
@@ -273,6 +281,92 @@ class LServeDecodeRunner:
         layernorm_ops.rms_norm(self.normed, self.x, self.final_norm, c.eps, False)
         logits = torch.matmul(self.normed, self.lm_head.t())
         fused_ext.argmax(self.tokens, logits)
+
+    # ---- context stage ------------------------------------------------------------------------------------------------
+    def prefill(self, tokens=None, hidden=None, seq_len=None, chunk=16384):
+        """The reference's context stage (llama_w8a8_unpad.py:253-313,382-427) over `batch` prompts of `seq_len` tokens each
+        (default: the `context` the runner was built for; model_runner.py:262-360 builds the same metadata): per layer
+        norm + quant -> qkv W8A8 GEMM -> RoPE in place + cache write (every token of a retrieval head, sink + local ring of a
+        streaming head) -> min/max statistics of the retrieval heads' keys -> varlen causal attention with the Lambda mask
+        on streaming heads -> quant -> o_proj -> residual -> norm + quant -> gate_up / SiLU*mul + quant / down in chunks of
+        `chunk` tokens (model_config.chunk_prefill_size) -> residual.  The synthetic page contents are overwritten; the
+        decode state (lengths, next tokens from the last position's logits) is set so that step() continues the sequences.
+        Input: `tokens` int64 [batch*seq_len] (embedding lookup) or `hidden` fp16 [batch*seq_len, hidden].
+        Returns the final hidden states [batch*seq_len, hidden]."""
+        c, B, dev = self.cfg, self.B, self.device
+        Hq, Hk, d = c.heads, c.kv_heads, c.head_dim
+        Lp = int(seq_len) if seq_len is not None else self.context0
+        if Lp < 1 or Lp + 1 > self.max_context:
+            raise ValueError("seq_len %d does not fit the pools (max_context %d)" % (Lp, self.max_context))
+        T = B * Lp
+        f16, i8 = torch.float16, torch.int8
+        if hidden is not None:
+            x = hidden.to(dev, f16).clone()
+        else:
+            if tokens is None:
+                g = torch.Generator(device=dev)
+                g.manual_seed(1234)
+                tokens = torch.randint(0, c.vocab, (T,), device=dev, generator=g)
+            x = torch.index_select(self.embed, 0, tokens.to(dev))
+        if tuple(x.shape) != (T, c.hidden):
+            raise ValueError("prefill input must cover batch * seq_len = %d tokens" % T)
+        cu = torch.arange(0, B + 1, dtype=torch.int32, device=dev) * Lp
+        lens = torch.full((B,), Lp, dtype=torch.int32, device=dev)
+        slens = torch.full((B,), min(Lp, self.sink + self.local), dtype=torch.int32, device=dev)
+        pad = fused_attention_fine_grained_dense.compute_padding_offsets(cu, Lp, T)
+        q_hidden = torch.empty((T, c.hidden), dtype=i8, device=dev)
+        q_attn = torch.empty((T, Hq * d), dtype=i8, device=dev)
+        scale = torch.empty((T,), dtype=f16, device=dev)
+        qkv = torch.empty((T, (Hq + 2 * Hk) * d), dtype=f16, device=dev)
+        proj = torch.empty((T, c.hidden), dtype=f16, device=dev)
+        ch = min(int(chunk), T)
+        gate_up = torch.empty((ch, 2 * c.inter), dtype=f16, device=dev)
+        mlp_act = torch.empty((ch, c.inter), dtype=f16, device=dev)
+        q_inter = torch.empty((ch, c.inter), dtype=i8, device=dev)
+        size_r, size_s = self.nr * self.row, self.ns * self.row
+        for li, L in enumerate(self.layers):
+            layernorm_ops.rms_norm_general(q_hidden, x, L["ln1"], scale, c.eps, True)
+            L["qkv"].forward(q_hidden, scale, qkv)
+            tail = (self.retr_tables[li], self.strm_tables[li], self.flags, self.rank, Hq, Hk, Lp, self.tpb, size_r, size_s,
+                    self.sink, self.local, self.sink_blocks, self.local_blocks, self.nr, self.ns, d, c.rope_theta, 1.0,
+                    self.max_context + 1, True, not self.kv8, not self.kv8)
+            if self.kv8:
+                fused_attention_per_tensor_dense.apply_bias_rope_update_kv_cache(qkv, self.kv_oq, lens, slens, pad, *tail)
+            else:
+                fused_attention_fine_grained_dense.apply_bias_rope_update_kv_cache(qkv, lens, slens, pad, *tail)
+            q = qkv[:, : Hq * d].view(T, Hq, d)
+            k = qkv[:, Hq * d:(Hq + Hk) * d].view(T, Hk, d)
+            v = qkv[:, (Hq + Hk) * d:].view(T, Hk, d)
+            if self.nr > 0:       # sparse decode mode: the page selector's statistics (llama_w8a8_unpad.py:290-294)
+                fused_attention_ctx_pool.paged_min_max_pool(k.contiguous(), self.retr_tables[li], cu, self.pooling_heads_idx,
+                                                            Lp, self.sub, self.tpb, size_r, True)
+            if self.ns > 0:
+                out = prefill_attn.token_streaming_attn_func(q, k, v, cu, cu, self.head_mask_type, self.streaming_info, Lp, Lp)
+            else:
+                out = prefill_attn.flash_attn_varlen_func(q, k, v, cu, cu, Lp, Lp, dropout_p=0.0, causal=True)
+            fused_kernels.invoke_quant(q_attn, out.view(T, Hq * d), scale)
+            L["o"].forward(q_attn, scale, proj)
+            x.add_(proj)
+            layernorm_ops.rms_norm_general(q_hidden, x, L["ln2"], scale, c.eps, True)
+            for s0 in range(0, T, ch):
+                n = min(ch, T - s0)
+                L["gate_up"].forward(q_hidden[s0:s0 + n], scale[s0:s0 + n], gate_up[:n])
+                activation_ops.silu_and_mul(mlp_act[:n], gate_up[:n])
+                fused_kernels.invoke_quant(q_inter[:n], mlp_act[:n], scale[:n])
+                L["down"].forward(q_inter[:n], scale[:n], proj[s0:s0 + n])
+            x.add_(proj)
+        # decode state: the sequences now hold Lp tokens; the next token comes from the last position of each prompt
+        self.context0, self.steps_done = Lp, 0
+        self.lengths.fill_(Lp)
+        self.graphs.clear()
+        npick = min(max(3, self.budget_tokens // self.tpb), Lp // self.tpb + 1)
+        if npick != self.budget_pages:
+            self.budget_pages = npick
+            self.page_idx = [torch.zeros((B, Hq, npick), dtype=torch.int32, device=dev) for _ in self.layers]
+        last = x[Lp - 1::Lp].contiguous()
+        layernorm_ops.rms_norm(self.normed, last, self.final_norm, c.eps, False)
+        fused_ext.argmax(self.tokens, torch.matmul(self.normed, self.lm_head.t()))
+        return x
 
     def step(self):
         """Decode one token.  Two HIP graphs (with / without page selection) per history length bucket: the page

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_prefill_attn_gpu.py tests/test_reference_lserve_layer_golden_gpu.py -q > gpurun_out/attn_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/attn_tests.log
+tail -5 gpurun_out/attn_tests.log
+timeout 600 python tools/lserve_prefill.py kv8 65536 256000 > gpurun_out/lserve_prefill.log 2>&1; echo "rc=$?" >> gpurun_out/lserve_prefill.log
+tail -5 gpurun_out/lserve_prefill.log
