@@ -88,12 +88,22 @@ __device__ __forceinline__ half_t epilogue(int acc, float sw, float sa, float sz
 #ifndef OMNI_GEMM_GRP_STEADY
 #define OMNI_GEMM_GRP_STEADY 1
 #endif
+#ifndef OMNI_GEMM_W8_COALESCED
+#define OMNI_GEMM_W8_COALESCED 1     // W8A8 prefill tile: row-coalesced weight loads + lane transpose through LDS (see the kernel)
+#endif
 template <int MB, int MODE, int WAVES, bool TO_SLAB, bool NT>
 __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
   constexpr int NTHREADS = 64 * WAVES;
   constexpr int A_LOADS = (MT * KCHUNK / 16 + NTHREADS - 1) / NTHREADS;  // 16-B pieces per thread
   __shared__ __attribute__((aligned(16))) uint8_t lds[2][MT * KCHUNK];
+  // W8A8: the int8 weight rows are plain [N][K].  With the MFMA operand's own lane map (row = lane & 15, 16-B piece =
+  // lane >> 4) a wave instruction touches 16 rows with every lane quad spanning four of them, and the L1 pulls 15 B/clk per
+  // CU out of L2 (tools/l1_pattern_probe.hip) where this tile needs 32.  Row-coalesced (row = lane >> 2, piece = lane & 3:
+  // a quad reads 64 consecutive bytes) the same loads run at 38 B/clk; the fragment is then turned into the operand map by
+  // one ds_write_b128 + ds_read_b128 through a wave-private KiB (conflict-free both ways: slot = piece * 16 + (row ^ 4 piece)).
+  constexpr bool W8C = MODE == MODE_W8 && OMNI_GEMM_W8_COALESCED;
+  __shared__ __attribute__((aligned(16))) uint8_t wtr[W8C ? WAVES * 1024 : 16];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -126,11 +136,15 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   // W4: lane -> (x = tile row, c = n3, e = k6); W8: lane -> (i = row in 16-block, g = k piece)
   const int lx = (lane >> 3) & 1, lc = lane & 7, le = lane >> 4;
   const uint8_t* wbase;
-  if constexpr (MODE == MODE_W8) {
+  if constexpr (W8C) {
+    wbase = p.W + (size_t)(ngc * 64 + (lane >> 2)) * p.K + (lane & 3) * 16;
+  } else if constexpr (MODE == MODE_W8) {
     wbase = p.W + (size_t)(ngc * 64 + (lane & 15)) * p.K + (lane >> 4) * 16;
   } else {
     wbase = p.W + ((size_t)(2 * ngc + lx) * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
   }
+  uint8_t* const wtr_w = wtr + (W8C ? wave * 1024 + ((lane & 3) * 16 + ((lane >> 2) ^ (4 * (lane & 3)))) * 16 : 0);
+  const uint8_t* const wtr_r = wtr + (W8C ? wave * 1024 + ((lane & 48) + ((lane & 15) ^ (4 * (lane >> 4)))) * 16 : 0);
   auto load_w = [&](int k, int j) -> uint4 {
     // W4: j = tile parity inside the 64-k step.  W8: j = 16-row block (0..3).
     const uint8_t* ptr;
@@ -274,7 +288,16 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
     for (int s = 0; s < STEPS; ++s) {
       if (STEADY || s < steps_here) {
         v4i wa[4];
-        if constexpr (MODE == MODE_W8) {
+        if constexpr (W8C) {
+          // (issuing the transpose of step s + 1 behind the MFMAs of step s instead was 5-9 % slower: 16 more live
+          // registers spill, and the fragment then has to be back from L2 one step earlier)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) {      // LDS is in order within a wave: no wait between the write and the read
+            *reinterpret_cast<uint4*>(wtr_w) = make_uint4(wq[s % WRING][rb].x, wq[s % WRING][rb].y, wq[s % WRING][rb].z,
+                                                          wq[s % WRING][rb].w);
+            wa[rb] = *reinterpret_cast<const v4i*>(wtr_r);
+          }
+        } else if constexpr (MODE == MODE_W8) {
 #pragma unroll
           for (int rb = 0; rb < 4; ++rb)
             wa[rb] = (v4i){(int)wq[s % WRING][rb].x, (int)wq[s % WRING][rb].y, (int)wq[s % WRING][rb].z,
@@ -502,6 +525,8 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
   // inactive waves (N/64 not a multiple of WAVES) stream the last valid group again and drop it
   const int ngc = wave_active ? ng : (p.N / 64 - 1);
   const uint8_t* wbase;
+  // (W8A8: the operand lane map is kept here -- the row-coalesced fetch + LDS transpose of w4a8_gemm_kernel measured no
+  //  gain at M = 1: this kernel waits on HBM latency, not on the L1's 15 B/clk)
   if constexpr (MODE == MODE_W8) wbase = p.W + (size_t)(ngc * 64 + (lane & 15)) * p.K + (lane >> 4) * 16;
   else wbase = p.W + ((size_t)(2 * ngc + lx) * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
   auto load_w = [&](int k, int j) -> uint4 {

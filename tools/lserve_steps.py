@@ -6,6 +6,10 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omniserve_amd import _lib  # noqa: E402
+
+if os.environ.get("OMNI_TUNE_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["OMNI_TUNE_LIB"])
 from omniserve_amd.lserve_runtime import LServeDecodeRunner  # noqa: E402
 from omniserve_amd.runtime import LlamaConfig  # noqa: E402
 
@@ -18,7 +22,7 @@ for _ in range(8):
 torch.cuda.synchronize()
 per = {True: [], False: []}
 for _ in range(steps):
-    sel = r.steps_done % r.interval == 0
+    sel = r.steps_done == 0 or (r.context0 + r.steps_done + 1) % r.interval == 0     # the runner's refresh rule
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     r.step()
