@@ -29,7 +29,14 @@ __global__ __launch_bounds__(256) void probe(const uint8_t* W, int* out, int row
         if (MAP == 0) off = wave_base + (size_t)(k / 64) * 4096 + j * 1024 + lane * 16;
         else if (MAP == 1) off = wave_base + (size_t)(j * 16 + (lane & 15)) * PITCH + k + (lane >> 4) * 16;
         else if (MAP == 2) off = wave_base + (size_t)(j * 16 + (lane >> 2)) * PITCH + k + (lane & 3) * 16;
-        else off = wave_base + (size_t)((j >> 1) * 32 + (k / 64 % 2) * 0 + (j & 1) * 8 + (lane >> 3) + ((j & 1) ? 0 : 0) + 16 * 0) * PITCH + (k & ~127) + (lane & 7) * 16 + 0 * j;
+        else if (MAP == 3) {   // the packed W4 tile map of the GEMV / GEMM kernels: two 512-B tiles (32 KiB apart) per instruction,
+                               // lane l -> tile (l >> 3) & 1, 16-B slot (l & 7) * 4 + (l >> 4) of the tile
+          off = wave_base + (size_t)(k / 64) * 4096 + (j >> 1) * 2048 + (j & 1) * 1024 * 0 + ((lane >> 3) & 1) * 131072 +
+                (size_t)(j & 1) * 512 + (((lane & 7) * 4 + (lane >> 4)) * 16);
+        } else {               // the same two tiles, lane-linear inside each tile (what a transposed packing would allow)
+          off = wave_base + (size_t)(k / 64) * 4096 + (j >> 1) * 2048 + ((lane >> 5) & 1) * 131072 + (size_t)(j & 1) * 512 +
+                (lane & 31) * 16;
+        }
         v[j] = *reinterpret_cast<const v4i*>(W + off);
       }
 #pragma unroll
@@ -59,10 +66,12 @@ static void run(const uint8_t* W, int* out, int rows, const char* name) {
 int main() {
   const int rows = 512 * 4 * 64 / 8;     // 64 MiB: the 8 iterations re-read it (L2 + MALL resident after the first pass)
   uint8_t* W; int* out;
-  hipMalloc(&W, (size_t)rows * PITCH); hipMalloc(&out, 4096);
+  hipMalloc(&W, (size_t)rows * PITCH + (1 << 20)); hipMalloc(&out, 4096);   // + slack: maps 3 / 4 reach 128 KiB past a wave's rows
   hipMemset(W, 1, (size_t)rows * PITCH);
   run<0>(W, out, rows, "contiguous 1 KiB per instruction");
   run<1>(W, out, rows, "MFMA map (row = lane & 15)");
   run<2>(W, out, rows, "row-coalesced (row = lane >> 2)");
+  run<3>(W, out, rows, "packed W4 tile map (2 x 512 B)");
+  run<4>(W, out, rows, "2 x 512 B, lane-linear");
   return 0;
 }
