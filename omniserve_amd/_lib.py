@@ -105,7 +105,15 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError("%s failed: %s (%d)" % (what, _ERR.get(rc, "error"), rc))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream() -> int:
+    """Raw hipStream_t of PyTorch's current stream on the current device (the private fast accessor when this torch has
+    it: the public `torch.cuda.current_stream().cuda_stream` builds a Stream object per call, ~1.5 us on a path that runs
+    ten times per decoder layer)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -124,7 +132,7 @@ def workspace(nbytes: int, device, tag: str = "gemm") -> torch.Tensor:
     (Pre-size it before HIP-graph capture: growing allocates.)  A superseded buffer is never released: a HIP graph
     captured earlier has its address baked in and keeps using it (geometric growth bounds the total at twice the
     final size)."""
-    key = (str(device), tag)
+    key = (device, tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         size = max(int(nbytes), 1 << 20)

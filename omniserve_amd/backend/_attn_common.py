@@ -63,29 +63,38 @@ def prefill_write(qkv, seq_lens, padding_offset, kv_pointers, head_num, kv_head_
     _lib.check(rc, what)
 
 
+_dense_ws_bytes = {}      # (B, Hq, D, context rounded up to 1024) -> omni_kv4_decode_workspace_bytes (monotone in the context)
+
+
 def decode_attention(q, k, v, kv_pointers, lengths, tokens_per_block, size_per_token, timestep,
                      rotary_embedding_dim, rotary_base, neox, int4, zeros, what):
+    # (runs once per decoder layer of every eager decode step: attributes are read once, the scratch size is cached)
     _lib.require_cuda(q, k, v, kv_pointers, lengths)
     B, Hq, D = q.shape
     Hkv = k.shape[1]
     _check_cfg(rotary_embedding_dim, neox, int4, zeros, D)
     if size_per_token != Hkv * D // 2:
         raise RuntimeError("%s: size_per_token %d != Hkv*Dh/2" % (what, size_per_token))
-    if q.dtype != torch.float16 or q.stride(2) != 1 or q.stride(1) != D:
+    qs, ks, vs = q.stride(), k.stride(), v.stride()
+    if q.dtype is not torch.float16 or qs[2] != 1 or qs[1] != D:
         raise RuntimeError("%s: q must be fp16 [B,H,D] with contiguous heads" % what)
-    if k.stride(2) != 1 or k.stride(1) != D or v.stride(2) != 1 or v.stride(1) != D:
+    if ks[2] != 1 or ks[1] != D or vs[2] != 1 or vs[1] != D:
         raise RuntimeError("%s: k/v heads must be contiguous" % what)      # TORCH_CHECK in the reference
-    if k.stride(0) != v.stride(0):
+    if ks[0] != vs[0]:
         raise RuntimeError("%s: k and v must share the row stride" % what)
-    if lengths.dtype != torch.int32 or not kv_pointers.is_contiguous():
+    if lengths.dtype is not torch.int32 or not kv_pointers.is_contiguous():
         raise RuntimeError("%s: lengths must be int32, kv_pointers contiguous" % what)
     max_ctx = max(int(timestep), 1)
-    table = rope_table(max_ctx + 1, D, float(rotary_base), 1.0, q.device)
-    need = _lib.lib().omni_kv4_decode_workspace_bytes(B, Hq, D, max_ctx)
-    ws = _lib.workspace(need, q.device, "attn")
-    out = torch.empty((B, Hq, D), dtype=q.dtype, device=q.device)
+    device = q.device
+    table = rope_table(max_ctx + 1, D, float(rotary_base), 1.0, device)
+    key = (B, Hq, D, (max_ctx + 1023) >> 10)
+    need = _dense_ws_bytes.get(key)
+    if need is None:
+        need = _dense_ws_bytes[key] = int(_lib.lib().omni_kv4_decode_workspace_bytes(B, Hq, D, key[3] << 10))
+    ws = _lib.workspace(need, device, "attn")
+    out = torch.empty((B, Hq, D), dtype=torch.float16, device=device)
     rc = _lib.lib().omni_kv4_decode_attention(
-        out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0),
+        out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), qs[0], ks[0],
         kv_pointers.data_ptr(), lengths.data_ptr(), B, kv_pointers.shape[-1], Hq, Hkv, D,
         int(tokens_per_block), max_ctx, table.data_ptr(), table.shape[0], ws.data_ptr(), ws.numel(),
         _lib.current_stream())

@@ -28,9 +28,10 @@ def build_table_numpy(max_pos: int, dim: int, base: float, scale: float = 1.0) -
 
 def rope_table(max_pos: int, dim: int, base: float, scale: float, device) -> torch.Tensor:
     """Cached device table with at least `max_pos` rows (rounded up to a power of two >= 4096)."""
-    key = (str(device), int(dim), float(base), float(scale))
+    key = (device, dim, base, scale)
     t = _cache.get(key)
     if t is None or t.shape[0] < max_pos:
+        dim, base, scale = int(dim), float(base), float(scale)
         rows = 4096
         while rows < max_pos:
             rows *= 2

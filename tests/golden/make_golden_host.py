@@ -57,6 +57,7 @@ def gen_page_choice():
     import omniserve.modeling.layers.decoding_attention as da
     cases = []
     rng = np.random.default_rng(2024)
+    real_selector = da.fused_attention_selector      # replaced by canned scores below, restored at the end
     for (B, Hq, tpb, sub, budget, timestep, ties) in [
         (2, 4, 64, 16, 256, 700, False),       # 11 pages, budget 4 pages
         (1, 8, 64, 16, 4096, 20000, False),    # 313 pages, budget 64 pages (configs[3] parameters)
@@ -85,6 +86,7 @@ def gen_page_choice():
         cases.append(dict(B=B, Hq=Hq, tokens_per_block=tpb, sub_chunk=sub, budget=budget, timestep=timestep, ties=ties,
                           stats=vals.astype(np.float32).reshape(-1).tolist(), selected=sel.numpy().tolist(),
                           selected_dtype=str(sel.dtype)))
+    da.fused_attention_selector = real_selector
     return cases
 
 
