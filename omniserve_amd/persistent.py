@@ -2,7 +2,7 @@
 
 Upstream allocates a fresh `ActivationBuffer` inside every `InputMetadata` (omniserve/utils/input_metadata.py:199-200:
 five `torch.empty` per engine step) and launches ~11 kernels per layer eagerly; on an MI355X the decode step is then
-host-launch bound (bench.py `drop_in`: 3.7-4.1 ms against 2.4 ms captured).  Two small, independent helpers:
+host-launch bound (bench.py `drop_in`: 2.9 ms against 2.4 ms captured).  Two small, independent helpers:
 
 * `PersistentActivationBuffer` -- allocated once for the largest step; `view_for(batched_seq_len)` hands out an object
   with exactly the attributes the reference's layers read from `input_metadata.activation_buffer`
