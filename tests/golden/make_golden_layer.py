@@ -1,10 +1,12 @@
 """Golden vectors of one QServe decoder layer produced by the REFERENCE's own model code.
 
     python tests/golden/make_golden_layer.py            # needs /root/reference (build container); writes
-                                                        # tests/golden/decoder_layer_w4a8kv4.npz
+                                                        # tests/golden/decoder_layer_w4a8kv4.npz (per channel) and
+                                                        # tests/golden/decoder_layer_w4a8kv4_g128.npz (BASELINE configs[2])
 
 `omniserve/modeling/models/llama_w4a8_unpad.py::LlamaDecoderLayer` (unmodified, imported from /root/reference) is
-instantiated with per-channel W4A8 weights produced by the reference's own packer (`from_linear`) and driven exactly as
+instantiated with per-channel (group_size -1) or per-group (128: two-level QoQ weights, norms and quantisers without the
+activation sum, llama_w4a8_unpad.py:81,212-215,395-401) W4A8 weights produced by the reference's own packer (`from_linear`) and driven exactly as
 the engine drives it -- one context-stage call over two 70-token prompts, then two generation-stage calls -- with its
 `omniserve_backend.*` calls landing on the oracle-backed C-ABI of tests/refstack.py (CPU).  What is recorded: the layer's
 packed weights, its inputs, its hidden-state outputs and the KV4 pages it leaves behind (per sequence, in logical page
@@ -33,6 +35,10 @@ B, L, DEC_STEPS, PAGES = 2, 70, 2, 2
 OUT = os.path.join(HERE, "decoder_layer_w4a8kv4.npz")
 
 
+def out_path(group_size):
+    return OUT if group_size == -1 else os.path.join(HERE, "decoder_layer_w4a8kv4_g%d.npz" % group_size)
+
+
 def _sp_attn_config():
     ns = types.SimpleNamespace()
     ns.sparse_kv_cache_enabled = lambda: False
@@ -43,7 +49,7 @@ def _sp_attn_config():
     return ns
 
 
-def generate():
+def generate(group_size=-1):
     from omniserve_amd import ckpt
     from oracle import kv4
     with refstack.reference_over_mirror():
@@ -57,16 +63,16 @@ def generate():
         model_config = types.SimpleNamespace(sp_attn_config=_sp_attn_config(), kv_quant_granularity="fine_grained",
                                              multiblock_switch=2048, chunk_prefill_size=1 << 20)
         kvcfg = {"INT4_ENABLED": True, "ZEROS_ENABLED": True}
-        layer = LlamaDecoderLayer(cfg, model_config, -1, 0, kvcfg)
+        layer = LlamaDecoderLayer(cfg, model_config, group_size, 0, kvcfg)
         weights = {}
 
         def fill(dst, n, k, name, scale):
             w = torch.randn((n, k), generator=g) * scale
-            fake, s1, s2, z = ckpt.qoq_quantize_weight(w, -1)
+            fake, s1, s2, z = ckpt.qoq_quantize_weight(w, group_size)
             lin = torch.nn.Linear(k, n, bias=False)
             lin.weight.data = fake.clone()
-            src = RefLinear.from_linear(lin, 4, -1, s1_scale=s1.float(), s2_scale=s2, zeros=z)     # the reference's packer
-            for b in ("qweight", "s1_scales", "s1_szeros"):
+            src = RefLinear.from_linear(lin, 4, group_size, s1_scale=s1.float(), s2_scale=s2, zeros=z)     # the reference's packer
+            for b in (("qweight", "s1_scales", "s1_szeros") if group_size == -1 else ("qweight", "s1_scales", "s2_scales", "s2_zeros")):
                 getattr(dst, b).data = getattr(src, b).data.clone()
                 weights["%s.%s" % (name, b)] = getattr(src, b).data.numpy().copy()
 
@@ -137,10 +143,12 @@ def generate():
             out["decode%d_k_pages" % s], out["decode%d_v_pages" % s] = pages()
         out["shape"] = np.asarray([HIDDEN, INTER, HQ, HK, D, TPB, B, L, DEC_STEPS, PAGES], np.int64)
         out["rope_base_eps"] = np.asarray([ROPE_BASE, EPS], np.float64)
+        out["group_size"] = np.asarray([group_size], np.int64)
         return out
 
 
 if __name__ == "__main__":
-    vec = generate()
-    np.savez_compressed(OUT, **vec)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes;", ", ".join(sorted(vec)))
+    for gs in (-1, 128):
+        vec = generate(gs)
+        np.savez_compressed(out_path(gs), **vec)
+        print("wrote", out_path(gs), os.path.getsize(out_path(gs)), "bytes;", ", ".join(sorted(vec)))

@@ -22,10 +22,11 @@ def test_fixture_is_complete(golden_dir):
 
 
 @pytest.mark.skipif(not refstack.reference_available(), reason="/root/reference is not on this machine")
-def test_fixture_matches_the_reference_layer_today(golden_dir):
+@pytest.mark.parametrize("group_size", [-1, 128])
+def test_fixture_matches_the_reference_layer_today(golden_dir, group_size):
     from tests.golden import make_golden_layer
-    fresh = make_golden_layer.generate()
-    z = np.load(os.path.join(golden_dir, "decoder_layer_w4a8kv4.npz"))
+    fresh = make_golden_layer.generate(group_size)
+    z = np.load(make_golden_layer.out_path(group_size))
     assert sorted(fresh) == sorted(z.files)
     for k in z.files:
         assert np.array_equal(np.asarray(fresh[k]).view(np.uint8), z[k].view(np.uint8)), k

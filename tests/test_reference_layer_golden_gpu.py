@@ -21,8 +21,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _load(golden_dir):
-    z = np.load(os.path.join(golden_dir, "decoder_layer_w4a8kv4.npz"))
+def _load(golden_dir, group_size):
+    name = "decoder_layer_w4a8kv4.npz" if group_size == -1 else "decoder_layer_w4a8kv4_g%d.npz" % group_size
+    z = np.load(os.path.join(golden_dir, name))
     return {k: z[k] for k in z.files}
 
 
@@ -45,20 +46,22 @@ def _close(got, want, what):
 
 
 @pytest.mark.parametrize("fused", [0, 1, 2])
-def test_runner_layer_matches_reference_layer_vectors(golden_dir, fused):
+@pytest.mark.parametrize("group_size", [-1, 128])      # per channel (configs[1]) and g128 (configs[2])
+def test_runner_layer_matches_reference_layer_vectors(golden_dir, group_size, fused):
     from omniserve_amd.runtime import DecodeRunner, LlamaConfig
-    v = _load(golden_dir)
+    v = _load(golden_dir, group_size)
+    assert int(v["group_size"][0]) == group_size
     hidden, inter, hq, hk, d, tpb, B, L, steps, pages = [int(t) for t in v["shape"]]
     base, eps = [float(t) for t in v["rope_base_eps"]]
     T = B * L
     dev = torch.device("cuda:0")
     cfg = LlamaConfig(hidden=hidden, inter=inter, heads=hq, kv_heads=hk, head_dim=d, layers=1, vocab=T + steps * B,
-                      rope_theta=base, eps=eps, group_size=-1)
+                      rope_theta=base, eps=eps, group_size=group_size)
     r = DecodeRunner(cfg, B, L, 8, dev, seed=1, use_graph=False, fused=fused)
     assert r.tpb == tpb
     Ly = r.layers[0]
     for name in ("qkv", "o", "gate_up", "down"):
-        for buf in ("qweight", "s1_scales", "s1_szeros"):
+        for buf in (("qweight", "s1_scales", "s1_szeros") if group_size == -1 else ("qweight", "s1_scales", "s2_scales", "s2_zeros")):
             dst = getattr(Ly[name], buf)
             src = torch.from_numpy(v["%s.%s" % (name, buf)])
             assert tuple(dst.shape) == tuple(src.shape), (name, buf)
