@@ -380,6 +380,14 @@ class LServeDecodeRunner:
             self._eager_step(hist, select)
             self.steps_done += 1
             return
+        if bucket + 1 < self.budget_pages:
+            # (cannot happen after __init__ / prefill() sized budget_pages; kept as a guard for hand-made states)
+            raise RuntimeError("page budget larger than the history's page count")
+        if hist + 1 <= self.budget_tokens and bucket + 1 > self.budget_pages:
+            # decoding_attention.py:99-100 attends EVERY page while the history fits the token budget; this driver keeps a
+            # fixed number of selected pages per head (the benchmark's regime: history >> budget)
+            raise NotImplementedError("history within the dynamic-sparse token budget and growing past the page count the "
+                                      "runner was sized for: re-run prefill() or build the runner for the longer context")
         key = (bucket, select)
         g = self.graphs.get(key)
         if g is None:
