@@ -321,11 +321,16 @@ class LServeDecodeRunner:
         proj = torch.empty((T, c.hidden), dtype=f16, device=dev)
         ch = min(int(chunk), T)
         gate_up = torch.empty((ch, 2 * c.inter), dtype=f16, device=dev)
-        mlp_act = torch.empty((ch, c.inter), dtype=f16, device=dev)
+        mlp_act = None if self.fused else torch.empty((ch, c.inter), dtype=f16, device=dev)
         q_inter = torch.empty((ch, c.inter), dtype=i8, device=dev)
         size_r, size_s = self.nr * self.row, self.ns * self.row
+        sums = torch.empty((T,), dtype=f16, device=dev) if self.fused else None    # by-product of the fused entry points
+        nl = len(self.layers)
         for li, L in enumerate(self.layers):
-            layernorm_ops.rms_norm_general(q_hidden, x, L["ln1"], scale, c.eps, True)
+            if self.fused and li > 0:      # residual += down_proj(previous layer), norm + quant: one pass over x
+                fused_ext.add_rms_norm_general_fuse_sum(q_hidden, x, proj, L["ln1"], sums, scale, c.eps)
+            else:
+                layernorm_ops.rms_norm_general(q_hidden, x, L["ln1"], scale, c.eps, True)
             L["qkv"].forward(q_hidden, scale, qkv)
             tail = (self.retr_tables[li], self.strm_tables[li], self.flags, self.rank, Hq, Hk, Lp, self.tpb, size_r, size_s,
                     self.sink, self.local, self.sink_blocks, self.local_blocks, self.nr, self.ns, d, c.rope_theta, 1.0,
@@ -346,15 +351,22 @@ class LServeDecodeRunner:
                 out = prefill_attn.flash_attn_varlen_func(q, k, v, cu, cu, Lp, Lp, dropout_p=0.0, causal=True)
             fused_kernels.invoke_quant(q_attn, out.view(T, Hq * d), scale)
             L["o"].forward(q_attn, scale, proj)
-            x.add_(proj)
-            layernorm_ops.rms_norm_general(q_hidden, x, L["ln2"], scale, c.eps, True)
+            if self.fused:
+                fused_ext.add_rms_norm_general_fuse_sum(q_hidden, x, proj, L["ln2"], sums, scale, c.eps)
+            else:
+                x.add_(proj)
+                layernorm_ops.rms_norm_general(q_hidden, x, L["ln2"], scale, c.eps, True)
             for s0 in range(0, T, ch):
                 n = min(ch, T - s0)
                 L["gate_up"].forward(q_hidden[s0:s0 + n], scale[s0:s0 + n], gate_up[:n])
-                activation_ops.silu_and_mul(mlp_act[:n], gate_up[:n])
-                fused_kernels.invoke_quant(q_inter[:n], mlp_act[:n], scale[:n])
+                if self.fused:             # SiLU*mul + quant without the fp16 round trip (bit-identical)
+                    fused_ext.silu_mul_quant_fuse_sum(q_inter[:n], gate_up[:n], sums[:n], scale[:n])
+                else:
+                    activation_ops.silu_and_mul(mlp_act[:n], gate_up[:n])
+                    fused_kernels.invoke_quant(q_inter[:n], mlp_act[:n], scale[:n])
                 L["down"].forward(q_inter[:n], scale[:n], proj[s0:s0 + n])
-            x.add_(proj)
+            if not self.fused or li == nl - 1:
+                x.add_(proj)
         # decode state: the sequences now hold Lp tokens; the next token comes from the last position of each prompt
         self.context0, self.steps_done = Lp, 0
         self.lengths.fill_(Lp)
