@@ -227,6 +227,11 @@ size_t omni_argmax_workspace_bytes(int rows);
 int omni_argmax_f16(void* out_i64, const void* logits_f16, int64_t row_stride, int rows, int cols, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* Embedding lookup of the decode drivers (torch.nn.Embedding upstream): out fp16 [rows, cols] = table[idx[r], :],
+ * idx int64 [rows] on the device; cols % 8 == 0; ids outside [0, table_rows) leave their row untouched. */
+int omni_gather_rows_f16(void* out_f16, const void* table_f16, const void* idx_i64, int rows, int cols,
+                         int64_t table_rows, void* stream);
+
 /* omni_silu_and_mul followed by omni_quant_fuse_sum without materialising the fp16 product
  * (activation.py:54-64 calls them back to back).  in fp16 [tokens, 2d] -> out int8 [tokens, d]. */
 int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f16, void* scale_f16,

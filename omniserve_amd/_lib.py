@@ -64,6 +64,7 @@ PROTOTYPES = {
     "omni_kv_decode_attention_fine_grained_partial": (_i, [_vp, _vp, _vp, _i64, _i64] + [_vp] * 8 + [_i] * 16 +
                                                       [_vp, _i, _vp, _sz, _c.POINTER(_i), _vp]),
     "omni_select_topk_pages": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "omni_gather_rows_f16": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp]),
     "omni_argmax_workspace_bytes": (_sz, [_i]),
     "omni_argmax_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _sz, _vp]),
     "omni_kv4_prefill_write_fine_grained": (_i, [_vp] * 7 + [_i] * 15 + [_vp, _i, _i, _vp]),

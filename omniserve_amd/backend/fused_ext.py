@@ -164,6 +164,20 @@ def sparse_decode_attention_quant(out_i8, input_sum, scale, q, k, v, retrieval_k
         kv_scale_orig_quant=kv_scale_orig_quant, per_tensor=per_tensor, merge_quant=(out_i8, input_sum, scale))
 
 
+def embed_rows(out, table, idx):
+    """out fp16 [rows, cols] = table[idx] (torch.index_select(table, 0, idx, out=out)): the embedding lookup of the decode
+    drivers as one short kernel -- upstream it is torch.nn.Embedding, not one of the reference's kernels."""
+    _lib.require_cuda(out, table, idx)
+    if table.dtype != torch.float16 or out.dtype != torch.float16 or table.dim() != 2 or not table.is_contiguous() or \
+            not out.is_contiguous() or out.shape[-1] != table.shape[1]:
+        raise RuntimeError("embed_rows: contiguous fp16 table [V, cols] and out [rows, cols] expected")
+    if idx.dtype != torch.int64 or not idx.is_contiguous() or idx.numel() != out.numel() // table.shape[1]:
+        raise RuntimeError("embed_rows: idx must be a contiguous int64 tensor with one id per output row")
+    rc = _lib.lib().omni_gather_rows_f16(out.data_ptr(), table.data_ptr(), idx.data_ptr(), idx.numel(), table.shape[1],
+                                         table.shape[0], _lib.current_stream())
+    _lib.check(rc, "fused_ext.embed_rows")
+
+
 def argmax(out, logits):
     """out int64 [rows] = torch.argmax(logits fp16 [rows, cols], dim=-1) (first maximum); greedy-sampling helper of the
     decode runner -- the reference's sampler is torch code, this is not one of its kernels."""

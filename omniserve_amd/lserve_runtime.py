@@ -192,7 +192,10 @@ class LServeDecodeRunner:
         c, B = self.cfg, self.B
         Hq, Hk, d = c.heads, c.kv_heads, c.head_dim
         self.lengths.add_(1)
-        torch.index_select(self.embed, 0, self.tokens, out=self.x)
+        if self.fused:
+            fused_ext.embed_rows(self.x, self.embed, self.tokens)
+        else:
+            torch.index_select(self.embed, 0, self.tokens, out=self.x)
         sc = self.act_scale                      # scales written by the norm kernels
         sq = self.act_scale2 if self.fused else sc   # ... by the quantisers (kept apart: a deferred epilogue reads them)
         pending = None                           # (sk, linear) of a down_proj whose epilogue is deferred

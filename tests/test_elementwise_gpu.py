@@ -260,3 +260,16 @@ def test_argmax_matches_torch():
     fused_ext.argmax(out, view)
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), torch.argmax(view.float().cpu(), dim=-1))
+
+
+def test_embed_rows_is_index_select():
+    from omniserve_amd.backend import fused_ext
+    g = torch.Generator(device="cpu").manual_seed(4)
+    table = torch.randn((1000, 4096), generator=g).half().to(dev())
+    idx = torch.randint(0, 1000, (16,), generator=g).to(dev())
+    out = torch.zeros((16, 4096), dtype=torch.float16, device=dev())
+    fused_ext.embed_rows(out, table, idx)
+    torch.cuda.synchronize()
+    assert torch.equal(out, torch.index_select(table, 0, idx))
+    with pytest.raises(RuntimeError):
+        fused_ext.embed_rows(out, table, idx.int())
