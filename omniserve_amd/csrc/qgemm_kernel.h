@@ -101,7 +101,8 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   // lane >> 4) a wave instruction touches 16 rows with every lane quad spanning four of them, and the L1 pulls 15 B/clk per
   // CU out of L2 (tools/l1_pattern_probe.hip) where this tile needs 32.  Row-coalesced (row = lane >> 2, piece = lane & 3:
   // a quad reads 64 consecutive bytes) the same loads run at 38 B/clk; the fragment is then turned into the operand map by
-  // one ds_write_b128 + ds_read_b128 through a wave-private KiB (conflict-free both ways: slot = piece * 16 + (row ^ 4 piece)).
+  // one ds_write_b128 + ds_read_b128 through a wave-private KiB, slot = piece * 16 + (row ^ 5 piece): the map among the
+  // candidates of tools/lds_transpose_probe.hip whose write costs what a lane-linear one does (row ^ 4 piece: +23 %).
   constexpr bool W8C = MODE == MODE_W8 && OMNI_GEMM_W8_COALESCED;
   __shared__ __attribute__((aligned(16))) uint8_t wtr[W8C ? WAVES * 1024 : 16];
 
@@ -143,8 +144,8 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   } else {
     wbase = p.W + ((size_t)(2 * ngc + lx) * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
   }
-  uint8_t* const wtr_w = wtr + (W8C ? wave * 1024 + ((lane & 3) * 16 + ((lane >> 2) ^ (4 * (lane & 3)))) * 16 : 0);
-  const uint8_t* const wtr_r = wtr + (W8C ? wave * 1024 + ((lane & 48) + ((lane & 15) ^ (4 * (lane >> 4)))) * 16 : 0);
+  uint8_t* const wtr_w = wtr + (W8C ? wave * 1024 + ((lane & 3) * 16 + ((lane >> 2) ^ (5 * (lane & 3)))) * 16 : 0);
+  const uint8_t* const wtr_r = wtr + (W8C ? wave * 1024 + ((lane & 48) + ((lane & 15) ^ (5 * (lane >> 4)))) * 16 : 0);
   auto load_w = [&](int k, int j) -> uint4 {
     // W4: j = tile parity inside the 64-k step.  W8: j = 16-row block (0..3).
     const uint8_t* ptr;
