@@ -69,6 +69,21 @@ def test_token_streaming_heads(seq_lens, sink, local):
 # ---- long sequences: the regimes the published prefill numbers come from (XCD-ordered 1-D grid, whole-tile skipping of
 # the causal / Lambda masks, LDS-DMA double buffering over hundreds of key tiles).  The f64 oracle is evaluated chunk
 # by chunk over the query rows (oracle.attention.varlen_attention_rows). ------------------------------------------------
+@pytest.mark.parametrize("split", [1, 2, 4, 8])
+@pytest.mark.parametrize("Hq,Hk,classes", [(32, 8, [0, -1, -1, 0, -1, 0, -1, -1]),      # three dense kv heads, irregular
+                                           (8, 2, [-1, 0]), (6, 3, [0, -1, -1]),        # Hk not a divisor of 8: W is raised
+                                           (4, 1, [-1])])
+def test_head_to_xcd_maps_give_the_same_result(split, Hq, Hk, classes):
+    """prefill_map_block (csrc/attn_prefill.hip): whatever the number of XCDs a kv head's query tiles are dealt to, and
+    whatever the dense / streaming pattern, every (sequence, head, tile) is computed exactly once."""
+    from omniserve_amd import _lib
+    _lib.lib().omni_prefill_set_xcd_split(split)
+    try:
+        _case([700, 129, 1], Hq, Hk, seed=7 + split, streaming=(classes, 32, 96))
+    finally:
+        _lib.lib().omni_prefill_set_xcd_split(0)
+
+
 def _long_case(L, Hq, Hk, seed, streaming=None, rows=None, lens=None):
     import block_sparse_attn as bsa
     rng = np.random.default_rng(seed)
