@@ -160,6 +160,9 @@ int omni_dequant_silu_and_mul_quant(void* out_i8, const void* in_i32, float scal
  * Bit-identical to the two reference calls they replace; they exist because at MI355X speeds a
  * decode step is bound by the number of dependent kernels, not by bytes. */
 
+/* In the four fused entry points below that take `sum_f16`, NULL means "no row sum": the W8A8 / per-group layers call
+ * the non-summing reference functions (rms_norm_general, invoke_quant), and the sum costs a second ordered reduction. */
+
 /* residual += delta (fp16 add, as the torch `x + proj` between the reference's calls,
  * llama_w4a8_unpad.py:425,437), then omni_rms_norm_general_fuse_sum on the updated residual. */
 int omni_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const void* delta_f16,

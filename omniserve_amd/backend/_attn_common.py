@@ -223,7 +223,8 @@ def decode_attention_fine_grained(q, k, v, retrieval_kv_pointers, streaming_kv_p
         _lib.check(rc, what + " (partials)")
         ml_bytes = B * Hq * ns.value * 2 * 4
         rc = _lib.lib().omni_attn_merge_quant_fuse_sum(out_i8.data_ptr(), ws.data_ptr(), ws.data_ptr() + ml_bytes, ns.value,
-                                                       input_sum.data_ptr(), scale.data_ptr(), B, Hq, _lib.current_stream())
+                                                       None if input_sum is None else input_sum.data_ptr(),
+                                                       scale.data_ptr(), B, Hq, _lib.current_stream())
         _lib.check(rc, what + " (merge + quant)")
         return None
     out = torch.empty((B, Hq, D), dtype=q.dtype, device=q.device)

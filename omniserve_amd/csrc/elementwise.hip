@@ -874,42 +874,65 @@ extern "C" int omni_debug_norm_stats(const void* in_f16, void* out_f32, float ep
 extern "C" int omni_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const void* delta_f16,
                                                   const void* weight_f16, void* sum_f16, void* scale_f16,
                                                   float eps, int tokens, int hidden, void* stream) {
-  if (!out_i8 || !residual_f16 || !delta_f16 || !weight_f16 || !sum_f16 || !scale_f16 || tokens < 0 || hidden < 1)
+  // sum_f16 == NULL: the row sum is not wanted (W8A8 / per-group callers: rms_norm_general without _fuse_sum upstream)
+  if (!out_i8 || !residual_f16 || !delta_f16 || !weight_f16 || !scale_f16 || tokens < 0 || hidden < 1)
     return OMNI_EINVAL;
   if (hidden > VPT * NT_MAX) return OMNI_EINVAL;
   if (tokens == 0) return OMNI_OK;
   {
     const int nv = norm_block(hidden, true);
     if (v2_ok(hidden, nv)) {
-      #undef KQ_
-      #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, true, SrcAdd>
-      OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8,
-                     SrcAdd{(half_t*)residual_f16, (const half_t*)delta_f16, hidden}, (const half_t*)weight_f16,
-                     (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
+      if (sum_f16) {
+        #undef KQ_
+        #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, true, SrcAdd>
+        OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8,
+                       SrcAdd{(half_t*)residual_f16, (const half_t*)delta_f16, hidden}, (const half_t*)weight_f16,
+                       (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
+      } else {
+        #undef KQ_
+        #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, false, SrcAdd>
+        OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8,
+                       SrcAdd{(half_t*)residual_f16, (const half_t*)delta_f16, hidden}, (const half_t*)weight_f16,
+                       (half_t*)nullptr, (half_t*)scale_f16, eps, hidden, nv);
+      }
       return omni_launch_status();
     }
   }
-  hipLaunchKernelGGL((general_norm_quant_kernel<true, true>), dim3(tokens), dim3(norm_block(hidden, true)),
-                     0, (hipStream_t)stream, (int8_t*)out_i8, (half_t*)residual_f16, (const half_t*)delta_f16,
-                     (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden);
+  if (sum_f16)
+    hipLaunchKernelGGL((general_norm_quant_kernel<true, true>), dim3(tokens), dim3(norm_block(hidden, true)),
+                       0, (hipStream_t)stream, (int8_t*)out_i8, (half_t*)residual_f16, (const half_t*)delta_f16,
+                       (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden);
+  else
+    hipLaunchKernelGGL((general_norm_quant_kernel<false, true>), dim3(tokens), dim3(norm_block(hidden, true)),
+                       0, (hipStream_t)stream, (int8_t*)out_i8, (half_t*)residual_f16, (const half_t*)delta_f16,
+                       (const half_t*)weight_f16, (half_t*)nullptr, (half_t*)scale_f16, eps, hidden);
   return omni_launch_status();
 }
 
 extern "C" int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f16, void* scale_f16,
                                             int tokens, int d, void* stream) {
-  if (!out_i8 || !in_f16 || !sum_f16 || !scale_f16 || tokens < 0 || d < 1) return OMNI_EINVAL;
+  // sum_f16 == NULL: silu_and_mul + invoke_quant (no row sum: the W8A8 / per-group MLP, activation.py:66-82)
+  if (!out_i8 || !in_f16 || !scale_f16 || tokens < 0 || d < 1) return OMNI_EINVAL;
   if (d % 32 != 0) return OMNI_EINVAL;
   if (tokens == 0) return OMNI_OK;
   {
     const int nv = norm_block(d, false);
     if (v2_ok(d, nv)) {
-      #undef KQ_
-      #define KQ_(RT_, RV_) quant_v2_kernel<RT_, RV_, true, SrcSilu>
-      OMNI_V2_LAUNCH(KQ_, tokens, d, d, (int8_t*)out_i8, SrcSilu{(const half_t*)in_f16, d},
-                     (half_t*)sum_f16, (half_t*)scale_f16, d, nv);
+      if (sum_f16) {
+        #undef KQ_
+        #define KQ_(RT_, RV_) quant_v2_kernel<RT_, RV_, true, SrcSilu>
+        OMNI_V2_LAUNCH(KQ_, tokens, d, d, (int8_t*)out_i8, SrcSilu{(const half_t*)in_f16, d},
+                       (half_t*)sum_f16, (half_t*)scale_f16, d, nv);
+      } else {
+        #undef KQ_
+        #define KQ_(RT_, RV_) quant_v2_kernel<RT_, RV_, false, SrcSilu>
+        OMNI_V2_LAUNCH(KQ_, tokens, d, d, (int8_t*)out_i8, SrcSilu{(const half_t*)in_f16, d},
+                       (half_t*)nullptr, (half_t*)scale_f16, d, nv);
+      }
       return omni_launch_status();
     }
   }
+  if (!sum_f16) return OMNI_EINVAL;     // (row lengths outside the v2 geometry: only the summing form is built)
   hipLaunchKernelGGL(silu_mul_quant_kernel, dim3(tokens), dim3(norm_block(d, false)), 0, (hipStream_t)stream,
                      (int8_t*)out_i8, (const half_t*)in_f16, (half_t*)sum_f16, (half_t*)scale_f16, d);
   return omni_launch_status();
@@ -942,7 +965,8 @@ extern "C" int omni_splitk_w8_add_rms_norm_general_fuse_sum(void* out_i8, void* 
                                                             const void* wscales_f16, const void* ascales_in_f16,
                                                             const void* weight_f16, void* sum_f16, void* scale_f16,
                                                             float eps, int tokens, int hidden, void* stream) {
-  if (!out_i8 || !residual_f16 || !slab_i32 || !wscales_f16 || !ascales_in_f16 || !weight_f16 || !sum_f16 ||
+  // sum_f16 == NULL: no row sum (the W8A8 / per-group layers never read one)
+  if (!out_i8 || !residual_f16 || !slab_i32 || !wscales_f16 || !ascales_in_f16 || !weight_f16 ||
       !scale_f16 || tokens < 0 || hidden < 1 || sk < 1)
     return OMNI_EINVAL;
   const int nv = norm_block(hidden, true);
@@ -952,17 +976,25 @@ extern "C" int omni_splitk_w8_add_rms_norm_general_fuse_sum(void* out_i8, void* 
                    (const half_t*)wscales_f16, (const half_t*)nullptr, (const half_t*)ascales_in_f16,
                    (const half_t*)nullptr, 0.f, 0.f};
   const bool v2_batched = false;
-  #undef KQ_
-  #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, true, SrcSlabAddW8>
-  OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8, src,
-                 (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
+  if (sum_f16) {
+    #undef KQ_
+    #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, true, SrcSlabAddW8>
+    OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8, src,
+                   (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
+  } else {
+    #undef KQ_
+    #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, false, SrcSlabAddW8>
+    OMNI_V2_LAUNCH(KQ_, tokens, hidden, hidden, (int8_t*)out_i8, src,
+                   (const half_t*)weight_f16, (half_t*)nullptr, (half_t*)scale_f16, eps, hidden, nv);
+  }
   return omni_launch_status();
 }
 
 // Fused extension: kv4_decode_merge_kernel + omni_quant_fuse_sum in one kernel (one workgroup per token).
 extern "C" int omni_attn_merge_quant_fuse_sum(void* out_i8, const void* part_ml_f32, const void* part_o_f32, int nsplit,
                                               void* sum_f16, void* scale_f16, int batch, int num_heads, void* stream) {
-  if (!out_i8 || !part_ml_f32 || !part_o_f32 || !sum_f16 || !scale_f16 || nsplit < 1 || batch < 0 || num_heads < 1)
+  // sum_f16 == NULL: merge + invoke_quant (no row sum)
+  if (!out_i8 || !part_ml_f32 || !part_o_f32 || !scale_f16 || nsplit < 1 || batch < 0 || num_heads < 1)
     return OMNI_EINVAL;
   const int hidden = num_heads * 128;
   const int nv = norm_block(hidden, false);
@@ -970,10 +1002,17 @@ extern "C" int omni_attn_merge_quant_fuse_sum(void* out_i8, const void* part_ml_
   if (batch == 0) return OMNI_OK;
   SrcAttnMerge src{(const float*)part_ml_f32, (const float*)part_o_f32, nsplit, num_heads, 0};
   const bool v2_batched = false;
-  #undef KQ_
-  #define KQ_(RT_, RV_) quant_v2_kernel<RT_, RV_, true, SrcAttnMerge>
-  OMNI_V2_LAUNCH(KQ_, batch, hidden, hidden, (int8_t*)out_i8, src, (half_t*)sum_f16,
-                 (half_t*)scale_f16, hidden, nv);
+  if (sum_f16) {
+    #undef KQ_
+    #define KQ_(RT_, RV_) quant_v2_kernel<RT_, RV_, true, SrcAttnMerge>
+    OMNI_V2_LAUNCH(KQ_, batch, hidden, hidden, (int8_t*)out_i8, src, (half_t*)sum_f16,
+                   (half_t*)scale_f16, hidden, nv);
+  } else {
+    #undef KQ_
+    #define KQ_(RT_, RV_) quant_v2_kernel<RT_, RV_, false, SrcAttnMerge>
+    OMNI_V2_LAUNCH(KQ_, batch, hidden, hidden, (int8_t*)out_i8, src, (half_t*)nullptr,
+                   (half_t*)scale_f16, hidden, nv);
+  }
   return omni_launch_status();
 }
 

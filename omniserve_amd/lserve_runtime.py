@@ -203,7 +203,7 @@ class LServeDecodeRunner:
         attn = fused_attention_per_tensor_sparse if self.kv8 else fused_attention_fine_grained_sparse
         size_r, size_s = self.nr * self.row, self.ns * self.row
         total_pages = hist // self.tpb + 1
-        sm = self.act_sum
+        sm = None          # W8A8: nobody reads a row sum (rms_norm_general / invoke_quant upstream): the fused kernels skip it
         for li, L in enumerate(self.layers):
             self._arm(L["qkv"])
             if pending is not None:       # residual += down_proj(previous layer) [deferred epilogue], norm + quant
@@ -327,7 +327,7 @@ class LServeDecodeRunner:
         mlp_act = None if self.fused else torch.empty((ch, c.inter), dtype=f16, device=dev)
         q_inter = torch.empty((ch, c.inter), dtype=i8, device=dev)
         size_r, size_s = self.nr * self.row, self.ns * self.row
-        sums = torch.empty((T,), dtype=f16, device=dev) if self.fused else None    # by-product of the fused entry points
+        sums = None        # W8A8: no row sums (the fused entry points skip them when given None)
         nl = len(self.layers)
         for li, L in enumerate(self.layers):
             if self.fused and li > 0:      # residual += down_proj(previous layer), norm + quant: one pass over x
@@ -363,7 +363,7 @@ class LServeDecodeRunner:
                 n = min(ch, T - s0)
                 L["gate_up"].forward(q_hidden[s0:s0 + n], scale[s0:s0 + n], gate_up[:n])
                 if self.fused:             # SiLU*mul + quant without the fp16 round trip (bit-identical)
-                    fused_ext.silu_mul_quant_fuse_sum(q_inter[:n], gate_up[:n], sums[:n], scale[:n])
+                    fused_ext.silu_mul_quant_fuse_sum(q_inter[:n], gate_up[:n], sums, scale[:n])
                 else:
                     activation_ops.silu_and_mul(mlp_act[:n], gate_up[:n])
                     fused_kernels.invoke_quant(q_inter[:n], mlp_act[:n], scale[:n])

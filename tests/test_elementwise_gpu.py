@@ -273,3 +273,28 @@ def test_embed_rows_is_index_select():
     assert torch.equal(out, torch.index_select(table, 0, idx))
     with pytest.raises(RuntimeError):
         fused_ext.embed_rows(out, table, idx.int())
+
+
+def test_fused_entry_points_without_the_row_sum():
+    """sum = None (W8A8 / per-group callers): same codes and scales as the summing form, nothing else written."""
+    from omniserve_amd.backend import fused_ext
+    rng = np.random.default_rng(12)
+    T, H, I = 5, 4096, 14336
+    g = (1.0 + 0.1 * rng.standard_normal(H)).astype(np.float16)
+    res = (rng.standard_normal((T, H)) * 2).astype(np.float16)
+    delta = rng.standard_normal((T, H)).astype(np.float16)
+    outs = []
+    for with_sum in (True, False):
+        q = torch.empty((T, H), dtype=torch.int8, device=dev())
+        sc = torch.empty((T,), dtype=torch.float16, device=dev())
+        sm = torch.full((T,), 7.0, dtype=torch.float16, device=dev())
+        r = to_dev(res.copy())
+        fused_ext.add_rms_norm_general_fuse_sum(q, r, to_dev(delta), to_dev(g), sm if with_sum else None, sc, 1e-5)
+        gu = to_dev((rng.standard_normal((T, 2 * I))).astype(np.float16)) if with_sum else gu
+        q2 = torch.empty((T, I), dtype=torch.int8, device=dev())
+        sc2 = torch.empty((T,), dtype=torch.float16, device=dev())
+        fused_ext.silu_mul_quant_fuse_sum(q2, gu, sm if with_sum else None, sc2)
+        torch.cuda.synchronize()
+        outs.append((q.cpu().numpy(), sc.cpu().numpy(), r.cpu().numpy(), q2.cpu().numpy(), sc2.cpu().numpy()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
