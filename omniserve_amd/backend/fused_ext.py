@@ -127,7 +127,7 @@ def decode_attention_quant_fuse_sum(out_i8, q, k, v, kv_pointers, lengths, token
     _lib.check(rc, "fused_ext.decode_attention_quant_fuse_sum (partials)")
     ml_bytes = B * Hq * ns.value * 2 * 4
     rc = _lib.lib().omni_attn_merge_quant_fuse_sum(out_i8.data_ptr(), ws.data_ptr(), ws.data_ptr() + ml_bytes, ns.value,
-                                                   input_sum.data_ptr(), scale.data_ptr(), B, Hq, _lib.current_stream())
+                                                   _ptr(input_sum), scale.data_ptr(), B, Hq, _lib.current_stream())
     _lib.check(rc, "fused_ext.decode_attention_quant_fuse_sum (merge+quant)")
 
 

@@ -312,6 +312,9 @@ class DecodeRunner:
         hq, hk, d = self.hl, self.kl, c.head_dim     # this rank's heads
         sA, mA = self.act_scale2, self.act_sum2   # scales / sums produced by quant-type kernels
         sB, mB = self.act_scale, self.act_sum     # ... by norm kernels
+        per_chn = c.group_size == -1
+        if not per_chn:    # g128: no activation sums anywhere (llama_w4a8_unpad.py:81,212-215,395-401): the reference calls
+            mA = mB = None # rms_norm_general / invoke_quant, and the fused entry points skip the second row reduction
         pending = None                             # (sk, linear) of a down_proj whose epilogue is deferred
         nl = len(self.layers)
         for li, L in enumerate(self.layers):
@@ -323,8 +326,10 @@ class DecodeRunner:
                 pending = None
             elif self.fused and li > 0:
                 fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln1"], mB, sB, c.eps)
-            else:
+            elif per_chn:
                 layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln1"], mB, sB, c.eps, True)
+            else:
+                layernorm_ops.rms_norm_general(qa_h, self.x, L["ln1"], sB, c.eps, True)
             L["qkv"].forward(qa_h, sB, mB, self.qkv_buf)
             q = self.qkv_buf[:, : hq * d].view(B, hq, d)
             k = self.qkv_buf[:, hq * d:(hq + hk) * d].view(B, hk, d)
@@ -337,7 +342,10 @@ class DecodeRunner:
                 attn = fused_attention_pure_dense.single_query_attention(
                     q, k, v, self.block_tables[li], self.lengths, None, 65536, self.tpb, hk * d // 2,
                     self.max_context, d, c.rope_theta, True, True, True)
-                fused_kernels.invoke_quant_fuse_sum(self._q_attn, attn.view(B, hq * d), mA, sA)
+                if per_chn:
+                    fused_kernels.invoke_quant_fuse_sum(self._q_attn, attn.view(B, hq * d), mA, sA)
+                else:
+                    fused_kernels.invoke_quant(self._q_attn, attn.view(B, hq * d), sA)
             if self.fused >= 2:
                 sk = self._partial(self._q_attn, L["o"])
                 self._arm(L["gate_up"])
@@ -350,14 +358,20 @@ class DecodeRunner:
                     fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln2"], mB, sB, c.eps)
                 else:
                     self.x.add_(self.proj_buf)
-                    layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln2"], mB, sB, c.eps, True)
+                    if per_chn:
+                        layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln2"], mB, sB, c.eps, True)
+                    else:
+                        layernorm_ops.rms_norm_general(qa_h, self.x, L["ln2"], sB, c.eps, True)
             L["gate_up"].forward(qa_h, sB, mB, self.gate_up_buf)
             self._arm(L["down"], deferred=self.fused >= 2 and li < nl - 1)
             if self.fused:
                 fused_ext.silu_mul_quant_fuse_sum(qa_i, self.gate_up_buf, mA, sA)
             else:
                 activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
-                fused_kernels.invoke_quant_fuse_sum(qa_i, self.mlp_act, mA, sA)
+                if per_chn:
+                    fused_kernels.invoke_quant_fuse_sum(qa_i, self.mlp_act, mA, sA)
+                else:
+                    fused_kernels.invoke_quant(qa_i, self.mlp_act, sA)
             if self.fused >= 2 and li < nl - 1:
                 pending = (self._partial(qa_i, L["down"]), L["down"])
             else:
@@ -417,9 +431,14 @@ class DecodeRunner:
         q = qkv[:, : hq * d].view(T, hq, d)
         k = qkv[:, hq * d:(hq + hk) * d].view(T, hk, d)
         v = qkv[:, (hq + hk) * d:].view(T, hk, d)
+        per_chn = c.group_size == -1
+        if not per_chn:
+            mA = mB = None      # g128: no activation sums (see _eager_step_body)
         for li, Ly in enumerate(self.layers):
-            if li == 0:
+            if li == 0 and per_chn:
                 layernorm_ops.rms_norm_general_fuse_sum(qh, x, Ly["ln1"], mB, sB, c.eps, True)
+            elif li == 0:
+                layernorm_ops.rms_norm_general(qh, x, Ly["ln1"], sB, c.eps, True)
             else:
                 fused_ext.add_rms_norm_general_fuse_sum(qh, x, proj, Ly["ln1"], mB, sB, c.eps)
             Ly["qkv"].forward(qh, sB, mB, qkv)
@@ -427,7 +446,10 @@ class DecodeRunner:
                                                 self.tpb, hk * d // 2, 0, 0, 0, 0, 0, hk, 0, d, c.rope_theta, 1.0,
                                                 1 << 20, True, True, True)
             attn = flash_attn_varlen_func(q, k, v, cu, cu, L, L, causal=True)
-            fused_kernels.invoke_quant_fuse_sum(qa, attn.view(T, hq * d), mA, sA)
+            if per_chn:
+                fused_kernels.invoke_quant_fuse_sum(qa, attn.view(T, hq * d), mA, sA)
+            else:
+                fused_kernels.invoke_quant(qa, attn.view(T, hq * d), sA)
             Ly["o"].forward(qa, sA, mA, proj)
             self._all_reduce(proj)
             fused_ext.add_rms_norm_general_fuse_sum(qh, x, proj, Ly["ln2"], mB, sB, c.eps)
