@@ -142,6 +142,12 @@ def prefetch_arm_gemm(weight, M, N, K, mode=0, deferred=False, budget_bytes=24 <
     _lib.check(rc, "fused_ext.prefetch_arm_gemm")
 
 
+def prefetch_disarm():
+    """Drop an armed (not yet consumed) prefetch descriptor of this thread."""
+    rc = _lib.lib().omni_prefetch_arm_gemm(None, 0, 0, 0, 0, 0, 0, 0)
+    _lib.check(rc, "fused_ext.prefetch_disarm")
+
+
 def set_weight_policy(policy):
     """0: decode-shape GEMMs stream their weights with non-temporal loads (default); 1: plain loads (for weights a
     preceding row kernel prefetched into L2).  Process-wide, evaluated at enqueue time."""

@@ -92,13 +92,14 @@ __global__ __launch_bounds__(NT_MAX) void quant_kernel(int8_t* __restrict__ out,
 
 // Fused extension: silu_and_mul + invoke_quant_fuse_sum without the fp16
 // [tokens, d] round trip; bit-identical to running the two kernels back to back.
+template <bool FUSE_SUM>
 __global__ __launch_bounds__(NT_MAX) void silu_mul_quant_kernel(int8_t* __restrict__ out,
                                                                  const half_t* __restrict__ in,
                                                                  half_t* __restrict__ sum_out,
                                                                  half_t* __restrict__ scale_out, int d) {
   __shared__ float red[32];
-  quant_row<true>(out + (size_t)blockIdx.x * d, SiluMulLoader{in + (size_t)blockIdx.x * 2 * d, d}, sum_out,
-                  scale_out, d, red);
+  quant_row<FUSE_SUM>(out + (size_t)blockIdx.x * d, SiluMulLoader{in + (size_t)blockIdx.x * 2 * d, d}, sum_out,
+                      scale_out, d, red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -724,6 +725,7 @@ extern "C" int omni_quant(void* out_i8, const void* in_f16, void* scale_f16, int
                    (half_t*)nullptr, (half_t*)scale_f16, hidden, nv);
     return omni_launch_status();
   }
+  (void)take_armed_prefetch();   // this geometry cannot carry the L2 prefetch: drop an armed descriptor instead of leaving it for a later launch
   hipLaunchKernelGGL((quant_kernel<false>), dim3(tokens), dim3(norm_block(hidden, false)), 0,
                      (hipStream_t)stream, (int8_t*)out_i8, (const half_t*)in_f16, (half_t*)nullptr,
                      (half_t*)scale_f16, hidden);
@@ -743,6 +745,7 @@ extern "C" int omni_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f
                    (half_t*)sum_f16, (half_t*)scale_f16, hidden, nv);
     return omni_launch_status();
   }
+  (void)take_armed_prefetch();   // this geometry cannot carry the L2 prefetch: drop an armed descriptor instead of leaving it for a later launch
   hipLaunchKernelGGL((quant_kernel<true>), dim3(tokens), dim3(norm_block(hidden, false)), 0,
                      (hipStream_t)stream, (int8_t*)out_i8, (const half_t*)in_f16, (half_t*)sum_f16,
                      (half_t*)scale_f16, hidden);
@@ -787,6 +790,7 @@ extern "C" int omni_rms_norm_general(void* out_i8, const void* in_f16, const voi
       return omni_launch_status();
     }
   }
+  (void)take_armed_prefetch();   // this geometry cannot carry the L2 prefetch: drop an armed descriptor instead of leaving it for a later launch
   hipLaunchKernelGGL((general_norm_quant_kernel<false, false>), dim3(tokens), dim3(norm_block(hidden, true)),
                      0, (hipStream_t)stream, (int8_t*)out_i8, (half_t*)in_f16, (const half_t*)nullptr,
                      (const half_t*)weight_f16, (half_t*)nullptr, (half_t*)scale_f16, eps, hidden);
@@ -812,6 +816,7 @@ extern "C" int omni_rms_norm_general_fuse_sum(void* out_i8, const void* in_f16,
       return omni_launch_status();
     }
   }
+  (void)take_armed_prefetch();   // this geometry cannot carry the L2 prefetch: drop an armed descriptor instead of leaving it for a later launch
   hipLaunchKernelGGL((general_norm_quant_kernel<true, false>), dim3(tokens), dim3(norm_block(hidden, true)),
                      0, (hipStream_t)stream, (int8_t*)out_i8, (half_t*)in_f16, (const half_t*)nullptr,
                      (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden);
@@ -898,6 +903,7 @@ extern "C" int omni_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f
       return omni_launch_status();
     }
   }
+  (void)take_armed_prefetch();
   if (sum_f16)
     hipLaunchKernelGGL((general_norm_quant_kernel<true, true>), dim3(tokens), dim3(norm_block(hidden, true)),
                        0, (hipStream_t)stream, (int8_t*)out_i8, (half_t*)residual_f16, (const half_t*)delta_f16,
@@ -932,9 +938,14 @@ extern "C" int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, vo
       return omni_launch_status();
     }
   }
-  if (!sum_f16) return OMNI_EINVAL;     // (row lengths outside the v2 geometry: only the summing form is built)
-  hipLaunchKernelGGL(silu_mul_quant_kernel, dim3(tokens), dim3(norm_block(d, false)), 0, (hipStream_t)stream,
-                     (int8_t*)out_i8, (const half_t*)in_f16, (half_t*)sum_f16, (half_t*)scale_f16, d);
+  (void)take_armed_prefetch();
+  // row lengths outside the v2 geometry (d > 16384: Llama-2-70B / Yi-34B intermediate sizes at TP = 1)
+  if (sum_f16)
+    hipLaunchKernelGGL(silu_mul_quant_kernel<true>, dim3(tokens), dim3(norm_block(d, false)), 0, (hipStream_t)stream,
+                       (int8_t*)out_i8, (const half_t*)in_f16, (half_t*)sum_f16, (half_t*)scale_f16, d);
+  else
+    hipLaunchKernelGGL(silu_mul_quant_kernel<false>, dim3(tokens), dim3(norm_block(d, false)), 0, (hipStream_t)stream,
+                       (int8_t*)out_i8, (const half_t*)in_f16, (half_t*)nullptr, (half_t*)scale_f16, d);
   return omni_launch_status();
 }
 
@@ -1098,9 +1109,14 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const unsigned long lo
 __global__ __launch_bounds__(256) void gather_rows_kernel(half_t* __restrict__ out, const half_t* __restrict__ table,
                                                            const int64_t* __restrict__ idx, int cols, int64_t table_rows) {
   const int64_t r = idx[blockIdx.x];
-  if (r < 0 || r >= table_rows) return;          // an out-of-range id leaves the row untouched (torch would raise)
-  const uint4* src = reinterpret_cast<const uint4*>(table + (size_t)r * cols);
   uint4* dst = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * cols);
+  if (r < 0 || r >= table_rows) {
+    // torch.index_select raises on an out-of-range id; a kernel inside a captured graph cannot: the row is filled
+    // with NaN so the sequence visibly fails instead of decoding from the previous step's stale embedding
+    for (int i = threadIdx.x; i < cols / 8; i += 256) dst[i] = make_uint4(0x7E007E00u, 0x7E007E00u, 0x7E007E00u, 0x7E007E00u);
+    return;
+  }
+  const uint4* src = reinterpret_cast<const uint4*>(table + (size_t)r * cols);
   for (int i = threadIdx.x; i < cols / 8; i += 256) dst[i] = src[i];
 }
 

@@ -7,7 +7,7 @@ namespace omni {
 static int g_override_waves = 0;
 static int g_override_sk = 0;
 int g_weight_policy = 0;             // 0: non-temporal weight loads (streamed once), 1: plain loads (L2-prefetched weights)
-static PrefetchArgs g_armed_prefetch = {};
+static thread_local PrefetchArgs g_armed_prefetch = {};   // per enqueueing thread: armed and consumed by the same caller
 
 PrefetchArgs take_armed_prefetch() {
   PrefetchArgs pf = g_armed_prefetch;

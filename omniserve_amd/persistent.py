@@ -101,6 +101,12 @@ class GraphedStep:
 
     def run(self) -> None:
         if self.graph is None:
+            # A stateful step (lengths += 1, KV append, token feedback) cannot be warmed up without a `restore`: the
+            # warm-up launches would advance it before the first replay.  Capture without warm-up instead (the capture
+            # pass itself executes nothing), then replay: exactly one execution.  Scratch that is sized lazily must
+            # therefore already exist -- call capture(restore) explicitly when it may not.
+            if self.warmup > 0:
+                raise RuntimeError("GraphedStep.run() before capture(): call capture(restore) first (warm-up launches "
+                                   "advance a stateful step), or construct with warmup=0")
             self.capture()
-            # the capture pass does not execute the kernels: run the step once for real
         self.graph.replay()

@@ -256,9 +256,12 @@ class DecodeRunner:
                 with torch.cuda.graph(graph):
                     self._eager_step()
                 self.graph = graph
-            except Exception as exc:     # noqa: BLE001  (e.g. a collective that cannot be captured on this stack)
+            except RuntimeError as exc:  # (e.g. a collective that cannot be captured on this stack)
                 if self.tp_size == 1:
                     raise
+                import warnings
+                warnings.warn("DecodeRunner: HIP-graph capture of the tensor-parallel step failed (%s); falling back to "
+                              "eager launches" % exc)
                 # tensor-parallel first contact: an RCCL all-reduce inside a captured HIP graph has never run on
                 # hardware here; fall back to eager launches instead of losing the run, and say so
                 torch.cuda.synchronize()
@@ -299,6 +302,8 @@ class DecodeRunner:
             self._eager_step_body()
         finally:
             fused_ext.set_weight_policy(0)
+            if self.prefetch_bytes > 0:
+                fused_ext.prefetch_disarm()     # a step that raised may leave a descriptor armed
 
     def _eager_step_body(self):
         # one decoder layer at decode shape = llama_w4a8_unpad.py:406-438
