@@ -210,6 +210,39 @@ int omni_kv4_decode_attention_partial(const void* q_f16, const void* k_f16, cons
 int omni_attn_merge_quant_fuse_sum(void* out_i8, const void* part_ml_f32, const void* part_o_f32, int nsplit,
                                    void* sum_f16, void* scale_f16, int batch, int num_heads, void* stream);
 
+/* ---- fused extension, round 3: the decode layer without its two quantiser row kernels ------------------------------
+ * Upstream runs  gate_up GEMM -> silu_and_mul -> invoke_quant_fuse_sum -> down GEMM  and  attention ->
+ * invoke_quant_fuse_sum -> o GEMM  (llama_w4a8_unpad.py:354-360,431-436; activation.py:54-64).  A per-token quantiser
+ * needs the row maximum before any code can be produced, which is what forces a row kernel (one workgroup per token, a
+ * pure latency chain at decode batch sizes) between two weight-streaming GEMVs.  Here the PRODUCER of the fp16
+ * activation also raises the row maxima of |x| in `amax_slots_u32` -- uint32 [rows][8] holding f32 bit patterns,
+ * raised with integer atomicMax (exact, order independent; the caller zeroes the buffer before the producer runs) --
+ * and the CONSUMING projection quantises its own K-slices on the fly:
+ *   omni_w4a8_per_{chn,group}_gemm_silu   gemm_forward_cuda + silu_and_mul: act fp16 [M, N/2] (gate = output channels
+ *       [0, N/2), up = [N/2, N)), bit-identical to the two reference calls; raises amax_slots.  M <= 16.
+ *   omni_attn_merge_f16_amax              the merge step of omni_kv4_decode_attention as a wide kernel: fp16 [B, Hq*128]
+ *       (the values omni_kv4_decode_attention returns); raises amax_slots.  Carries an armed L2 prefetch.
+ *   omni_w4a8_per_{chn,group}_gemm_partial_f16   omni_w4a8_per_*_gemm_partial on the codes
+ *       invoke_quant[_fuse_sum](act) would produce -- code = rni_sat(x * (127 / amax)), fused_kernels.cu:126-131 --
+ *       computed inside the GEMV; rider workgroups of the same launch replay the reference's ordered row sum
+ *       (fused_kernels.cu:108-127) and write sum_f16 (NULL: not wanted) / scale_f16 = h(amax / 127) for the consumer of
+ *       the slabs (omni_splitk_[w8_]add_rms_norm_general_fuse_sum).  M <= 16, K <= 16384.
+ * Codes, scales, sums and slabs are bit-identical to the reference call sequence (tests/test_rowfree_gpu.py). */
+int omni_w4a8_per_chn_gemm_silu(const void* in_feats, const void* qweight, const void* wscales, const void* ascales,
+                                const void* w_szs, const void* a_ssums, void* act_f16, void* amax_slots_u32, int M, int N,
+                                int K, void* stream);
+int omni_w4a8_per_group_gemm_silu(const void* in_feats, const void* qweight, const void* zeros, const void* scales_i8,
+                                  const void* wscales, const void* ascales, void* act_f16, void* amax_slots_u32, int M,
+                                  int N, int K, void* stream);
+int omni_w4a8_per_chn_gemm_partial_f16(const void* act_f16, const void* amax_slots_u32, const void* qweight,
+                                       void* slab_i32, size_t slab_bytes, void* sum_f16, void* scale_f16, int M, int N,
+                                       int K, int* sk_out, void* stream);
+int omni_w4a8_per_group_gemm_partial_f16(const void* act_f16, const void* amax_slots_u32, const void* qweight,
+                                         const void* zeros, const void* scales_i8, void* slab_i32, size_t slab_bytes,
+                                         void* sum_f16, void* scale_f16, int M, int N, int K, int* sk_out, void* stream);
+int omni_attn_merge_f16_amax(void* out_f16, const void* part_ml_f32, const void* part_o_f32, int nsplit,
+                             void* amax_slots_u32, int batch, int num_heads, void* stream);
+
 /* The same split for the LServe decode attention (retrieval / streaming heads, optional page list; KV4 pages when both
  * scale pointers are NULL, per-tensor KV8 pages otherwise): partials only, finished by omni_attn_merge_quant_fuse_sum. */
 int omni_kv_decode_attention_fine_grained_partial(
@@ -372,8 +405,8 @@ int omni_kv4_prefill_write_fine_grained(
  * token) during which HBM idles.  omni_prefetch_arm_gemm describes the NEXT decode-shape GEMM (M <= 128; mode 0 =
  * W4A8 per-channel, 1 = per-group, 2 = W8A8; deferred != 0 for omni_w4a8_per_chn_gemm_partial) and arms a one-shot
  * descriptor: the next decode-size (< 1024 tokens) launch of omni_quant[_fuse_sum], omni_rms_norm_general[_fuse_sum],
- * omni_add_rms_norm_general_fuse_sum, omni_silu_mul_quant_fuse_sum, omni_splitk_add_rms_norm_general_fuse_sum or
- * omni_attn_merge_quant_fuse_sum carries `blocks` extra workgroups that pull up to budget_bytes of that GEMM's packed
+ * omni_add_rms_norm_general_fuse_sum, omni_silu_mul_quant_fuse_sum, omni_splitk_add_rms_norm_general_fuse_sum,
+ * omni_attn_merge_quant_fuse_sum or omni_attn_merge_f16_amax carries `blocks` extra workgroups that pull up to budget_bytes of that GEMM's packed
  * weights (the head of every wave's weight stream, laid out by the GEMM's own plan) into the XCD-private L2s.
  * weight == NULL, blocks <= 0 or budget_bytes <= 0 disarms.  A pure performance hint: results never depend on it.
  * omni_gemm_set_weight_policy(1) makes the decode-shape GEMMs load weights with plain instead of non-temporal

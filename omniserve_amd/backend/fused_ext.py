@@ -131,11 +131,119 @@ def decode_attention_quant_fuse_sum(out_i8, q, k, v, kv_pointers, lengths, token
     _lib.check(rc, "fused_ext.decode_attention_quant_fuse_sum (merge+quant)")
 
 
+# ---- row-kernel-free decode layer (round 3): the quantisers between two projections folded into the projections ----------
+AMAX_WORDS = 8 * 16 * 8      # csrc/common.h: [XCD][row][sub-slot] row-maximum candidates of one activation tensor (<= 16 rows)
+
+
+def new_amax_slots(rows, device):
+    """Zeroed buffer of row-maximum candidates (f32 bit patterns, layout [8 XCDs][16 rows][8 sub-slots]) for an
+    activation of `rows` <= 16 rows.  A producer (gemm_silu_*, decode_attention_f16_amax) RAISES the words with an integer
+    max: zero the buffer before every producer call that should start a fresh maximum."""
+    if rows > 16:
+        raise RuntimeError("row-maximum hand-off covers at most 16 activation rows")
+    return torch.zeros((AMAX_WORDS,), dtype=torch.int32, device=device)
+
+
+def amax_rows(amax, rows):
+    """float32 [rows]: the row maxima a buffer of candidates currently holds (tests / debugging)."""
+    return amax.view(torch.float32).view(8, 16, 8).amax(dim=(0, 2))[:rows]
+
+
+def gemm_silu_per_chn(in_feats, qweight, wscales, ascales, w_szs, a_ssums, act, amax):
+    """gate_up projection + silu_and_mul in one kernel: act fp16 [M, N/2] = silu_and_mul(gemm_forward_cuda(...)) bit for
+    bit, and the row maxima of |act| raised in `amax` (new_amax_slots).  M <= 16."""
+    _lib.require_cuda(in_feats, qweight, wscales, ascales, w_szs, a_ssums, act, amax)
+    M, K = in_feats.shape
+    N = qweight.shape[0]
+    if act.dtype != torch.float16 or tuple(act.shape) != (M, N // 2) or not act.is_contiguous():
+        raise RuntimeError("gemm_silu_per_chn: act must be a contiguous fp16 [M, N/2] tensor")
+    rc = _lib.lib().omni_w4a8_per_chn_gemm_silu(in_feats.data_ptr(), qweight.data_ptr(), wscales.data_ptr(),
+                                                ascales.data_ptr(), w_szs.data_ptr(), a_ssums.data_ptr(),
+                                                act.data_ptr(), amax.data_ptr(), M, N, K, _lib.current_stream())
+    _lib.check(rc, "fused_ext.gemm_silu_per_chn")
+
+
+def gemm_silu_per_group(in_feats, qweight, s2_zeros, s2_scales, wscales, ascales, act, amax):
+    """The g128 form of gemm_silu_per_chn."""
+    _lib.require_cuda(in_feats, qweight, s2_zeros, s2_scales, wscales, ascales, act, amax)
+    M, K = in_feats.shape
+    N = qweight.shape[0]
+    if act.dtype != torch.float16 or tuple(act.shape) != (M, N // 2) or not act.is_contiguous():
+        raise RuntimeError("gemm_silu_per_group: act must be a contiguous fp16 [M, N/2] tensor")
+    rc = _lib.lib().omni_w4a8_per_group_gemm_silu(in_feats.data_ptr(), qweight.data_ptr(), s2_zeros.data_ptr(),
+                                                  s2_scales.data_ptr(), wscales.data_ptr(), ascales.data_ptr(),
+                                                  act.data_ptr(), amax.data_ptr(), M, N, K, _lib.current_stream())
+    _lib.check(rc, "fused_ext.gemm_silu_per_group")
+
+
+def gemm_partial_f16_per_chn(act, amax, qweight, slab, sum_out, scale_out):
+    """o / down projection straight from fp16 activations: the int8 codes invoke_quant_fuse_sum(act) would produce are
+    computed inside the GEMV from `amax` (row maxima left by the producer of `act`); writes int32 split-K slabs (returns
+    sk, as gemm_partial_per_chn) and -- by rider workgroups -- the fp16 row sums / scales of invoke_quant_fuse_sum into
+    sum_out / scale_out, for splitk_add_rms_norm_general_fuse_sum.  M <= 16, K <= 16384."""
+    import ctypes
+    _lib.require_cuda(act, amax, qweight, slab, sum_out, scale_out)
+    M, K = act.shape
+    N = qweight.shape[0]
+    if act.dtype != torch.float16 or not act.is_contiguous():
+        raise RuntimeError("gemm_partial_f16_per_chn: act must be a contiguous fp16 [M, K] tensor")
+    sk = ctypes.c_int(0)
+    rc = _lib.lib().omni_w4a8_per_chn_gemm_partial_f16(act.data_ptr(), amax.data_ptr(), qweight.data_ptr(),
+                                                       slab.data_ptr(), slab.numel() * slab.element_size(),
+                                                       _ptr(sum_out), scale_out.data_ptr(), M, N, K, ctypes.byref(sk),
+                                                       _lib.current_stream())
+    _lib.check(rc, "fused_ext.gemm_partial_f16_per_chn")
+    return sk.value
+
+
+def gemm_partial_f16_per_group(act, amax, qweight, s2_zeros, s2_scales, slab, sum_out, scale_out):
+    """The g128 form of gemm_partial_f16_per_chn (sum_out may be None: the per-group layers read no row sums)."""
+    import ctypes
+    _lib.require_cuda(act, amax, qweight, s2_zeros, s2_scales, slab, sum_out, scale_out)
+    M, K = act.shape
+    N = qweight.shape[0]
+    if act.dtype != torch.float16 or not act.is_contiguous():
+        raise RuntimeError("gemm_partial_f16_per_group: act must be a contiguous fp16 [M, K] tensor")
+    sk = ctypes.c_int(0)
+    rc = _lib.lib().omni_w4a8_per_group_gemm_partial_f16(act.data_ptr(), amax.data_ptr(), qweight.data_ptr(),
+                                                         s2_zeros.data_ptr(), s2_scales.data_ptr(), slab.data_ptr(),
+                                                         slab.numel() * slab.element_size(), _ptr(sum_out),
+                                                         scale_out.data_ptr(), M, N, K, ctypes.byref(sk),
+                                                         _lib.current_stream())
+    _lib.check(rc, "fused_ext.gemm_partial_f16_per_group")
+    return sk.value
+
+
+def decode_attention_f16_amax(out_f16, amax, q, k, v, kv_pointers, lengths, tokens_per_block, timestep, rotary_base):
+    """single_query_attention (KV4 + zeros, neox RoPE): the split partials, then the merge as a wide kernel writing the
+    fp16 [B, Hq*Dh] output (the values single_query_attention returns) into out_f16 and raising the row maxima of |out|
+    in `amax` -- the input pair of gemm_partial_f16_*."""
+    import ctypes
+    from ..rope import rope_table
+    _lib.require_cuda(out_f16, amax, q, k, v, kv_pointers, lengths)
+    B, Hq, D = q.shape
+    Hkv = k.shape[1]
+    max_ctx = max(int(timestep), 1)
+    table = rope_table(max_ctx + 1, D, float(rotary_base), 1.0, q.device)
+    need = _lib.lib().omni_kv4_decode_workspace_bytes(B, Hq, D, max_ctx)
+    ws = _lib.workspace(need, q.device, "attn")
+    ns = ctypes.c_int(0)
+    rc = _lib.lib().omni_kv4_decode_attention_partial(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), kv_pointers.data_ptr(),
+        lengths.data_ptr(), B, kv_pointers.shape[-1], Hq, Hkv, D, int(tokens_per_block), max_ctx,
+        table.data_ptr(), table.shape[0], ws.data_ptr(), ws.numel(), ctypes.byref(ns), _lib.current_stream())
+    _lib.check(rc, "fused_ext.decode_attention_f16_amax (partials)")
+    ml_bytes = B * Hq * ns.value * 2 * 4
+    rc = _lib.lib().omni_attn_merge_f16_amax(out_f16.data_ptr(), ws.data_ptr(), ws.data_ptr() + ml_bytes, ns.value,
+                                             amax.data_ptr(), B, Hq, _lib.current_stream())
+    _lib.check(rc, "fused_ext.decode_attention_f16_amax (merge)")
+
+
 def prefetch_arm_gemm(weight, M, N, K, mode=0, deferred=False, budget_bytes=24 << 20, blocks=240):
     """Arm the one-shot L2 weight prefetch for the NEXT decode-shape GEMM (include/omniserve_hip.h:
     omni_prefetch_arm_gemm): the next decode-size quant / norm row kernel launched through this library carries
     `blocks` extra workgroups that pull up to `budget_bytes` of `weight` into the L2s.  mode: 0 W4A8 per-channel,
-    1 per-group, 2 W8A8.  budget_bytes <= 0 disarms.  A performance hint only."""
+    1 per-group, 2 W8A8; | 0x10: the GEMM will run as gemm_silu_* (gate / up tile rows paired per workgroup).  budget_bytes <= 0 disarms.  A performance hint only."""
     _lib.require_cuda(weight)
     rc = _lib.lib().omni_prefetch_arm_gemm(weight.data_ptr(), int(M), int(N), int(K), int(mode), int(bool(deferred)),
                                            int(budget_bytes), int(blocks))

@@ -79,6 +79,64 @@ __device__ __forceinline__ int8_t rni_sat_s8(float x) {
   return (int8_t)(int)r;
 }
 
+// silu(x) * y of silu_and_mul (activation_kernels.cu:10-13,84-97): silu in f32, rounded to fp16, times y in f32, rounded
+// to fp16.  The reference is built with --use_fast_math (ex2.approx + approximate division): v_exp_f32 / v_rcp_f32 are
+// the same class of approximation.  ONE definition for every kernel that produces this value (silu_and_mul, the fused
+// SiLU quantiser, the gate_up GEMV's fused epilogue), so they agree bit for bit.
+__device__ __forceinline__ half_t silu_mul_h(half_t a, half_t b) {
+  const float xf = (float)a;
+  const float e = __builtin_amdgcn_exp2f(xf * -1.4426950408889634f);
+  const half_t s = (half_t)(xf * __builtin_amdgcn_rcpf(1.0f + e));
+  return (half_t)((float)s * (float)b);
+}
+
+// four fp16 values (two packed dwords) -> the four int8 codes rni_sat_s8(f32(x) * q), packed little-endian, for a row
+// whose multiplier is q = 127 / max|x| (quant_multiplier below).  2.25 VALU per element instead of 5.75 for the
+// literal rint / NaN test / clamp / convert / pack sequence:
+//   * f32(x) * q is one rounding to f32, as in rni_sat_s8(x * q);
+//   * adding 1.5 * 2^23 rounds that product to an integer half-to-even (the f32 add IS the rounding) and leaves its
+//     two's-complement byte in the low mantissa bits;
+//   * |x| <= max|x| makes |x * q| <= 127 (1 + 2^-23): the saturation can never fire, no clamp;
+//   * NaN products (NaN or inf inputs: inf * 0) keep a NaN through the add, and every NaN this path can produce --
+//     the default NaN and widened fp16 payloads -- has a zero low byte: code 0, which is cvt.rni.sat's NaN -> 0.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float quant_multiplier(float amax) {
+  // 127 / amax; an all-zero row (amax = 0: the reference divides by zero, then 0 * inf = NaN -> code 0) gets 0 so that the
+  // products are 0 -> code 0 without going through NaN
+  return amax == 0.0f ? 0.0f : 127.0f / amax;
+}
+// f32(x) * q in ONE instruction (v_fma_mix_f32 widens the fp16 operand itself; fma(x, q, +0) is the once-rounded product,
+// i.e. v_cvt_f32_f16 + v_mul_f32) -- hipcc emits shift + convert + multiply; and the packed f32 add as written (left to
+// itself the backend splits most of the pairs again).
+__device__ __forceinline__ float mul_f16lo_f32(uint32_t h2, float q) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(q));
+  return r;
+}
+__device__ __forceinline__ float mul_f16hi_f32(uint32_t h2, float q) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(q));
+  return r;
+}
+// (64-bit integer operands: with <2 x float> asm outputs hipcc 7.2 read element 0 for both elements of the result)
+__device__ __forceinline__ uint64_t pk_add_f32_bits(uint64_t a, uint64_t b) {
+  uint64_t r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t quant4_f16(uint32_t h01, uint32_t h23, float q) {
+  constexpr uint64_t magic = 0x4B4000004B400000ull;       // {1.5 * 2^23, 1.5 * 2^23}
+  auto pair = [](float lo, float hi) -> uint64_t {
+    return ((uint64_t)__builtin_bit_cast(uint32_t, hi) << 32) | __builtin_bit_cast(uint32_t, lo);
+  };
+  const uint64_t pa = pk_add_f32_bits(pair(mul_f16lo_f32(h01, q), mul_f16hi_f32(h01, q)), magic);
+  const uint64_t pb = pk_add_f32_bits(pair(mul_f16lo_f32(h23, q), mul_f16hi_f32(h23, q)), magic);
+  // v_perm_b32(S0, S1, sel): selector byte 0-3 -> byte of S1, 4-7 -> byte of S0, 0x0c -> 0x00
+  const uint32_t lo = __builtin_amdgcn_perm((uint32_t)(pa >> 32), (uint32_t)pa, 0x0c0c0400u);
+  const uint32_t hi = __builtin_amdgcn_perm((uint32_t)(pb >> 32), (uint32_t)pb, 0x04000c0cu);
+  return lo | hi;
+}
+
 // cvt.rni.sat.u8.f32
 __device__ __forceinline__ uint32_t rni_sat_u8(float x) {
   float r = __builtin_rintf(x);
@@ -186,6 +244,46 @@ __device__ __forceinline__ float wave_sum64(float v) {
   const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
   return (r0 + r1) + (r2 + r3);
 }
+
+// ---- row maxima handed from the producer of an fp16 activation to the projection that quantises it (fused extension) ----
+// u32 [AMAX_XCC][AMAX_ROWS][AMAX_SUB] holding f32 bit patterns of candidates for max |x| of each activation row
+// (<= 16 rows), zeroed by the caller before the producer runs.  A producer workgroup raises [its XCD][row][sub] with an
+// integer max (non-negative f32 bit patterns order like unsigned integers: exact and order independent).  Every word is
+// only ever touched from ONE XCD, so the read-modify-write can stay in that XCD's L2 (workgroup-scope atomic: no sc1, the
+// L2 is the point of coherence for all CUs of an XCD) instead of going to the memory side, and 448 workgroups x 16 rows
+// finishing together spread over 8 L2s x 4 cache lines each (the first version -- device-scope atomics on 128 words in 4
+// cache lines -- cost the gate_up GEMV 5.5 us of its 15).  The kernel boundary publishes the words to the consumer.
+constexpr int AMAX_XCC = 8, AMAX_ROWS = 16, AMAX_SUB = 8;
+constexpr int AMAX_WORDS = AMAX_XCC * AMAX_ROWS * AMAX_SUB;      // 4 KiB per activation tensor
+
+__device__ __forceinline__ int xcc_id() {
+  uint32_t v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return (int)(v & (AMAX_XCC - 1));
+}
+__device__ __forceinline__ void amax_raise(uint32_t* amax, int row, int sub, float v) {
+  uint32_t* w = amax + ((size_t)xcc_id() * AMAX_ROWS + row) * AMAX_SUB + (sub & (AMAX_SUB - 1));
+  __hip_atomic_fetch_max(w, __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// wave-cooperative read: every lane gets max |x| of row (lane & 15).  Lane l reads the 8 candidates of its row from XCDs
+// 2 * (l >> 4) and 2 * (l >> 4) + 1 (four 16-B loads), the four lanes of a row meet through the permlane swaps.
+// Split into issue (loads only) and finish so that a caller can put other loads in flight before it waits.
+struct AmaxRaw { uint4 a0, a1, b0, b1; };
+__device__ __forceinline__ AmaxRaw amax_rows_issue(const uint32_t* amax) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t* base = amax + ((size_t)(2 * (lane >> 4)) * AMAX_ROWS + (lane & 15)) * AMAX_SUB;
+  AmaxRaw r;
+  r.a0 = *reinterpret_cast<const uint4*>(base); r.a1 = *reinterpret_cast<const uint4*>(base + 4);
+  r.b0 = *reinterpret_cast<const uint4*>(base + AMAX_ROWS * AMAX_SUB);
+  r.b1 = *reinterpret_cast<const uint4*>(base + AMAX_ROWS * AMAX_SUB + 4);
+  return r;
+}
+__device__ __forceinline__ float amax_rows_finish(const AmaxRaw& r) {
+  const uint32_t ma = max(max(max(r.a0.x, r.a0.y), max(r.a0.z, r.a0.w)), max(max(r.a1.x, r.a1.y), max(r.a1.z, r.a1.w)));
+  const uint32_t mb = max(max(max(r.b0.x, r.b0.y), max(r.b0.z, r.b0.w)), max(max(r.b1.x, r.b1.y), max(r.b1.z, r.b1.w)));
+  return rows4_max(__builtin_bit_cast(float, max(ma, mb)));
+}
+__device__ __forceinline__ float amax_rows_wave(const uint32_t* amax) { return amax_rows_finish(amax_rows_issue(amax)); }
 
 // ---- L2 weight prefetch riding on a latency-bound row kernel (fused extension) -------------------
 // The decode step alternates bandwidth-bound GEMVs with row kernels (norm / quant: 16 workgroups, pure latency

@@ -28,12 +28,7 @@ constexpr int VPT = 16;  // elements per thread held in registers: hidden <= 163
 // (activation_kernels.cu:10-13,84-97).  The reference is built with --use_fast_math, i.e. ex2.approx and an
 // approximate division, so its f32 intermediate is not bit-defined; v_exp_f32 / v_rcp_f32 are the same class
 // of approximation (<= 1 fp16 ulp from the exact value after rounding; tests allow 2).
-__device__ __forceinline__ half_t silu_mul_h(half_t a, half_t b) {
-  const float xf = (float)a;
-  const float e = __builtin_amdgcn_exp2f(xf * -1.4426950408889634f);
-  const half_t s = (half_t)(xf * __builtin_amdgcn_rcpf(1.0f + e));
-  return (half_t)((float)s * (float)b);
-}
+// (silu_mul_h lives in common.h: the gate_up GEMV's fused epilogue uses the same function)
 
 struct PlainLoader {   // x[i] of a contiguous fp16 row
   const half_t* row;
@@ -425,7 +420,7 @@ struct SrcAttnMerge {  // merged decode-attention output (flash-decoding partial
     }
     const float inv = 1.0f / (l + 1e-6f);
 #pragma unroll
-    for (int e = 0; e < VT; ++e) x[e] = (float)(half_t)(o[e] * inv);   // = kv4_decode_merge_kernel's fp16 output
+    for (int e = 0; e < VT; ++e) x[e] = (float)(half_t)rounded_f32(o[e] * inv);   // = kv4_decode_merge_kernel's fp16 output
   }
 };
 
@@ -1024,6 +1019,57 @@ extern "C" int omni_attn_merge_quant_fuse_sum(void* out_i8, const void* part_ml_
     OMNI_V2_LAUNCH(KQ_, batch, hidden, hidden, (int8_t*)out_i8, src, (half_t*)nullptr,
                    (half_t*)scale_f16, hidden, nv);
   }
+  return omni_launch_status();
+}
+
+// Fused extension (row-kernel-free decode layer): the flash-decoding merge alone, as a WIDE kernel -- one thread per 8
+// output elements, no block reduction -- writing the fp16 attention output (the values omni_kv4_decode_attention
+// returns) and raising the row maxima of |out| in amax_slots (integer atomicMax on the f32 bits: exact, order
+// independent).  The o projection then quantises on the fly (omni_w4a8_per_chn_gemm_partial_f16).  Carries the armed L2
+// prefetch like the row kernels do.
+__global__ __launch_bounds__(256) void attn_merge_f16_kernel(half_t* __restrict__ out, SrcAttnMerge src0,
+                                                             uint32_t* __restrict__ amax, int batch, int hidden,
+                                                             PrefetchArgs pf) {
+  __shared__ __attribute__((aligned(16))) uint8_t dma_scratch[4 * 1024];
+  if (pf.blocks > 0 && (int)blockIdx.x >= pf.first_block) {
+    prefetch_weights_to_l2(pf, dma_scratch);
+    return;
+  }
+  const int tpt = hidden / VT;                                  // threads per token (a multiple of 64)
+  const int gt = blockIdx.x * 256 + threadIdx.x;
+  const int token = gt / tpt;
+  if (token >= batch) return;                                    // (whole waves: tpt % 64 == 0)
+  const int i = (gt - token * tpt) * VT;
+  const SrcAttnMerge src = src0.at_row(token);
+  SrcAttnMerge::Raw raw;
+  float x[VT];
+  src.fetch(i, raw);
+  src.finish(i, raw, x);
+  v8h o;
+  float mx = 0.0f;
+#pragma unroll
+  for (int e = 0; e < VT; ++e) {
+    o[e] = (half_t)x[e];                                         // x[e] is already an fp16 value
+    mx = __builtin_fmaxf(mx, __builtin_fabsf(x[e]));
+  }
+  *reinterpret_cast<v8h*>(out + (size_t)token * hidden + i) = o;
+  mx = wave_max64(mx);
+  if ((threadIdx.x & 63) == 0) amax_raise(amax, token, i >> 9, mx);
+}
+
+extern "C" int omni_attn_merge_f16_amax(void* out_f16, const void* part_ml_f32, const void* part_o_f32, int nsplit,
+                                        void* amax_slots_u32, int batch, int num_heads, void* stream) {
+  if (!out_f16 || !part_ml_f32 || !part_o_f32 || !amax_slots_u32 || nsplit < 1 || batch < 0 || num_heads < 1)
+    return OMNI_EINVAL;
+  if (num_heads % 4 != 0 || batch > AMAX_ROWS) return OMNI_EINVAL;   // a wave (512 elements) must not straddle two tokens
+  if (batch == 0) return OMNI_OK;
+  const int hidden = num_heads * 128;
+  PrefetchArgs pf = take_armed_prefetch();
+  const int wgs = (batch * (hidden / VT) + 255) / 256;
+  pf.first_block = wgs;
+  SrcAttnMerge src{(const float*)part_ml_f32, (const float*)part_o_f32, nsplit, num_heads, 0};
+  hipLaunchKernelGGL(attn_merge_f16_kernel, dim3(wgs + pf.blocks), dim3(256), 0, (hipStream_t)stream, (half_t*)out_f16,
+                     src, (uint32_t*)amax_slots_u32, batch, hidden, pf);
   return omni_launch_status();
 }
 

@@ -717,7 +717,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       L += pc;
     }
     if constexpr (DIRECT) {
-      p.out[((size_t)b * p.num_heads + hq0 + g) * DH + d] = (half_t)(acc * (1.0f / (L + 1e-6f)));
+      p.out[((size_t)b * p.num_heads + hq0 + g) * DH + d] = (half_t)rounded_f32(acc * (1.0f / (L + 1e-6f)));   // (two roundings: see kv4_decode_merge_kernel)
     } else {
       const size_t pi = ((size_t)b * p.num_heads + hq0 + g) * p.nsplit + split;
       p.part_o[pi * DH + d] = acc;
@@ -822,7 +822,10 @@ __global__ __launch_bounds__(128) void kv4_decode_merge_kernel(half_t* __restric
     l += w * part_ml[(bh * nsplit + s) * 2 + 1];
     o += w * part_o[(bh * nsplit + s) * DH + d];
   }
-  out[bh * DH + d] = (half_t)(o * (1.0f / (l + 1e-6f)));
+  // rounded_f32: product rounded to f32, then to fp16 (two roundings, as the reference's float -> half store); left alone
+  // the backend folds the multiply into v_fma_mixlo_f16 (ONE rounding) here but not in the fused merge of
+  // elementwise.hip (SrcAttnMerge), and the two paths disagree on ~2^-13 of the elements
+  out[bh * DH + d] = (half_t)rounded_f32(o * (1.0f / (l + 1e-6f)));
 }
 
 struct DecodePlan {

@@ -20,6 +20,8 @@
 //    fp16 results are bit-identical to oracle/w4a8.py.
 #pragma once
 #include "common.h"
+#include "row_reduce.h"
+#include <cstdlib>
 
 namespace omni {
 
@@ -45,7 +47,18 @@ struct GemmArgs {
   int64_t out_stride;
   int kslice;             // k per split (multiple of 64)
   int tiles_m, tiles_n;   // > 0: 1-D grid with the XCD-aware tile order of w4a8_gemm_kernel
+  // ---- row-kernel-free decode forms (fused extension; see w4a8_gemv_kernel EPI / A16) ----
+  const half_t* A16;      // [M,K] fp16 activations quantised on the fly (A16 kernels; `A` unused)
+  uint32_t* amax;         // [AMAX_WORDS] row-maximum candidates (common.h): EPI = 1 raises them, A16 reads them
+  half_t* sum_out;        // [M] A16 rider outputs: the reference-ordered fp16 row sum (NULL = not wanted) ...
+  half_t* scale_out;      // [M] ... and h(amax / 127)
+  int dbg;                // timing experiments (OMNI_GEMV_DBG; wrong results): 1 no rider work, 2 no conversion, 4 no row-maximum atomics
 };
+static inline int gemv_dbg_flags() {
+  static const int v = [] { const char* e = getenv("OMNI_GEMV_DBG"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 
 // per-byte add mod 256 (CUDA __vadd4)
 __device__ __forceinline__ uint32_t vadd4(uint32_t x, uint32_t y) {
@@ -442,6 +455,34 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   }
 }
 
+// Rider workgroup of the fp16-input GEMV (A16): activation row blockIdx.x.  Replays invoke_quant_fuse_sum's row sum --
+// thread t of min(K, 1024) virtual threads adds x[t], x[t + nv], ... in f32, then the 32-lane / 32-warp butterflies
+// (fused_kernels.cu:108-127, reduction_utils.cuh:47-85) -- with the machinery the row kernels use (row_reduce.h), so the
+// fp16 sum equals omni_quant_fuse_sum's bit for bit; scale = h(amax / 127) from the producer's row maximum.
+template <int NTHR>
+__device__ __forceinline__ void a16_rider(const GemmArgs& p, float* xs, float* red) {
+  const int row = blockIdx.x;
+  if (row >= p.M) return;
+  const int hidden = p.K;
+  const int nv = hidden < 1024 ? hidden : 1024;
+  const int t = threadIdx.x;
+  const half_t* x = p.A16 + (size_t)row * p.K;
+  const float rowmax = amax_rows_wave(p.amax);      // (every wave reads all 16 rows; lane `row` of each holds this row's)
+  for (int i = t * VT; i < hidden; i += NTHR * VT) {
+    const v8h v = *reinterpret_cast<const v8h*>(x + i);
+    *reinterpret_cast<v4f*>(xs + i) = (v4f){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    *reinterpret_cast<v4f*>(xs + i + 4) = (v4f){(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+  }
+  __syncthreads();
+  float s[1][VT], tot[1];
+  ordered_partials<1>(xs, t, nv, hidden, s, [](float (&v)[1][VT], int e, float val) { v[0][e] = v[0][e] + val; });
+  tree_sum8<1>(s, red, t, nv >> 5, tot);
+  if (t == row) {                                   // (row < 16 <= 64: a lane of wave 0)
+    if (p.sum_out) p.sum_out[row] = (half_t)tot[0];
+    p.scale_out[row] = (half_t)(rowmax / 127.0f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Decode-shape kernel (M <= 128): pure weight streaming.
 //   * each wave keeps a ring of RING k-steps (RING x 2 KiB) of packed weights in flight: the
@@ -488,9 +529,22 @@ struct GemvCfg {
 // MZ = 2 (M = 65..128): the workgroup carries BOTH 64-row tiles of its channel group -- waves (kw, half) -- so the two
 // reads of a weight byte are issued side by side by waves of one CU (the second is served by L1 / the in-flight line in
 // L2) instead of by two workgroups somewhere on the chip at different times.
-template <int MB, int MODE, bool TO_SLAB, int KW = 1, bool NT = true, int MZ = 1>
-__global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 4 && KW == 4 && MZ == 1) ? 2 : 1)) void w4a8_gemv_kernel(GemmArgs p) {
+// EPI = 1 (gate_up projection, fused extension): the wave's two tile rows are tile row g of the GATE half and tile row g
+// of the UP half (instead of two consecutive ones), so lane l < 32 finishes gate channel c of row m and lane l + 32 the
+// matching up channel: the epilogue rounds both to fp16 exactly as the plain kernel stores them, exchanges them across
+// the wave halves, applies silu_and_mul's arithmetic and stores act[M, N/2] -- the fp16 tensor silu_and_mul would have
+// written -- plus the row maxima of |act| (integer atomicMax on the f32 bits: exact and order independent).
+// A16 = true (o / down projection, fused extension): the int8 codes are produced on the fly from fp16 activations and
+// the row maxima the producer left in `amax` (code = rni_sat(x * (127 / amax)), invoke_quant's arithmetic,
+// fused_kernels.cu:126-131); the first grid row (blockIdx.y == 0) are RIDER workgroups, one per activation
+// row, which replay the reference's ordered row sum (fused_kernels.cu:108-127) and write sum / scale for the consumer
+// of the slabs.  Together they remove the quant row kernel between two GEMVs, bit for bit.
+template <int MB, int MODE, bool TO_SLAB, int KW = 1, bool NT = true, int MZ = 1, int EPI = 0, bool A16 = false>
+__global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), (((MB == 4 && KW == 4 && MZ == 1) || A16) ? 2 : 1)) void w4a8_gemv_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
+  static_assert(EPI == 0 || (MODE != MODE_W8 && !TO_SLAB && MZ == 1), "SiLU epilogue: int4 tile layout, in-kernel epilogue");
+  static_assert(!A16 || (TO_SLAB && MZ == 1 && MB == 1 && GemvCfg<MB, MODE>::WAVES == 1), "fp16-input form: slab output, one 16-row single-wave tile");
+  static_assert(EPI == 0 || MB == 1, "row-maximum hand-off covers 16 rows");
   constexpr int WAVES = GemvCfg<MB, MODE>::WAVES;
   static_assert(KW == 1 || WAVES == 1, "in-workgroup K split is for single-wave tiles");
   static_assert(KW <= GemvCfg<MB, MODE>::MAX_KW, "LDS budget");
@@ -506,7 +560,15 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
   constexpr int APT = (MT * RK / 16) / NTHREADS;          // 16-B activation pieces per thread per round
   static_assert((MT * RK / 16) % NTHREADS == 0, "activation round must tile the workgroup");
   __shared__ __attribute__((aligned(16))) uint8_t lds_all[KW * MZ][2][MT * RK];
+  __shared__ float epi_red[A16 ? 96 : 1];   // A16 rider: scratch of the reduction tree
 
+  if constexpr (A16) {
+    if (blockIdx.y == 0) {      // rider workgroups (dispatched first): ordered row sum + scale of activation row blockIdx.x
+      if (!(p.dbg & 1)) a16_rider<64 * KW>(p, reinterpret_cast<float*>(&lds_all[0][0][0]), epi_red);
+      return;
+    }
+  }
+  const int by = A16 ? (int)blockIdx.y - 1 : (int)blockIdx.y;     // K slice of this workgroup
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int half = MZ > 1 ? wave / KW : 0;                // row tile of this wave inside the workgroup
@@ -517,7 +579,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
   const int m0 = (blockIdx.z * MZ + half) * MT;          // row tile (M > 64: grid.z = 2, or both tiles in the workgroup)
   const bool wave_active = (ng * 64) < p.N;
   const int kpart = p.kslice / KW;                        // host: kslice % (64 * KW) == 0 when KW > 1
-  const int k_begin = blockIdx.y * p.kslice + kw * kpart;
+  const int k_begin = by * p.kslice + kw * kpart;
   const int k_end = min(p.K, k_begin + kpart);
   const int nsteps = (k_end - k_begin) / KSTEP;
   const int rounds = nsteps / RING;
@@ -528,8 +590,11 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
   const uint8_t* wbase;
   // (W8A8: the operand lane map is kept here -- the row-coalesced fetch + LDS transpose of w4a8_gemm_kernel measured no
   //  gain at M = 1: this kernel waits on HBM latency, not on the L1's 15 B/clk)
+  // tile row (32 channels) this lane streams: two consecutive rows of the 64-channel group, or (EPI = 1) row ngc of the
+  // gate half and row ngc of the up half
+  const int trow = EPI == 1 ? (lx ? p.N / 64 + ngc : ngc) : 2 * ngc + lx;
   if constexpr (MODE == MODE_W8) wbase = p.W + (size_t)(ngc * 64 + (lane & 15)) * p.K + (lane >> 4) * 16;
-  else wbase = p.W + ((size_t)(2 * ngc + lx) * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
+  else wbase = p.W + ((size_t)trow * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
   auto load_w = [&](int k, int j) -> uint4 {
     const uint8_t* ptr;
     if constexpr (MODE == MODE_W8) ptr = wbase + (size_t)j * 16 * p.K + k;
@@ -539,7 +604,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
     else v = *reinterpret_cast<const v4i*>(ptr);
     return make_uint4((uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
   };
-  const size_t gcol = (size_t)(2 * ngc + lx) * 32 + lc * 4;  // per-group param column of this lane
+  const size_t gcol = (size_t)trow * 32 + lc * 4;  // per-group param column of this lane
   auto load_gp = [&](const uint8_t* base, int k) -> uint32_t {
     return *reinterpret_cast<const uint32_t*>(base + (size_t)(k / 128) * p.N + gcol);
   };
@@ -559,14 +624,42 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
       kk = id % (RK / 16);
     }
   };
-  uint4 areg[APT];
+  uint4 areg[A16 ? 1 : APT];
+  uint4 araw[A16 ? APT : 1][2];      // A16: the 16 fp16 values behind each 16-code piece
+  float qrow[A16 ? APT : 1];         // A16: 127 / amax of the row of piece j (rows do not change from round to round)
+  float qlane = 0.0f;                // A16: 127 / amax of row (lane & 15)
+  AmaxRaw amax_raw;                  // A16: requested at kernel start, consumed after the weight ring is in flight
+  if constexpr (A16) amax_raw = amax_rows_issue(p.amax);
+  auto compute_q = [&]() {
+    // (pins the reduction of the candidates HERE: called from two places, the optimiser otherwise hoists the common
+    //  code -- and the wait for these loads -- to the top of the kernel, in front of every other request)
+    asm volatile("" : "+v"(amax_raw.a0.x), "+v"(amax_raw.a0.y), "+v"(amax_raw.a0.z), "+v"(amax_raw.a0.w),
+                      "+v"(amax_raw.a1.x), "+v"(amax_raw.a1.y), "+v"(amax_raw.a1.z), "+v"(amax_raw.a1.w),
+                      "+v"(amax_raw.b0.x), "+v"(amax_raw.b0.y), "+v"(amax_raw.b0.z), "+v"(amax_raw.b0.w),
+                      "+v"(amax_raw.b1.x), "+v"(amax_raw.b1.y), "+v"(amax_raw.b1.z), "+v"(amax_raw.b1.w));
+    qlane = quant_multiplier(amax_rows_finish(amax_raw));
+#pragma unroll
+    for (int j = 0; j < APT; ++j) {
+      if (QUAD_ROWS && (j % CPR) != 0) { qrow[j] = qrow[j > 0 ? j - 1 : 0]; continue; }   // same row as the previous piece
+      int m, kk;
+      piece(j, m, kk);
+      const int mc = m0 + m < p.M ? m0 + m : p.M - 1;
+      qrow[j] = __shfl(qlane, mc & 15, 64);
+    }
+  };
   auto load_a = [&](int kr) {  // kr = first k of the round
 #pragma unroll
     for (int j = 0; j < APT; ++j) {
       int m, kk;
       piece(j, m, kk);
       const int mc = m0 + m < p.M ? m0 + m : p.M - 1;  // rows >= M re-read the last row (results never stored)
-      areg[j] = *reinterpret_cast<const uint4*>(p.A + (size_t)mc * p.K + kr + kk * 16);
+      if constexpr (A16) {
+        const half_t* src = p.A16 + (size_t)mc * p.K + kr + kk * 16;
+        araw[j][0] = *reinterpret_cast<const uint4*>(src);
+        araw[j][1] = *reinterpret_cast<const uint4*>(src + 8);
+      } else {
+        areg[j] = *reinterpret_cast<const uint4*>(p.A + (size_t)mc * p.K + kr + kk * 16);
+      }
     }
   };
   auto store_a = [&](int buf) {
@@ -574,17 +667,26 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
     for (int j = 0; j < APT; ++j) {
       int m, kk;
       piece(j, m, kk);
+      uint4 av;
+      if constexpr (A16) {
+        if (p.dbg & 2) av = make_uint4(araw[j][0].x ^ araw[j][1].x, araw[j][0].y ^ araw[j][1].y, araw[j][0].z ^ araw[j][1].z, araw[j][0].w ^ araw[j][1].w);
+        else
+        av = make_uint4(quant4_f16(araw[j][0].x, araw[j][0].y, qrow[j]), quant4_f16(araw[j][0].z, araw[j][0].w, qrow[j]),
+                        quant4_f16(araw[j][1].x, araw[j][1].y, qrow[j]), quant4_f16(araw[j][1].z, araw[j][1].w, qrow[j]));
+      } else {
+        av = make_uint4(areg[j].x, areg[j].y, areg[j].z, areg[j].w);
+      }
       if constexpr (MODE == MODE_W8) {
         *reinterpret_cast<uint4*>(&lds[buf][((kk >> 2) * MT + m) * 64 + (kk & 3) * 16]) =
-            make_uint4(areg[j].x, areg[j].y, areg[j].z, areg[j].w);   // component-wise: keeps areg in VGPRs
+            make_uint4(av.x, av.y, av.z, av.w);   // component-wise: keeps the staging registers in VGPRs
       } else {
         // dword e of the piece goes to 16-B slot (e + kp) & 3 of row (kp, m): see w4a8_gemm_kernel
         const int kp = kk >> 2, tp = (kk >> 1) & 1, d = kk & 1;
         uint8_t* dst = &lds[buf][(kp * MT + m) * 64 + tp * 8 + d * 4];
-        *reinterpret_cast<uint32_t*>(dst + ((0 + kp) & 3) * 16) = areg[j].x;
-        *reinterpret_cast<uint32_t*>(dst + ((1 + kp) & 3) * 16) = areg[j].y;
-        *reinterpret_cast<uint32_t*>(dst + ((2 + kp) & 3) * 16) = areg[j].z;
-        *reinterpret_cast<uint32_t*>(dst + ((3 + kp) & 3) * 16) = areg[j].w;
+        *reinterpret_cast<uint32_t*>(dst + ((0 + kp) & 3) * 16) = av.x;
+        *reinterpret_cast<uint32_t*>(dst + ((1 + kp) & 3) * 16) = av.y;
+        *reinterpret_cast<uint32_t*>(dst + ((2 + kp) & 3) * 16) = av.z;
+        *reinterpret_cast<uint32_t*>(dst + ((3 + kp) & 3) * 16) = av.w;
       }
     }
   };
@@ -603,6 +705,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
   const int i0 = (lane >> 4) * 4;
   auto chan = [&](int ab) -> int {
     if constexpr (MODE == MODE_W8) return ng * 64 + ab * 16 + i0;
+    else if constexpr (EPI == 1) return (i0 >> 3) * (p.N / 2) + ng * 32 + ab * 8 + (i0 & 7);   // gate | up channel
     else return ng * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
   };
   uint2 swv[ABW], szv[ABW];
@@ -666,6 +769,10 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
   uint32_t gs[RING], gz[RING];
   if (rounds > 0) {
     // ---- prologue: ring for round 0 in flight, activations of round 0 into LDS ----------------
+    // (A16: the fp16 activations are requested BEFORE the weights -- loads return in order, so they are back from L2
+    //  while the ring is still in flight from HBM and the int8 conversion (~800 VALU per wave) runs under the weights'
+    //  flight time; requested after the ring, it sat exposed behind the last weight byte: +1.5 us per launch)
+    if constexpr (A16) load_a(k_begin);
 #pragma unroll
     for (int s = 0; s < RING; ++s) {
 #pragma unroll
@@ -675,7 +782,13 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
         gz[s] = load_gp(p.s2z, k_begin + s * KSTEP);
       }
     }
-    load_a(k_begin);
+    if constexpr (!A16) load_a(k_begin);
+    if constexpr (A16) {
+      // (first wait of the kernel: the row maxima, requested before everything else.  The fence keeps the scheduler from
+      //  hoisting their reduction -- and with it a vmcnt(0) -- in front of the activation and weight requests)
+      __builtin_amdgcn_sched_barrier(0);
+      compute_q();
+    }
     store_a(0);
     if constexpr (WAVES > 1) __syncthreads();
     // ---- steady state ---------------------------------------------------------------------------
@@ -730,13 +843,24 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
     }
   }
   // ---- leftovers (nsteps % RING): one step at a time, unpipelined (planner avoids this) ------------
+  if constexpr (A16) {
+    if (rounds == 0) compute_q();
+  }
   for (int st = rounds * RING; st < nsteps; ++st) {
     const int kn = k_begin + st * KSTEP;
     if constexpr (WAVES > 1) __syncthreads();
     for (int id = tid; id < MT * 4; id += NTHREADS) {
       const int m = id >> 2, kk = id & 3;
       const int mc = m0 + m < p.M ? m0 + m : p.M - 1;
-      const uint4 a = *reinterpret_cast<const uint4*>(p.A + (size_t)mc * p.K + kn + kk * 16);
+      uint4 a;
+      if constexpr (A16) {
+        const half_t* src = p.A16 + (size_t)mc * p.K + kn + kk * 16;
+        const uint4 r0 = *reinterpret_cast<const uint4*>(src), r1 = *reinterpret_cast<const uint4*>(src + 8);
+        const float q = __shfl(qlane, mc & 15, 64);
+        a = make_uint4(quant4_f16(r0.x, r0.y, q), quant4_f16(r0.z, r0.w, q), quant4_f16(r1.x, r1.y, q), quant4_f16(r1.z, r1.w, q));
+      } else {
+        a = *reinterpret_cast<const uint4*>(p.A + (size_t)mc * p.K + kn + kk * 16);
+      }
       if constexpr (MODE == MODE_W8) {
         *reinterpret_cast<uint4*>(&lds[0][m * 64 + kk * 16]) = a;
       } else {
@@ -773,6 +897,9 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
       for (int ab = 0; ab < 4; ++ab) mine[(mb * 4 + ab) * 64 + lane] = acc[mb][ab];
     __syncthreads();
   }
+  float rowmax[MB];     // EPI = 1: max |act| of row (mb, lane & 15) over the channels this lane finished
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) rowmax[mb] = 0.0f;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m = m0 + mb * 16 + mcol;
@@ -790,7 +917,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
       if (m >= p.M) continue;
       const int n = chan(ab);
       if constexpr (TO_SLAB) {
-        int32_t* dst = p.slab + ((size_t)blockIdx.y * p.M + m) * p.N + n;
+        int32_t* dst = p.slab + ((size_t)by * p.M + m) * p.N + n;
         *reinterpret_cast<v4i*>(dst) = a4;
       } else {
         typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
@@ -803,9 +930,46 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), ((MB == 
         half_t o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = epilogue<MODE>(a4[r], (float)sw4[r], sa, (float)sz4[r], as);
-        *reinterpret_cast<uint2*>(p.out + (size_t)m * p.out_stride + n) =
-            *reinterpret_cast<const uint2*>(o);
+        if constexpr (EPI == 1) {
+          // lanes < 32 hold the fp16 gate outputs, lanes >= 32 the up outputs of the same (row, 4 channels)
+          const uint2 mine = *reinterpret_cast<const uint2*>(o);
+          const uint2 other = make_uint2((uint32_t)__shfl_xor((int)mine.x, 32, 64), (uint32_t)__shfl_xor((int)mine.y, 32, 64));
+          const uint2 g2 = lane < 32 ? mine : other, u2 = lane < 32 ? other : mine;
+          typedef _Float16 v4h_t2 __attribute__((ext_vector_type(4)));
+          const v4h_t2 g4 = __builtin_bit_cast(v4h_t2, g2), u4 = __builtin_bit_cast(v4h_t2, u2);
+          half_t act[4];
+          float mx = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            act[r] = silu_mul_h(g4[r], u4[r]);
+            mx = __builtin_fmaxf(mx, __builtin_fabsf((float)act[r]));
+          }
+          rowmax[mb] = __builtin_fmaxf(rowmax[mb], mx);
+          if (lane < 32)
+            *reinterpret_cast<uint2*>(p.out + (size_t)m * p.out_stride + (ng * 32 + ab * 8 + (i0 & 7))) =
+                *reinterpret_cast<const uint2*>(act);
+        } else {
+          *reinterpret_cast<uint2*>(p.out + (size_t)m * p.out_stride + n) =
+              *reinterpret_cast<const uint2*>(o);
+        }
       }
+    }
+  }
+  if constexpr (EPI == 1) {
+    // row maxima: across the lanes of a row (lane & 15), then across the K-part waves, then one atomicMax per row
+    __shared__ float smax[KW][MT];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const float v = rows4_max(rowmax[mb]);
+      if (lane < 16) smax[kw][mb * 16 + lane] = (m0 + mb * 16 + lane) < p.M ? v : 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x < MT) {
+      float v = smax[0][threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < KW; ++w) v = __builtin_fmaxf(v, smax[w][threadIdx.x]);
+      const int m = m0 + threadIdx.x;
+      if (m < p.M && !(p.dbg & 4)) amax_raise(p.amax, m, blockIdx.x >> 3, v);
     }
   }
 }
@@ -958,6 +1122,63 @@ static int launch_gemm(GemmArgs a, void* ws, size_t ws_bytes, hipStream_t st) {
     }
   }
   return omni_launch_status();
+}
+
+// ---- row-kernel-free forms (fused extension) ---------------------------------------------------------------
+template <int MODE, bool NT>
+static int launch_gemv_silu_nt(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
+  dim3 grid(a.N / 64, 1, 1);
+  switch (pl.kw) {
+    case 4: hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, false, 4, NT, 1, 1, false>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, false, 2, NT, 1, 1, false>), grid, dim3(128), 0, st, a); break;
+    default: hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, false, 1, NT, 1, 1, false>), grid, dim3(64), 0, st, a); break;
+  }
+  return omni_launch_status();
+}
+
+// gate_up projection with silu_and_mul fused into the epilogue: out = act fp16 [M, N/2], a.amax raised per row.
+// M <= 16 (the single-wave 16-row tile) and a plan without a grid-level K split (K <= 4096 per workgroup).
+template <int MODE>
+static int launch_gemm_silu(GemmArgs a, hipStream_t st) {
+  if (a.M < 1 || a.M > 16 || a.N % 128 != 0 || a.K % 64 != 0 || a.K < 64 || !a.amax || !a.out) return OMNI_EINVAL;
+  if (MODE == MODE_GRP && a.K % 128 != 0) return OMNI_EINVAL;
+  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64, false, false);
+  if (pl.sk != 1 || pl.mb != 1) return OMNI_EINVAL;
+  a.kslice = pl.kslice;
+  a.dbg = gemv_dbg_flags();
+  return g_weight_policy == 1 ? launch_gemv_silu_nt<MODE, false>(a, pl, st) : launch_gemv_silu_nt<MODE, true>(a, pl, st);
+}
+
+template <int MODE, bool NT>
+static int launch_gemv_f16_nt(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
+  dim3 grid(a.N / 64, pl.sk + 1, 1);     // first grid row: the rider workgroups (one per activation row)
+  switch (pl.kw) {
+    case 4: hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, true, 4, NT, 1, 0, true>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((w4a8_gemv_kernel<1, MODE, true, 2, NT, 1, 0, true>), grid, dim3(128), 0, st, a); break;
+    default: return OMNI_EINVAL;
+  }
+  return omni_launch_status();
+}
+
+// o / down projection from fp16 activations + producer row maxima: int32 split-K slabs (like launch_gemm_partial) plus
+// the sum / scale the slab consumer needs, written by rider workgroups.  M <= 16; K <= 16384 (the rider parks a row
+// as f32 in the workgroup's staging LDS); the row must be whole 8-step rounds per wave.
+template <int MODE>
+static int launch_gemm_partial_f16(GemmArgs a, void* slab, size_t slab_bytes, int* sk_out, hipStream_t st) {
+  if (a.M < 1 || a.M > 16 || a.N % 64 != 0 || a.K % 64 != 0 || a.K < 64 || !slab || !sk_out || !a.A16 || !a.amax ||
+      !a.scale_out)
+    return OMNI_EINVAL;
+  if (MODE == MODE_GRP && a.K % 128 != 0) return OMNI_EINVAL;
+  if (a.N / 64 < a.M) return OMNI_EINVAL;                                   // one rider per row in a grid row of N/64
+  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64, true, false);
+  if (pl.mb != 1 || pl.kw < 2) return OMNI_EINVAL;
+  if ((size_t)a.K * sizeof(float) > (size_t)pl.kw * 2 * 16 * GemvCfg<1, MODE>::AR * KSTEP) return OMNI_EINVAL;   // rider LDS
+  if (slab_bytes < (size_t)pl.sk * a.M * a.N * sizeof(int32_t)) return OMNI_ENOMEM;
+  a.slab = static_cast<int32_t*>(slab);
+  a.kslice = pl.kslice;
+  *sk_out = pl.sk;
+  a.dbg = gemv_dbg_flags();
+  return g_weight_policy == 1 ? launch_gemv_f16_nt<MODE, false>(a, pl, st) : launch_gemv_f16_nt<MODE, true>(a, pl, st);
 }
 
 // Deferred-epilogue variant (fused extension): only the int32 split-K slabs are produced; the consumer

@@ -132,6 +132,11 @@ extern "C" int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, i
   using namespace omni;
   g_armed_prefetch = PrefetchArgs{};
   if (!weight || blocks <= 0 || budget_bytes <= 0) return OMNI_OK;          // disarm
+  // mode | 0x10: the gate_up form with the fused SiLU epilogue (omni_w4a8_per_*_gemm_silu): workgroup x streams tile row x
+  // of the gate half and tile row N/64 + x of the up half
+  const bool silu = (mode & 0x10) != 0;
+  mode &= 0xF;
+  if (silu && (mode == MODE_W8 || deferred || (N / 64) % 8 != 0)) return mode == MODE_W8 ? OMNI_EINVAL : OMNI_OK;
   if (mode < 0 || mode > 2 || M < 1 || M > 128 || N % 64 != 0 || K % 64 != 0 || K < 64) return OMNI_EINVAL;
   const GemmPlan pl = plan_gemm(M, N, K, mode == MODE_GRP ? 128 : 64, deferred != 0, mode == MODE_W8);
   PrefetchArgs pf{};
@@ -154,6 +159,12 @@ extern "C" int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, i
     if (pf.rows_pf < 1 || pf.pf_bytes < 1024) return OMNI_OK;
   } else {
     pf.row_bytes = (long long)K * 16; pf.rows_per_wg = 2 * groups_per_wg;
+    if (silu) {
+      // as 2 * (N/64) single-row workgroups: item v = tile row v is fetched on XCD v % 8, and (N/64) % 8 == 0 makes that
+      // the XCD of the real workgroup v % (N/64) for both of its rows
+      pf.rows_per_wg = 1;
+      pf.gx = N / 32;
+    }
     pf.rows_pf = pf.rows_per_wg;
     const long long part_bytes = pf.row_bytes / ((long long)pf.gy * pf.kw);
     const long long total = pf.row_bytes * pf.rows_per_wg * pf.gx;

@@ -126,6 +126,7 @@ class DecodeRunner:
         o_proj and after down_proj.  shard_full=True builds the full layers from the seed and keeps this
         rank's shards (tests: every rank then holds shards of the SAME model); otherwise only the local shapes
         are drawn (bench: synthetic weights, no point in materialising 70B parameters per rank)."""
+        import os
         self.cfg, self.B, self.device = cfg, batch, device
         self.tp_rank, self.tp_size, self.tp_group = int(tp_rank), int(tp_size), tp_group
         if cfg.heads % self.tp_size or cfg.kv_heads % self.tp_size or cfg.inter % (128 * self.tp_size):
@@ -135,16 +136,23 @@ class DecodeRunner:
         # norm + quant, silu*mul + quant); 2/True = additionally defer the split-K epilogue of o_proj /
         # down_proj into the following add+norm kernel.  All bit-identical to the reference sequence
         # (SURVEY.md 8f.1).
-        self.fused = 2 if fused is True else int(fused)
+        # 3 (default where it applies: batch <= 16, one GPU) = additionally NO quantiser row kernels: the gate_up GEMV
+        # applies silu_and_mul in its epilogue and leaves the row maxima, the attention merge is a wide kernel that
+        # leaves fp16 + row maxima, and o_proj / down_proj quantise their input on the fly (fused_ext.gemm_silu_*,
+        # decode_attention_f16_amax, gemm_partial_f16_*): 7 kernels per layer instead of 9, same bits.
+        self.fused = 3 if fused is True else int(fused)
         if (self.tp_size > 1 or batch > 128) and self.fused > 1:
             # tensor parallel: the all-reduce needs the fp16 projection; batch > 128: the projections run through the
             # prefill tile, which has no slab-only form -- no deferred epilogue in either case
             self.fused = 1
+        if self.fused >= 3 and not (batch <= 16 and max(cfg.heads * cfg.head_dim, cfg.inter) <= 16384 and
+                                    cfg.hidden // 64 >= batch and cfg.heads % 4 == 0 and
+                                    int(os.environ.get("OMNI_FUSED_MAX", "3")) >= 3):
+            self.fused = 2
         # L2 weight prefetch riding on the row kernels (fused extension; a hint, results are unaffected): MiB of the
         # next GEMV's weights each row kernel pulls into the L2s (0 = off), with how many extra workgroups, and
         # whether the GEMVs then use plain instead of non-temporal weight loads.  Defaults: on with the fused
         # entry points (environment overrides for sweeps: OMNI_PREFETCH_MB, OMNI_PREFETCH_BLOCKS, OMNI_WEIGHT_POLICY).
-        import os
         if prefetch_mb is None:
             # measured (profiles/r02_*): +6-7 % at bs = 16 with 28-40 MiB per row kernel (the L2s hold 32 MiB; the
             # excess lands in MALL), nothing at bs = 128, -4 % at bs = 64 where the row kernels are no longer idle
@@ -225,6 +233,13 @@ class DecodeRunner:
         self.proj_buf = torch.empty((B, c.hidden), dtype=f16, device=device)
         self.gate_up_buf = torch.empty((B, 2 * il), dtype=f16, device=device)
         self.mlp_act = torch.empty((B, il), dtype=f16, device=device)
+        self.attn_f16 = torch.empty((B, hl * c.head_dim), dtype=f16, device=device)
+        # row-maximum candidates of the level-3 path: [layer][0 = attention output, 1 = MLP activation][AMAX_WORDS], zeroed once
+        # per step (the producers raise them with atomicMax)
+        self.amax = torch.zeros((c.layers, 2, fused_ext.AMAX_WORDS), dtype=torch.int32, device=device)
+        # the down projection of the level-3 path has no row kernel in front of it to carry an L2 prefetch: its weights
+        # are streamed with non-temporal loads whatever the step's policy says
+        self.down_nt = int(os.environ.get("OMNI_DOWN_NT", "1"))
         self.normed = torch.empty((B, c.hidden), dtype=f16, device=device)
         self.lengths = torch.full((B,), context, dtype=torch.int32, device=device)
         self.tokens = torch.randint(0, c.vocab, (B,), device=device, generator=gen)
@@ -281,6 +296,14 @@ class DecodeRunner:
             return fused_ext.gemm_partial_per_chn(x_i8, lin.qweight, self.slab)
         return fused_ext.gemm_partial_per_group(x_i8, lin.qweight, lin.s2_zeros, lin.s2_scales, self.slab)
 
+    def _partial_f16(self, act, amax, lin, sum_out, scale_out):
+        """Level 3: o_proj / down_proj from fp16 activations + row maxima (codes computed inside the GEMV; sums / scales by
+        rider workgroups): int32 split-K slabs in self.slab, returns the slab count."""
+        if lin.group == -1:
+            return fused_ext.gemm_partial_f16_per_chn(act, amax, lin.qweight, self.slab, sum_out, scale_out)
+        return fused_ext.gemm_partial_f16_per_group(act, amax, lin.qweight, lin.s2_zeros, lin.s2_scales, self.slab,
+                                                    sum_out, scale_out)
+
     def _consume(self, q_out, sk, lin, a_scale, a_sum, gamma, out_sum, out_scale):
         """residual += epilogue(sum of the slabs); norm + quant of it (the GEMM epilogue lives in this row kernel)."""
         if lin.group == -1:
@@ -290,11 +313,12 @@ class DecodeRunner:
             fused_ext.splitk_w8_add_rms_norm_general_fuse_sum(q_out, self.x, self.slab, sk, lin.s1_scales, a_scale, gamma,
                                                               out_sum, out_scale, self.cfg.eps)
 
-    def _arm(self, lin, deferred=False):
-        """The next row kernel prefetches the head of `lin`'s weight stream into the L2s (no-op when disabled)."""
+    def _arm(self, lin, deferred=False, silu=False):
+        """The next row kernel prefetches the head of `lin`'s weight stream into the L2s (no-op when disabled).
+        silu: `lin` will run as fused_ext.gemm_silu_* (gate / up tile rows paired per workgroup)."""
         if self.prefetch_bytes > 0:
-            fused_ext.prefetch_arm_gemm(lin.qweight, self.B, lin.n, lin.k, 0 if lin.group == -1 else 1, deferred,
-                                        self.prefetch_bytes, self.prefetch_blocks)
+            fused_ext.prefetch_arm_gemm(lin.qweight, self.B, lin.n, lin.k, (0 if lin.group == -1 else 1) | (0x10 if silu else 0),
+                                        deferred, self.prefetch_bytes, self.prefetch_blocks)
 
     def _eager_step(self):
         fused_ext.set_weight_policy(self.weight_policy)
@@ -309,6 +333,8 @@ class DecodeRunner:
         # one decoder layer at decode shape = llama_w4a8_unpad.py:406-438
         c = self.cfg
         self.lengths.add_(1)
+        if self.fused >= 3:
+            self.amax.zero_()
         if self.fused:     # (level >= 1: one short kernel; torch's index_select takes 12.6 us for 16 rows)
             fused_ext.embed_rows(self.x, self.embed, self.tokens)
         else:
@@ -340,7 +366,10 @@ class DecodeRunner:
             k = self.qkv_buf[:, hq * d:(hq + hk) * d].view(B, hk, d)
             v = self.qkv_buf[:, (hq + hk) * d:].view(B, hk, d)
             self._arm(L["o"], deferred=self.fused >= 2)      # rides on the quantiser after the attention
-            if self.fused >= 2:     # attention with its split merge fused into the activation quant
+            if self.fused >= 3:     # merge as a wide kernel (fp16 + row maxima); o_proj quantises on the fly
+                fused_ext.decode_attention_f16_amax(self.attn_f16, self.amax[li, 0], q, k, v, self.block_tables[li],
+                                                    self.lengths, self.tpb, self.max_context, c.rope_theta)
+            elif self.fused >= 2:   # attention with its split merge fused into the activation quant
                 fused_ext.decode_attention_quant_fuse_sum(self._q_attn, q, k, v, self.block_tables[li], self.lengths,
                                                           self.tpb, self.max_context, c.rope_theta, mA, sA)
             else:
@@ -352,8 +381,11 @@ class DecodeRunner:
                 else:
                     fused_kernels.invoke_quant(self._q_attn, attn.view(B, hq * d), sA)
             if self.fused >= 2:
-                sk = self._partial(self._q_attn, L["o"])
-                self._arm(L["gate_up"])
+                if self.fused >= 3:
+                    sk = self._partial_f16(self.attn_f16, self.amax[li, 0], L["o"], mA, sA)
+                else:
+                    sk = self._partial(self._q_attn, L["o"])
+                self._arm(L["gate_up"], silu=self.fused >= 3 and li < nl - 1)
                 self._consume(qa_h, sk, L["o"], sA, mA, L["ln2"], mB, sB)
             else:
                 L["o"].forward(self._q_attn, sA, mA, self.proj_buf)
@@ -367,6 +399,21 @@ class DecodeRunner:
                         layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln2"], mB, sB, c.eps, True)
                     else:
                         layernorm_ops.rms_norm_general(qa_h, self.x, L["ln2"], sB, c.eps, True)
+            if self.fused >= 3 and li < nl - 1:
+                # gate_up with silu_and_mul in its epilogue -> fp16 activation + row maxima; down_proj quantises on the fly
+                G = L["gate_up"]
+                if per_chn:
+                    fused_ext.gemm_silu_per_chn(qa_h, G.qweight, G.s1_scales, sB, G.s1_szeros, mB, self.mlp_act,
+                                                self.amax[li, 1])
+                else:
+                    fused_ext.gemm_silu_per_group(qa_h, G.qweight, G.s2_zeros, G.s2_scales, G.s1_scales, sB,
+                                                  self.mlp_act, self.amax[li, 1])
+                if self.down_nt and self.weight_policy:
+                    fused_ext.set_weight_policy(0)
+                pending = (self._partial_f16(self.mlp_act, self.amax[li, 1], L["down"], mA, sA), L["down"])
+                if self.down_nt and self.weight_policy:
+                    fused_ext.set_weight_policy(self.weight_policy)
+                continue
             L["gate_up"].forward(qa_h, sB, mB, self.gate_up_buf)
             self._arm(L["down"], deferred=self.fused >= 2 and li < nl - 1)
             if self.fused:
