@@ -12,11 +12,13 @@ its own 16 sequences (independent replicas of the TP=1 config: weak scaling, no 
 collective); value = tokens decoded by all ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel = the gate_up W4A8 GEMV (N=28672, K=4096, M=16): algorithmic
-                bytes (packed weights + activations + output) / average duration measured with
-                HIP events on the launch stream, weights rotated over all 32 layers (1.9 GB) so
-                nothing is cache resident and NO L2 prefetch runs.  peak = 8 TB/s (MI355X HBM3E).
-                `gemv_aggregate` = the same for the four projections of a layer together.
+  roofline      dominant kernel = the gate_up W4A8 GEMV (N=28672, K=4096, M=16) in the form the step runs
+                it (fusion level 3: with the silu_and_mul epilogue): algorithmic bytes (packed weights +
+                activations + output) / average duration measured with HIP events on the launch stream,
+                weights rotated over all 32 layers (1.9 GB) so nothing is cache resident and NO L2
+                prefetch runs.  peak = 8 TB/s (MI355X HBM3E).  `gemv_aggregate` = the four projections of
+                a layer together, `attention` = the KV4 decode attention of a layer vs 1088*T*B bytes,
+                `step` = the whole decode step vs weights + KV + lm_head bytes.
   drop_in       the same decode step through the REFERENCE call sequence only (no fused extension
                 entry points, no HIP graph, no prefetch): what an unmodified reference host stack
                 would get from the mirror.
@@ -25,7 +27,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
   configs2_g128_bs64   BASELINE.json configs[2]: g128 weights, batch 64 (decode step + protocol).
   cpu_baseline  the oracle restatement of the per-channel GEMMs of one decoder layer at bs=16
                 (torch._int_mm on the host cores) extrapolated to a full step -- a reported
-                baseline, not a target.
+                baseline, not a target; `gemm_4096` = BASELINE.json configs[0] on the host (8 threads, 1 thread).
   w4a8_gemm_4096  BASELINE.json configs[0] shape on the GPU: int8 TOPS vs the 5 PFLOP/s dense
                 int8 MFMA peak.
 """
@@ -43,16 +45,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_ACHIEVABLE_GBS = 6300.0  # same guide, "8 TB/s peak (spec); ~6.3 TB/s achievable"
 INT8_PEAK_TOPS = 5000.0     # dense int8 MFMA
-# (M, N, K, group) -> HBM bytes per launch of the decode GEMV measured with rocprofv3 --pmc (separate FETCH_SIZE /
-# WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide streaming reads on gfx950).  Taken
-# from the committed profile, NOT re-measured by the run that prints it (PMC collection wraps the process).
-PMC_TRAFFIC_BYTES = {(16, 28672, 4096, -1): 60430000}
-# The same kernel INSIDE the captured decode step (rocprofv3 --kernel-trace of this command, profiles/r02_g_*): the preceding
-# row kernel has pulled the head of its weight stream into L2, so the launch is shorter than the isolated one timed below.
-# Reported next to the isolated figure (which is what `achieved` / `frac` are computed from), not instead of it.
-IN_STEP_US = {(16, 28672, 4096, -1): 9.7}
-IN_STEP_SOURCE = "profiles/r02_g_decode_by_kernel_final.md (rocprofv3 of `bench.py --steps 32 --warmup 4 --no-extras`, 1184 launches, prefetch 40 MiB)"
-PMC_TRAFFIC_SOURCE = "profiles/r02_b_pmc_traffic_four_gemvs.md (separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes over this kernel, not this run)"
+# Numbers that only a profiler run can produce -- the dominant kernel's HBM traffic per launch (rocprofv3 --pmc, separate
+# FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and its duration INSIDE
+# the captured decode step (rocprofv3 --kernel-trace) -- are read from the JSON the profiling script writes
+# (tools/r03_profile.sh -> tools/make_bench_constants.py -> profiles/bench_constants.json), keyed by kernel form and
+# shape, together with the file they came from.  Nothing is hard-coded here: a kernel change without a new profile run
+# shows up as `null`, not as a stale number.
+def _profile_constants():
+    path = os.path.join(ROOT, "profiles", "bench_constants.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
 
 def event_time_ms(fn, iters, warm=3):
@@ -110,14 +115,86 @@ def _time_projection(runner, name):
     return ms, B * K + lin0.weight_bytes() + 2 * B * N + 4 * N + 4 * B
 
 
-def roofline_gate_up(runner):
-    """Event-time the gate_up GEMV alone, rotating over the layers' weights; plus the four projections together."""
+def _graph_time_ms(fn, nl, reps=6):
+    """fn(i) launched once per layer in one HIP graph, replayed `reps` times: ms per launch (HIP events on the launch stream)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(nl):
+            fn(i)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(nl):
+            fn(i)
+    g.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / (reps * nl)
+
+
+def _time_gate_up_silu(runner):
+    """The gate_up projection in the form fusion level 3 runs it: GEMV + silu_and_mul epilogue + row maxima (one kernel),
+    cold weights, no prefetch -> (ms per launch, algorithmic bytes: weights + int8 input + fp16 ACTIVATION out + params)."""
+    from omniserve_amd.backend import fused_ext
+    B, nl = runner.B, len(runner.layers)
+    lin0 = runner.layers[0]["gate_up"]
+    N, K = lin0.n, lin0.k
+    x = torch.randint(-127, 128, (B, K), dtype=torch.int8, device=runner.device)
+    sc = torch.full((B,), 0.01, dtype=torch.float16, device=runner.device)
+    sm = torch.zeros((B,), dtype=torch.float16, device=runner.device)
+    act = torch.empty((B, N // 2), dtype=torch.float16, device=runner.device)
+    amax = fused_ext.new_amax_slots(B, runner.device)
+
+    def fn(i):
+        G = runner.layers[i % nl]["gate_up"]
+        if G.group == -1:
+            fused_ext.gemm_silu_per_chn(x, G.qweight, G.s1_scales, sc, G.s1_szeros, sm, act, amax)
+        else:
+            fused_ext.gemm_silu_per_group(x, G.qweight, G.s2_zeros, G.s2_scales, G.s1_scales, sc, act, amax)
+
+    return _graph_time_ms(fn, nl), B * K + lin0.weight_bytes() + 2 * B * (N // 2) + 4 * N + 4 * B
+
+
+def _time_attention(runner):
+    """The KV4 decode attention of one layer as the step runs it (split partials + merge), pools rotated over the layers
+    (570 MB: cold) -> (ms per layer, algorithmic KV bytes per layer = 1088 * T * B for Llama-3-8B)."""
+    from omniserve_amd.backend import fused_ext
+    c, B, nl = runner.cfg, runner.B, len(runner.layers)
+    hq, hk, d = runner.hl, runner.kl, c.head_dim
+    q = runner.qkv_buf[:, : hq * d].view(B, hq, d)
+    k = runner.qkv_buf[:, hq * d:(hq + hk) * d].view(B, hk, d)
+    v = runner.qkv_buf[:, (hq + hk) * d:].view(B, hk, d)
+    T = int(runner.lengths[0].item())
+    if runner.fused >= 3:
+        def fn(i):
+            fused_ext.decode_attention_f16_amax(runner.attn_f16, runner.amax[i % nl, 0], q, k, v, runner.block_tables[i % nl],
+                                                runner.lengths, runner.tpb, runner.max_context, c.rope_theta)
+    else:
+        def fn(i):
+            fused_ext.decode_attention_quant_fuse_sum(runner._q_attn, q, k, v, runner.block_tables[i % nl], runner.lengths,
+                                                      runner.tpb, runner.max_context, c.rope_theta, runner.act_sum2,
+                                                      runner.act_scale2)
+    return _graph_time_ms(fn, nl), runner.kv_bytes_per_step(T) // nl, T
+
+
+def roofline_gate_up(runner, ms_per_step=None):
+    """Event-time the gate_up GEMV alone, rotating over the layers' weights; plus the four projections together, the
+    attention kernel pair, and the whole step against its algorithmic bytes."""
     B = runner.B
     lin0 = runner.layers[0]["gate_up"]
     N, K = lin0.n, lin0.k
-    ms, alg = _time_projection(runner, "gate_up")
+    ms_plain, alg_plain = _time_projection(runner, "gate_up")
+    silu = runner.fused >= 3
+    ms, alg = _time_gate_up_silu(runner) if silu else (ms_plain, alg_plain)
     achieved = alg / (ms * 1e-3) / 1e9
-    parts = {"gate_up": (ms, alg)}
+    parts = {"gate_up": (ms_plain, alg_plain)}
     for name in ("qkv", "o", "down"):
         parts[name] = _time_projection(runner, name)
     tot_ms = sum(v[0] for v in parts.values())
@@ -125,25 +202,48 @@ def roofline_gate_up(runner):
     aggregate = {"us_per_layer": round(tot_ms * 1e3, 2), "bytes_per_layer": tot_b,
                  "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  "us": {k: round(v[0] * 1e3, 2) for k, v in parts.items()},
-                 "note": "each projection's GEMV (+ its split-K epilogue kernel where the plan splits) timed alone in a "
-                         "HIP graph of 32 launches over the layers' (cold) weights; inside the decode step the row kernels prefetch the head of each weight "
-                         "stream into L2 (profiles/r02_* has the in-step durations)"}
-    # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    # runs, FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes): only known for the
-    # default shape; anything else reports null.
-    traffic = PMC_TRAFFIC_BYTES.get((B, N, K, lin0.group))
-    return {"bound": "hbm", "kernel": "w4a8_gemv_kernel<1,CHN,false,4> (gate_up GEMV M=%d N=%d K=%d, one kernel)" % (B, N, K),
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            # context: MI355X_MICROARCH.md puts the ACHIEVABLE stream rate at ~6.3 TB/s (a plain copy-like probe of this
-            # access pattern measures 5.7-5.9 TB/s, tools/stream_probe.hip); the launch costs ~1.6 us of the ~12.5 us
-            "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
-            "traffic_source": PMC_TRAFFIC_SOURCE if traffic else None,
-            "bytes_per_launch": alg, "us_per_launch": round(ms * 1e3, 2), "gemv_aggregate": aggregate,
-            "how_timed": "isolated: HIP graph of one launch per layer (cold weights, no L2 prefetch), HIP events on the launch "
-                         "stream; rocprofv3 of the whole command mixes these launches with the shorter in-step ones",
-            "in_step_us_per_launch": IN_STEP_US.get((B, N, K, lin0.group)),
-            "in_step_source": IN_STEP_SOURCE if (B, N, K, lin0.group) in IN_STEP_US else None}
+                 "note": "each projection's GEMV through the reference entry point (+ its split-K epilogue kernel where the "
+                         "plan splits) timed alone in a HIP graph of 32 launches over the layers' (cold) weights; every launch "
+                         "pays its ~1.7 us kernel boundary; inside the decode step the row kernels prefetch the head of each "
+                         "weight stream into L2 (profiles/ has the in-step durations)"}
+    consts = _profile_constants()
+    form = "silu" if silu else "plain"
+    key = "gate_up_%s M=%d N=%d K=%d g=%d" % (form, B, N, K, lin0.group)
+    prof = consts.get(key, {})
+    out = {"bound": "hbm",
+           "kernel": ("w4a8_gemv_kernel<1,CHN,false,4,*,1,EPI=1> (gate_up GEMV + silu_and_mul epilogue, M=%d N=%d K=%d, one kernel)"
+                      if silu else "w4a8_gemv_kernel<1,CHN,false,4> (gate_up GEMV M=%d N=%d K=%d, one kernel)") % (B, N, K),
+           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": prof.get("pmc_traffic_bytes"),
+           "traffic_source": prof.get("pmc_source"),
+           "bytes_per_launch": alg, "us_per_launch": round(ms * 1e3, 2),
+           "how_timed": "isolated: HIP graph of one launch per layer (cold weights, no L2 prefetch), HIP events on the launch "
+                        "stream, duration = elapsed / launches (each launch includes its ~1.7 us dependent-kernel boundary); "
+                        "rocprofv3 of the whole command mixes these launches with the shorter in-step ones",
+           "in_step_us_per_launch": prof.get("in_step_us"), "in_step_source": prof.get("in_step_source"),
+           "measured_copy_rate_GBps": HBM_ACHIEVABLE_GBS,      # context only (MI355X_MICROARCH.md: float4 copy 6.29 TB/s); `frac` is against the 8 TB/s peak
+           "gemv_aggregate": aggregate}
+    if silu:
+        out["gate_up_plain_form"] = {"us_per_launch": round(ms_plain * 1e3, 2), "bytes_per_launch": alg_plain,
+                                     "frac": round(alg_plain / (ms_plain * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    try:
+        a_ms, a_bytes, T = _time_attention(runner)
+        out["attention"] = {"kernel": "kv4_decode_flash_kernel<4> + merge (one layer, B=%d, T=%d)" % (B, T),
+                            "us_per_layer": round(a_ms * 1e3, 2), "bytes_per_layer": a_bytes,
+                            "achieved": round(a_bytes / (a_ms * 1e-3) / 1e9, 1),
+                            "frac": round(a_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "note": "algorithmic KV bytes 1088*T*B per layer; two dependent launches (split partials, merge); "
+                                    "at T=1024 the kernel is a latency chain (page table -> K/V -> softmax -> combine), not a stream"}
+    except Exception as exc:   # noqa: BLE001
+        out["attention"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if ms_per_step:
+        c = runner.cfg
+        lm = 2 * c.vocab * c.hidden
+        sb = runner.gemm_weight_bytes_per_step() + runner.kv_bytes_per_step(int(runner.lengths[0].item())) + lm
+        out["step"] = {"bytes": sb, "achieved": round(sb / (ms_per_step * 1e-3) / 1e9, 1),
+                       "frac": round(sb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "note": "whole decode step: W4A8 weights + KV4 pages + fp16 lm_head (%d B) over the timed ms_per_step" % lm}
+    return out
 
 
 def gemm_4096(device):
@@ -325,6 +425,36 @@ def tp_rank_leg(device, tp=8, batch=128, context=1024, steps=16, warmup=4):
             "all_reduce_calls_per_step": 2 * cfg.layers, "all_reduce_payload_bytes_per_step": ar_bytes}
 
 
+def cpu_gemm_4096():
+    """BASELINE.json configs[0] / SURVEY.md 8(d): the oracle's restatement of ONE W4A8 per-channel GEMM at M = N = K = 4096
+    on the host -- codes unpacked once (untimed), timed: torch._int_mm(A int8 [M,K], U^T int8 [K,N]) -> int32 plus the
+    reference's fp32 epilogue -> fp16 -- on 8 threads and on 1 thread, median of 5 after 2 warm-ups."""
+    import numpy as np
+    M = N = K = 4096
+    rng = np.random.default_rng(0)
+    a = torch.from_numpy(rng.integers(-127, 128, size=(M, K), dtype=np.int8))
+    ut = torch.from_numpy(rng.integers(0, 16, size=(N, K), dtype=np.int8)).t().contiguous()
+    sw = torch.full((N,), 0.01); sz = torch.full((N,), 0.05)
+    sa = torch.full((M, 1), 0.01); asum = torch.zeros((M, 1))
+    out = {"M": M, "N": N, "K": K, "gop": round(2.0 * M * N * K / 1e9, 1)}
+    keep = torch.get_num_threads()
+    for th in (8, 1):
+        torch.set_num_threads(th)
+        ts = []
+        for i in range(7):
+            t0 = time.perf_counter()
+            acc = torch._int_mm(a, ut)
+            _ = ((acc.float() * sw) * sa - sz * asum).half()
+            ts.append(time.perf_counter() - t0)
+            if sum(ts) > 25.0 and i >= 2:
+                break
+        ts = sorted(ts[2:] or ts)
+        med = ts[len(ts) // 2]
+        out["threads_%d" % th] = {"ms": round(med * 1e3, 1), "gops": round(2.0 * M * N * K / med / 1e9, 1)}
+    torch.set_num_threads(keep)
+    return out
+
+
 def cpu_baseline(cfg, batch):
     """Oracle port of one decoder layer's four per-channel W4A8 GEMMs at M=batch on the host cores
     (unpack once, untimed; timed: torch._int_mm + the fp32 epilogue), extrapolated to a step."""
@@ -352,12 +482,13 @@ def cpu_baseline(cfg, batch):
     layer()
     t0 = time.perf_counter()
     reps = 0
-    while time.perf_counter() - t0 < 12.0:
+    while time.perf_counter() - t0 < 8.0:
         layer()
         reps += 1
     dt = (time.perf_counter() - t0) / reps
     step_s = dt * cfg.layers
     return {"value": round(batch / step_s, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "gemm_4096": cpu_gemm_4096(),
             "sample": "oracle port (torch._int_mm int8 + fp32 epilogue) of the 4 per-channel W4A8 GEMMs of one "
                       "Llama-3-8B decoder layer at M=%d (rows padded to %d) on %d host threads, %d reps in %.1f s, "
                       "x%d layers; attention, norms, quantisers and lm_head are NOT in the sample (GEMMs only)" % (
@@ -475,7 +606,7 @@ def main():
             result[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     if rank == 0 and not args.no_extras:
-        leg("roofline", lambda: roofline_gate_up(runner))
+        leg("roofline", lambda: roofline_gate_up(runner, elapsed / args.steps * 1e3))
         prefetch_mb = runner.prefetch_bytes / float(1 << 20)
         result["config"]["l2_prefetch_mib_per_row_kernel"] = prefetch_mb
         if world == 1:
