@@ -505,19 +505,22 @@ __device__ __forceinline__ void a16_rider(const GemmArgs& p, float* xs, float* r
 #ifndef OMNI_GEMV_ABLATE
 #define OMNI_GEMV_ABLATE 0      // timing experiments (wrong results): 1 no activation reloads, 2 a quarter of the MFMAs,
 #endif                          // 4 no weight reloads, 8 no LDS publication of the next activation round
-template <int MB, int MODE>
+// VAR = 1 (MB = 2, int4 modes): the 32-row tile in the geometry used for M = 33..128 where it beats the 64-row tile --
+// 16-KiB activation rounds of 4 k-steps, a 4-step weight ring, four K parts per workgroup (profiles/r03_c_*).
+template <int MB, int MODE, int VAR = 0>
 struct GemvCfg {
+  static constexpr bool NARROW = VAR == 1 && MB == 2 && MODE != MODE_W8;
   static constexpr int WL = (MODE == MODE_W8) ? 4 : 2;
   // AR = k-steps per activation round (one LDS buffer), RING = k-steps of weights in flight per wave (a multiple of AR:
   // the 64-row tile keeps 16-KiB activation rounds but a deeper weight ring -- bytes in flight per wave are what bounds it)
-  static constexpr int AR = (MODE == MODE_W8) ? 4 : (MB <= 2 ? 8 : OMNI_GEMV_AR_MB4);
-  static constexpr int RING = (MODE == MODE_W8) ? 4 : (MB <= 2 ? 8 : OMNI_GEMV_RING_MB4);
+  static constexpr int AR = (MODE == MODE_W8) ? 4 : (NARROW ? 4 : (MB <= 2 ? 8 : OMNI_GEMV_AR_MB4));
+  static constexpr int RING = (MODE == MODE_W8) ? 4 : (NARROW ? 4 : (MB <= 2 ? 8 : OMNI_GEMV_RING_MB4));
   // single-wave tiles of up to 64 rows (no barrier; K is split over the workgroup's KW waves instead).  M = 65..128
   // runs as two 64-row tiles per channel group (grid.z = 2): the second read of the packed weights is served by
   // L2 / MALL.  (Round 1 had a 128-row tile here -- four channel groups per workgroup sharing a 32-KiB activation
   // round, 128 accumulator registers per wave spilling into AGPRs, an 8-KiB weight ring: 0.6 TB/s; removed.)
   static constexpr int WAVES = 1;
-  static constexpr int MAX_KW = (MB == 1 || (MB == 4 && MODE != MODE_W8 && OMNI_GEMV_AR_MB4 == 2)) ? 4 : 2;   // LDS: KW x 2 buffers x MT x RK <= 64 KiB
+  static constexpr int MAX_KW = (MB == 1 || NARROW || (MB == 4 && MODE != MODE_W8 && OMNI_GEMV_AR_MB4 == 2)) ? 4 : 2;   // LDS: KW x 2 buffers x MT x RK <= 64 KiB
 };
 
 //   * KW > 1 (single 64-channel group per workgroup only): KW waves split the workgroup's K-slice,
@@ -539,21 +542,21 @@ struct GemvCfg {
 // fused_kernels.cu:126-131); the first grid row (blockIdx.y == 0) are RIDER workgroups, one per activation
 // row, which replay the reference's ordered row sum (fused_kernels.cu:108-127) and write sum / scale for the consumer
 // of the slabs.  Together they remove the quant row kernel between two GEMVs, bit for bit.
-template <int MB, int MODE, bool TO_SLAB, int KW = 1, bool NT = true, int MZ = 1, int EPI = 0, bool A16 = false>
-__global__ __launch_bounds__((64 * GemvCfg<MB, MODE>::WAVES * KW * MZ), (((MB == 4 && KW == 4 && MZ == 1) || A16) ? 2 : 1)) void w4a8_gemv_kernel(GemmArgs p) {
+template <int MB, int MODE, bool TO_SLAB, int KW = 1, bool NT = true, int MZ = 1, int EPI = 0, bool A16 = false, int VAR = 0>
+__global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((MB == 4 && KW == 4 && MZ == 1) || A16 || VAR == 1) ? 2 : 1)) void w4a8_gemv_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
   static_assert(EPI == 0 || (MODE != MODE_W8 && !TO_SLAB && MZ == 1), "SiLU epilogue: int4 tile layout, in-kernel epilogue");
-  static_assert(!A16 || (TO_SLAB && MZ == 1 && MB == 1 && GemvCfg<MB, MODE>::WAVES == 1), "fp16-input form: slab output, one 16-row single-wave tile");
+  static_assert(!A16 || (TO_SLAB && MZ == 1 && MB == 1 && GemvCfg<MB, MODE, VAR>::WAVES == 1), "fp16-input form: slab output, one 16-row single-wave tile");
   static_assert(EPI == 0 || MB == 1, "row-maximum hand-off covers 16 rows");
-  constexpr int WAVES = GemvCfg<MB, MODE>::WAVES;
+  constexpr int WAVES = GemvCfg<MB, MODE, VAR>::WAVES;
   static_assert(KW == 1 || WAVES == 1, "in-workgroup K split is for single-wave tiles");
-  static_assert(KW <= GemvCfg<MB, MODE>::MAX_KW, "LDS budget");
+  static_assert(KW <= GemvCfg<MB, MODE, VAR>::MAX_KW, "LDS budget");
   static_assert(KW == 1 || KW == 2 || KW == 4, "KW");
   static_assert(MZ == 1 || (MZ == 2 && WAVES == 1), "row-tile pairs are for single-wave tiles");
   constexpr int NTHREADS = 64 * WAVES;                   // threads sharing one staged activation tile
-  constexpr int WL = GemvCfg<MB, MODE>::WL;
-  constexpr int RING = GemvCfg<MB, MODE>::RING;
-  constexpr int AR = GemvCfg<MB, MODE>::AR;
+  constexpr int WL = GemvCfg<MB, MODE, VAR>::WL;
+  constexpr int RING = GemvCfg<MB, MODE, VAR>::RING;
+  constexpr int AR = GemvCfg<MB, MODE, VAR>::AR;
   constexpr int SUB = RING / AR;                         // activation rounds per ring round
   static_assert(RING % AR == 0 && (SUB == 1 || SUB % 2 == 0), "ring = whole activation rounds, buffer parity static");
   constexpr int RK = AR * KSTEP;                         // k per activation round
@@ -1015,7 +1018,8 @@ struct GemmPlan {
   int sk;      // K splits (grid level, int32 slabs)
   int kslice;  // k per split
   int kw;      // K parts inside a workgroup (decode kernel)
-  int mz;      // row tiles (grid.z) of the decode kernel: 2 for M = 65..128
+  int mz;      // row tiles (grid.z) of the decode kernel: 2 for M = 65..128 (64-row tiles), up to 4 (32-row tiles)
+  int narrow;  // 1: M = 33..128 on 32-row tiles (GemvCfg VAR = 1)
 };
 
 // Tuning hook (tests / bench sweeps): waves<=0 and sk<=0 restore the heuristic.
@@ -1068,6 +1072,17 @@ static void launch_gemv_kernel_nt(const GemmArgs& a, const GemmPlan& pl, hipStre
   if constexpr (MB == 4) {
     if (pl.kw == 2 && pl.mz == 2) {   // both 64-row tiles of a channel group in one workgroup (4 waves, 128 KiB of LDS)
       hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 2, NT, 2>), dim3(grid.x, grid.y, 1), dim3(256), 0, st, a);
+      return;
+    }
+  }
+  if constexpr (MB == 2 && MODE != MODE_W8) {
+    if (pl.narrow) {     // M = 33..128 as 32-row tiles (grid.z row tiles), four K parts per workgroup
+      if (pl.kw == 4)
+        hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 4, NT, 1, 0, false, 1>), grid, dim3(256), 0, st, a);
+      else if (pl.kw == 2)
+        hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 2, NT, 1, 0, false, 1>), grid, dim3(128), 0, st, a);
+      else
+        hipLaunchKernelGGL((w4a8_gemv_kernel<MB, MODE, TO_SLAB, 1, NT, 1, 0, false, 1>), grid, dim3(64), 0, st, a);
       return;
     }
   }

@@ -19,6 +19,7 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
   GemmPlan pl;
   pl.kw = 1;
   pl.mz = 1;
+  pl.narrow = 0;
   if (M > 128) {  // MFMA-bound regime: 128 x 256 tile per workgroup, no split
     pl.mb = 8; pl.waves = 4; pl.sk = 1; pl.kslice = K;
     return pl;
@@ -31,6 +32,29 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
   const int ngroups = N / 64;
   auto ok = [&](int s) { return s >= 1 && (K % s) == 0 && ((K / s) % kalign) == 0; };
   int sk = 1;
+  // M = 33..128, int4 modes: 32-row tiles (ceil(M / 32) row tiles per channel group, the re-reads of a weight byte are
+  // served by L1 / L2) beat the 64-row tile whenever their grid still fits the chip in one round -- smaller serial
+  // chains per wave at the same two waves per SIMD (measured, profiles/r03_c_*: Llama-2-70B TP=8 shard at M = 128
+  // gate_up 24.8 -> 21.6 us, down 18.4 -> 12.9, qkv 12.5 -> 10.0, o 7.6 -> 5.6; Llama-3-8B g128 at M = 64 down 20.4 ->
+  // 18.6, qkv 12.8 -> 10.1, o 10.9 -> 9.9, but gate_up 23.0 -> 31.5: 896 workgroups, two rounds -- stays on 64 rows).
+  static const int narrow_mode = [] { const char* e = getenv("OMNI_GEMV_NARROW"); return e ? atoi(e) : 1; }();   // 0: never (A/B)
+  // (g128 at M <= 64: faster launch by launch, but the Llama-3-8B bs = 64 decode step measured 1.2 % slower with it -- off)
+  if (!w8 && M > 32 && !(kalign == 128 && M <= 64) && narrow_mode != 0 && g_override_waves == 0 && g_override_sk == 0) {
+    const int mz = (M + 31) / 32;
+    if (ngroups * mz <= 640 && (K % (4 * kalign)) == 0) {
+      pl.mb = 2; pl.mz = mz; pl.waves = 1; pl.narrow = 1; pl.kw = 4;
+      // smallest split with <= 2048 k per wave and >= 128 workgroups; parts of at least 256 k
+      int best = 1;
+      for (int s = 1; s <= 64; ++s) {
+        if (!ok(s) || ((K / s) % (4 * kalign)) != 0 || K / (s * 4) < 256) continue;
+        best = s;
+        if (K / (s * 4) <= 2048 && ngroups * mz * s >= 128) break;
+      }
+      pl.sk = best;
+      pl.kslice = K / best;
+      return pl;
+    }
+  }
   if (pl.mb == 1) {
     // M <= 16: single-wave tiles, K split first inside the workgroup (kw waves, no slab traffic) and only
     // then across workgroups.  Measured on MI355X (tools/kw_sweep*.py): a wave should stream <= 1024 k
