@@ -66,7 +66,11 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
     auto fits = [&](int s) { return ok(s) && ((K / s) % (kw * kalign)) == 0; };
     // W8A8 rows are twice the bytes per k: the deferred (slab-only) plan halves the k per wave (same bytes per wave)
     const int part_target = (deferred && w8) ? 256 : 512;
-    if (!deferred && part(1) <= 1024) {
+    // W8A8 rows are twice the bytes per k: with few channel groups (qkv at batch 1: 96 workgroups streaming 256 KiB each)
+    // a split to 512 k per wave + the slab epilogue launch beats the single kernel (OMNI_W8_SMALL_SPLIT=0: off, A/B)
+    static const int w8_small_split = [] { const char* e = getenv("OMNI_W8_SMALL_SPLIT"); return e ? atoi(e) : 1; }();
+    const bool w8_small = w8 && !deferred && w8_small_split && ngroups <= 128 && part(1) > 512;
+    if (!deferred && part(1) <= 1024 && !w8_small) {
       sk = 1;
     } else {
       int best = 0;
