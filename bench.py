@@ -508,6 +508,10 @@ def main():
     ap.add_argument("--fused-level", type=int, default=3, help="0 reference sequence, 1 fused add+norm / silu+quant, 2 + deferred split-K epilogue, 3 + no quantiser row kernels (SiLU in the gate_up epilogue, o / down quantise on the fly)")
     ap.add_argument("--no-lserve", action="store_true", help="skip the configs[3] (LServe, 256K context) leg")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / gemm_4096 legs")
+    ap.add_argument("--tp-comm", choices=["rccl", "peer"], default="rccl",
+                    help="with --tp: the two all-reduces per layer on torch.distributed / RCCL (default) or on the library's own "
+                         "peer-mapped collective folded into the add + norm kernel (omniserve_amd/tp.py: PeerComm; validated with "
+                         "two ranks on one GPU only -- no multi-GPU box was available to its author)")
     ap.add_argument("--tp", action="store_true", help="with N > 1: shard ONE model over the N GPUs (Megatron TP, fp16 "
                     "all-reduce over RCCL after o_proj / down_proj; strong scaling) instead of N replicas")
     args = ap.parse_args()
@@ -531,7 +535,8 @@ def main():
     runner = DecodeRunner(cfg, args.batch, args.context, args.steps + args.warmup + 4, device,
                           seed=1234 + (0 if tp else rank), use_graph=not args.no_graph,
                           fused=0 if args.no_fused else args.fused_level,
-                          tp_rank=rank if tp else 0, tp_size=world if tp else 1)
+                          tp_rank=rank if tp else 0, tp_size=world if tp else 1,
+                          tp_comm=args.tp_comm if tp else None)
     for _ in range(args.warmup):
         runner.step()
     torch.cuda.synchronize()
@@ -571,7 +576,21 @@ def main():
         us = float(t.item())
         nbytes = buf.numel() * 2
         ar = {"all_reduce_us": round(us, 2), "payload_bytes": nbytes, "calls_per_step": 2 * cfg.layers,
-              "bus_GBps": round(2.0 * (world - 1) / world * nbytes / us / 1e3, 1)}
+              "bus_GBps": round(2.0 * (world - 1) / world * nbytes / us / 1e3, 1), "step_collective": args.tp_comm}
+        if runner.comm is not None:
+            # the library's own collective on the same payload (an even number of calls keeps the slot parity of the step)
+            for _ in range(6):
+                runner.comm.all_reduce(buf)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(50):
+                runner.comm.all_reduce(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / 50 * 1e3], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ar["peer_all_reduce_us"] = round(float(t.item()), 2)
+            runner.comm.check_error()
     total_tokens = args.batch * args.steps * (1 if tp else world)
     result = {
         "metric": "decode tokens/sec/GPU Llama-3-8B W4A8KV4 bs=%d" % args.batch if world == 1 else

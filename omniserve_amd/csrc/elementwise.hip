@@ -14,6 +14,7 @@
 // fallback for row lengths the v2 geometry does not cover.)
 #include "common.h"
 #include "row_reduce.h"
+#include "tp_comm.h"
 #include <cstdlib>
 
 namespace omni {
@@ -350,6 +351,31 @@ struct SrcSlabAddT {  // residual += h(GEMM epilogue(sum of split-K slabs)), in 
     *reinterpret_cast<v8h*>(res + i) = o;
   }
 };
+// tensor parallel: residual += h( sum over ranks of the peers' fp16 partial projections ) -- the all-reduce of
+// llama_w4a8_unpad.py's row-parallel outputs folded into the consumer (tp_comm.h)
+struct SrcPeerAdd {
+  static constexpr bool BATCH = false;
+  struct Raw { v8h a, s; };
+  half_t* res;
+  TpPeers tp;
+  int stride;
+  __device__ __forceinline__ SrcPeerAdd at_row(int m) const {
+    SrcPeerAdd r = *this;
+    r.res = res + (size_t)m * stride;
+    r.tp.slot_off = tp.slot_off + (long long)m * stride;
+    return r;
+  }
+  __device__ __forceinline__ void fetch(int i, Raw& r) const {
+    r.a = *reinterpret_cast<const v8h*>(res + i);
+    r.s = tp_sum8(tp, (size_t)i);
+  }
+  __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
+    v8h o;
+#pragma unroll
+    for (int e = 0; e < VT; ++e) { o[e] = (half_t)((float)r.a[e] + (float)r.s[e]); x[e] = (float)o[e]; }
+    *reinterpret_cast<v8h*>(res + i) = o;
+  }
+};
 typedef SrcSlabAddT<true> SrcSlabAddChn;
 typedef SrcSlabAddT<false> SrcSlabAddW8;
 struct SrcSilu {  // h(h(silu(gate)) * up) of a [2d] row
@@ -504,15 +530,9 @@ __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, 
 
 // rms_norm_general[_fuse_sum] (+ fused residual sources): NV = roundup32(min(hidden,1024))
 template <int RT, int RV, bool FUSE_SUM, typename Src>
-__global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict__ out, Src src0, const half_t* __restrict__ gamma,
-                                                              half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
-                                                              float eps, int hidden, int nv, PrefetchArgs pf) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];   // [hidden] (>= RT/64 KiB, see OMNI_V2_LAUNCH)
-  __shared__ float red[96];
-  if (pf.blocks > 0 && (int)blockIdx.x >= pf.first_block) {    // extra workgroups: L2 prefetch for the next GEMV
-    prefetch_weights_to_l2(pf, xs);
-    return;
-  }
+__device__ __forceinline__ void general_norm_v2_body(int8_t* __restrict__ out, const Src& src0, const half_t* __restrict__ gamma,
+                                                     half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
+                                                     float eps, int hidden, int nv, float* xs, float* red) {
   const int p = threadIdx.x;
   OMNI_CLK(0);
   const Src src = src0.at_row(blockIdx.x);
@@ -596,6 +616,31 @@ __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict_
     if (p == 0) sum_out[blockIdx.x] = (half_t)tot[0];
   }
   OMNI_CLK(7);
+}
+
+template <int RT, int RV, bool FUSE_SUM, typename Src>
+__global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict__ out, Src src0, const half_t* __restrict__ gamma,
+                                                              half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
+                                                              float eps, int hidden, int nv, PrefetchArgs pf) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // [hidden] (>= RT/64 KiB, see OMNI_V2_LAUNCH)
+  __shared__ float red[96];
+  if (pf.blocks > 0 && (int)blockIdx.x >= pf.first_block) {    // extra workgroups: L2 prefetch for the next GEMV
+    prefetch_weights_to_l2(pf, xs);
+    return;
+  }
+  general_norm_v2_body<RT, RV, FUSE_SUM, Src>(out, src0, gamma, sum_out, scale_out, eps, hidden, nv, xs, red);
+}
+
+// tensor parallel: the same row kernel behind the peers' barrier (tp_comm.h); one workgroup per token, all resident
+template <int RT, int RV, bool FUSE_SUM>
+__global__ __launch_bounds__(RT) void tp_add_norm_v2_kernel(int8_t* __restrict__ out, SrcPeerAdd src0, const half_t* __restrict__ gamma,
+                                                             half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
+                                                             float eps, int hidden, int nv) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  __shared__ float red[96];
+  const uint32_t e = tp_publish_and_wait(src0.tp);
+  general_norm_v2_body<RT, RV, FUSE_SUM, SrcPeerAdd>(out, src0, gamma, sum_out, scale_out, eps, hidden, nv, xs, red);
+  tp_finish(src0.tp, e);
 }
 
 // rms_norm (fp16 out): NV = min(hidden,1024)
@@ -1070,6 +1115,37 @@ extern "C" int omni_attn_merge_f16_amax(void* out_f16, const void* part_ml_f32, 
   SrcAttnMerge src{(const float*)part_ml_f32, (const float*)part_o_f32, nsplit, num_heads, 0};
   hipLaunchKernelGGL(attn_merge_f16_kernel, dim3(wgs + pf.blocks), dim3(256), 0, (hipStream_t)stream, (half_t*)out_f16,
                      src, (uint32_t*)amax_slots_u32, batch, hidden, pf);
+  return omni_launch_status();
+}
+
+// Tensor parallel (fused extension, tp_comm.h): residual += all-reduce(partial projections); rms_norm_general[_fuse_sum].
+// The partial projection of THIS rank must already sit in its slot (written by the projection's launch).
+extern "C" int omni_tp_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const void* const* peer_data,
+                                                     void* const* peer_flags, int rank, int world,
+                                                     long long slot_offset_elems, const void* weight_f16, void* sum_f16,
+                                                     void* scale_f16, float eps, int tokens, int hidden, void* stream) {
+  if (!out_i8 || !residual_f16 || !weight_f16 || !scale_f16 || !peer_data || !peer_flags || tokens < 0 || hidden < 1)
+    return OMNI_EINVAL;
+  if (world < 1 || world > TP_MAX_WORLD || rank < 0 || rank >= world || slot_offset_elems < 0) return OMNI_EINVAL;
+  const int nv = norm_block(hidden, true);
+  if (!v2_ok(hidden, nv) || tokens > 256) return OMNI_EINVAL;     // (every token's workgroup must be resident: they meet at a ticket)
+  if (tokens == 0) return OMNI_OK;
+  SrcPeerAdd src{};
+  src.res = (half_t*)residual_f16; src.stride = hidden;
+  for (int p = 0; p < TP_MAX_WORLD; ++p) {
+    const int q = p < world ? p : 0;
+    if (!peer_data[q] || !peer_flags[q]) return OMNI_EINVAL;
+    src.tp.data[p] = (const half_t*)peer_data[q];
+    src.tp.flags[p] = (uint32_t*)peer_flags[q];
+  }
+  src.tp.rank = rank; src.tp.world = world; src.tp.slot_off = slot_offset_elems;
+  const size_t lds = (size_t)hidden * sizeof(float);
+  if (sum_f16)
+    hipLaunchKernelGGL((tp_add_norm_v2_kernel<512, 4, true>), dim3(tokens), dim3(512), lds, (hipStream_t)stream, (int8_t*)out_i8,
+                       src, (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
+  else
+    hipLaunchKernelGGL((tp_add_norm_v2_kernel<512, 4, false>), dim3(tokens), dim3(512), lds, (hipStream_t)stream, (int8_t*)out_i8,
+                       src, (const half_t*)weight_f16, (half_t*)nullptr, (half_t*)scale_f16, eps, hidden, nv);
   return omni_launch_status();
 }
 

@@ -1,0 +1,104 @@
+// Tensor-parallel collectives of the decode path over peer-mapped device memory (hipIpc; xGMI on a multi-GPU node).
+//
+// The reference has no tensor parallelism; BASELINE configs[4] asks for Llama-2-70B at TP = 8 with the
+// two all-reduces per layer.  At bs = 128 the payload is 2 MiB (128 x 8192 fp16): latency-, not bandwidth-bound, and 160
+// of them run per decode step -- a library collective per call costs a launch each and cannot be fused with its
+// consumer.  Here every rank owns one fine-grained buffer (two data slots + a few flag words) that all peers map:
+//
+//   producer kernel (the projection's epilogue)  writes the rank's fp16 partial projection into ITS OWN slot;
+//   consumer kernel (all-reduce, or residual add + norm + quant: tp_* below), first workgroup: publishes "slot s of
+//   epoch e is complete" by storing e into flag word [my rank] of every peer; every workgroup: waits until its own flag
+//   words of all peers reached e, then reads the peers' slots directly and sums them in RANK ORDER in f32 (one rounding to
+//   fp16: every rank computes bit-identical sums; at world = 2 it equals an fp16 ring all-reduce); the last workgroup to
+//   finish advances the rank's epoch counter.
+//
+// Nothing is sent twice and there is no separate all-reduce launch when the consumer is the add + norm kernel.  Slots
+// alternate per call (call j of a step uses slot j & 1): a rank can only overwrite slot s for call j + 2 after it passed
+// the barrier of call j + 1, which every peer reaches only after it finished reading call j.
+// Epochs live in device memory, so a captured HIP graph replays correctly.  Every spin is bounded (a lost peer sets the
+// error word instead of hanging the GPU).
+#pragma once
+#include "common.h"
+
+namespace omni {
+
+constexpr int TP_MAX_WORLD = 8;
+constexpr int TP_FLAG_WORDS = 64;      // per rank: [0, 8) arrival epochs written by the peers, then the words below
+constexpr int TP_W_EPOCH = 16;         // completed collectives of this rank
+constexpr int TP_W_TICKET = 17;        // workgroups of the running consumer kernel that finished
+constexpr int TP_W_ERROR = 18;         // != 0: a wait timed out
+
+struct TpPeers {
+  const half_t* data[TP_MAX_WORLD];    // rank p's data buffer (two slots), as mapped into THIS process
+  uint32_t* flags[TP_MAX_WORLD];       // rank p's flag words
+  int rank, world;
+  long long slot_off;                  // element offset of the slot this call uses
+};
+
+__device__ __forceinline__ uint32_t tp_load_sys(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Prologue of a consumer kernel: publish my slot, wait for every peer's.  Returns the epoch (0 = timed out).
+__device__ __forceinline__ uint32_t tp_publish_and_wait(const TpPeers& tp) {
+  __shared__ uint32_t s_epoch;
+  uint32_t* mine = tp.flags[tp.rank];
+  const uint32_t e = tp_load_sys(mine + TP_W_EPOCH) + 1;
+  if (blockIdx.x == 0 && (int)threadIdx.x < tp.world) {
+    // the slot was written by the previous kernel on this stream (complete and released at the kernel boundary)
+    __hip_atomic_store(tp.flags[threadIdx.x] + tp.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if ((int)threadIdx.x < tp.world) {
+    uint32_t seen = tp_load_sys(mine + threadIdx.x);
+    long long spins = 0;
+    while ((int32_t)(seen - e) < 0) {                 // (wrap-safe "seen < e")
+      __builtin_amdgcn_s_sleep(4);
+      seen = tp_load_sys(mine + threadIdx.x);
+      if (++spins > (1ll << 23)) {                    // ~ seconds: a peer is gone -- report, do not hang the queue
+        __hip_atomic_store(mine + TP_W_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  if (threadIdx.x == 0) s_epoch = e;
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system-scope acquire: the peers' slots are readable from here on
+  return s_epoch;
+}
+
+// Epilogue: the last workgroup of the kernel to get here advances this rank's epoch.
+__device__ __forceinline__ void tp_finish(const TpPeers& tp, uint32_t e) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t* mine = tp.flags[tp.rank];
+    const uint32_t done = __hip_atomic_fetch_add(mine + TP_W_TICKET, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(mine + TP_W_TICKET, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + TP_W_EPOCH, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// h( sum over ranks 0 .. world-1 of f32(data_p[i .. i+8)) ): the all-reduced fp16 vector, identical on every rank
+__device__ __forceinline__ v8h tp_sum8(const TpPeers& tp, size_t i) {
+  v8h t[TP_MAX_WORLD];
+#pragma unroll
+  for (int p = 0; p < TP_MAX_WORLD; ++p)
+    t[p] = *reinterpret_cast<const v8h*>(tp.data[p < tp.world ? p : 0] + tp.slot_off + i);   // branch-free: all loads in flight
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll
+  for (int p = 0; p < TP_MAX_WORLD; ++p) {
+    if (p < tp.world) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)t[p][e];
+    }
+  }
+  v8h o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+  return o;
+}
+
+}  // namespace omni

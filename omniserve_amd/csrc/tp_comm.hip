@@ -1,0 +1,68 @@
+// Peer-mapped communication buffers and the plain all-reduce of the tensor-parallel decode path (see tp_comm.h).
+#include "tp_comm.h"
+
+using namespace omni;
+
+namespace omni {
+
+__global__ __launch_bounds__(256) void tp_allreduce_f16_kernel(half_t* __restrict__ out, TpPeers tp, long long count) {
+  const uint32_t e = tp_publish_and_wait(tp);
+  const long long nvec = count / 8;
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256)
+    *reinterpret_cast<v8h*>(out + v * 8) = tp_sum8(tp, (size_t)v * 8);
+  tp_finish(tp, e);
+}
+
+}  // namespace omni
+
+static int fill_peers(TpPeers& tp, const void* const* peer_data, void* const* peer_flags, int rank, int world,
+                      long long slot_off) {
+  if (!peer_data || !peer_flags || world < 1 || world > TP_MAX_WORLD || rank < 0 || rank >= world || slot_off < 0)
+    return OMNI_EINVAL;
+  for (int p = 0; p < TP_MAX_WORLD; ++p) {
+    const int q = p < world ? p : 0;
+    if (!peer_data[q] || !peer_flags[q]) return OMNI_EINVAL;
+    tp.data[p] = static_cast<const half_t*>(peer_data[q]);
+    tp.flags[p] = static_cast<uint32_t*>(peer_flags[q]);
+  }
+  tp.rank = rank; tp.world = world; tp.slot_off = slot_off;
+  return OMNI_OK;
+}
+
+// ---- buffers: fine-grained device memory (coherent with peers that map it), shared through hipIpc handles ------------
+extern "C" int omni_tp_alloc(size_t bytes, void** ptr_out) {
+  if (!ptr_out || bytes == 0) return OMNI_EINVAL;
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) return OMNI_ENOMEM;
+  if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return OMNI_ELAUNCH; }
+  *ptr_out = p;
+  return OMNI_OK;
+}
+extern "C" int omni_tp_free(void* ptr) { return hipFree(ptr) == hipSuccess ? OMNI_OK : OMNI_EINVAL; }
+extern "C" int omni_tp_ipc_handle(void* ptr, void* handle64) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+  if (!ptr || !handle64) return OMNI_EINVAL;
+  return hipIpcGetMemHandle(static_cast<hipIpcMemHandle_t*>(handle64), ptr) == hipSuccess ? OMNI_OK : OMNI_EINVAL;
+}
+extern "C" int omni_tp_ipc_open(const void* handle64, void** ptr_out) {
+  if (!handle64 || !ptr_out) return OMNI_EINVAL;
+  hipIpcMemHandle_t h = *static_cast<const hipIpcMemHandle_t*>(handle64);
+  return hipIpcOpenMemHandle(ptr_out, h, hipIpcMemLazyEnablePeerAccess) == hipSuccess ? OMNI_OK : OMNI_EINVAL;
+}
+extern "C" int omni_tp_ipc_close(void* ptr) { return hipIpcCloseMemHandle(ptr) == hipSuccess ? OMNI_OK : OMNI_EINVAL; }
+
+// out fp16 [count] = sum over the ranks of their slot (count % 8 == 0).  peer_data / peer_flags: host arrays of `world`
+// device pointers (rank p's buffers as mapped into this process; entry `rank` = the caller's own).  Only enqueues.
+extern "C" int omni_tp_allreduce_f16(void* out_f16, const void* const* peer_data, void* const* peer_flags, int rank,
+                                     int world, long long slot_offset_elems, long long count, void* stream) {
+  if (!out_f16 || count < 0 || count % 8 != 0) return OMNI_EINVAL;
+  TpPeers tp;
+  const int rc = fill_peers(tp, peer_data, peer_flags, rank, world, slot_offset_elems);
+  if (rc != OMNI_OK) return rc;
+  if (count == 0) return OMNI_OK;
+  long long wgs = (count / 8 + 255) / 256;
+  if (wgs > 128) wgs = 128;                 // all workgroups must be resident together (they wait on each other's ticket)
+  hipLaunchKernelGGL(tp_allreduce_f16_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, (half_t*)out_f16, tp,
+                     count);
+  return omni_launch_status();
+}

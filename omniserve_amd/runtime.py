@@ -120,7 +120,7 @@ class DecodeRunner:
 
     def __init__(self, cfg: LlamaConfig, batch: int, context: int, max_new: int, device, seed=0,
                  use_graph=True, fused=True, tp_rank=0, tp_size=1, tp_group=None, shard_full=False,
-                 prefetch_mb=None, prefetch_blocks=240, weight_policy=None):
+                 prefetch_mb=None, prefetch_blocks=240, weight_policy=None, tp_comm=None):
         """tp_size > 1: Megatron-style tensor parallelism (omniserve_amd/tp.py): qkv / gate_up column-parallel,
         o / down row-parallel, attention by kv head, one fp16 sum all-reduce of the [B, hidden] projection after
         o_proj and after down_proj.  shard_full=True builds the full layers from the seed and keeps this
@@ -129,6 +129,12 @@ class DecodeRunner:
         import os
         self.cfg, self.B, self.device = cfg, batch, device
         self.tp_rank, self.tp_size, self.tp_group = int(tp_rank), int(tp_size), tp_group
+        # tp_comm = "peer": the decode step's collectives run on the library's own peer-mapped all-reduce (tp.PeerComm: one
+        # launch per collective, folded into the add + norm kernel where one follows) instead of torch.distributed / RCCL
+        self.comm = None
+        if self.tp_size > 1 and (tp_comm if tp_comm is not None else os.environ.get("OMNI_TP_COMM", "")) == "peer":
+            from . import tp
+            self.comm = tp.PeerComm(self.tp_rank, self.tp_size, batch * cfg.hidden, device, tp_group)
         if cfg.heads % self.tp_size or cfg.kv_heads % self.tp_size or cfg.inter % (128 * self.tp_size):
             raise ValueError("heads / kv_heads / intermediate size not divisible by the TP degree")
         self.hl, self.kl, self.il = cfg.heads // self.tp_size, cfg.kv_heads // self.tp_size, cfg.inter // self.tp_size
@@ -355,6 +361,8 @@ class DecodeRunner:
                 sk, lin = pending
                 self._consume(qa_h, sk, lin, sA, mA, L["ln1"], mB, sB)
                 pending = None
+            elif self.fused and li > 0 and self.comm is not None:
+                self.comm.add_rms_norm(qa_h, self.x, L["ln1"], mB, sB, c.eps)      # all-reduce(down_proj) + add + norm + quant
             elif self.fused and li > 0:
                 fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln1"], mB, sB, c.eps)
             elif per_chn:
@@ -388,10 +396,15 @@ class DecodeRunner:
                 self._arm(L["gate_up"], silu=self.fused >= 3 and li < nl - 1)
                 self._consume(qa_h, sk, L["o"], sA, mA, L["ln2"], mB, sB)
             else:
-                L["o"].forward(self._q_attn, sA, mA, self.proj_buf)
-                self._all_reduce(self.proj_buf)
+                peer = self.comm is not None and self.fused
+                proj = self.comm.slot(B * c.hidden, (B, c.hidden)) if peer else self.proj_buf
+                L["o"].forward(self._q_attn, sA, mA, proj)
+                if not peer:
+                    self._all_reduce(self.proj_buf)
                 self._arm(L["gate_up"])
-                if self.fused:
+                if peer:
+                    self.comm.add_rms_norm(qa_h, self.x, L["ln2"], mB, sB, c.eps)  # all-reduce(o_proj) + add + norm + quant
+                elif self.fused:
                     fused_ext.add_rms_norm_general_fuse_sum(qa_h, self.x, self.proj_buf, L["ln2"], mB, sB, c.eps)
                 else:
                     self.x.add_(self.proj_buf)
@@ -427,8 +440,12 @@ class DecodeRunner:
             if self.fused >= 2 and li < nl - 1:
                 pending = (self._partial(qa_i, L["down"]), L["down"])
             else:
-                L["down"].forward(qa_i, sA, mA, self.proj_buf)
-                self._all_reduce(self.proj_buf)
+                peer = self.comm is not None and self.fused
+                L["down"].forward(qa_i, sA, mA, self.comm.slot(B * c.hidden, (B, c.hidden)) if peer else self.proj_buf)
+                if peer and li == nl - 1:
+                    self.comm.all_reduce(self.proj_buf)
+                elif not peer:
+                    self._all_reduce(self.proj_buf)     # (peer: consumed by the next layer's add + norm)
                 if not self.fused or li == nl - 1:
                     self.x.add_(self.proj_buf)
         layernorm_ops.rms_norm(self.normed, self.x, self.final_norm, c.eps, False)

@@ -67,3 +67,112 @@ def all_reduce_(buf: torch.Tensor, group=None) -> torch.Tensor:
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf
+
+
+class PeerComm:
+    """The library's own tensor-parallel collective over peer-mapped device memory (include/omniserve_hip.h: omni_tp_*;
+    csrc/tp_comm.h).  torch.distributed is used ONCE, to exchange the 64-byte IPC handles; after that a collective is one
+    kernel launch on the current stream (HIP-graph capturable): no RCCL call, no host synchronisation.
+
+        comm = PeerComm(rank, world, max_elems, device, group)     # collective: every rank constructs it
+        out_view = comm.slot(numel)              # fp16 tensor aliasing this rank's slot of the NEXT call: the projection
+                                                 # writes its partial result straight into it
+        comm.all_reduce(out)                     # out <- sum over ranks           (consumes the slot, flips to the other)
+        comm.add_rms_norm(...)                   # or: residual += sum; norm; quant (one launch)
+
+    Every rank must issue the same sequence of collectives.  A rank that waits for a lost peer sets an error word instead
+    of hanging (check_error())."""
+
+    FLAG_WORDS = 64
+
+    class _Blob:      # raw device memory as a torch tensor (torch.as_tensor understands __cuda_array_interface__)
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    def __init__(self, rank, world, max_elems, device, group=None):
+        import ctypes
+        import torch.distributed as dist
+        from . import _lib
+        if world > 8:
+            raise ValueError("PeerComm supports up to 8 ranks")
+        self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
+        self.slot_elems = (int(max_elems) + 7) // 8 * 8
+        self.data_bytes = 2 * self.slot_elems * 2
+        self.nbytes = self.data_bytes + 4 * self.FLAG_WORDS
+        lib = _lib.lib()
+        with torch.cuda.device(self.device):
+            p = ctypes.c_void_p()
+            _lib.check(lib.omni_tp_alloc(self.nbytes, ctypes.byref(p)), "omni_tp_alloc")
+            self._own = p.value
+            h = (ctypes.c_ubyte * 64)()
+            _lib.check(lib.omni_tp_ipc_handle(self._own, h), "omni_tp_ipc_handle")
+            handles = [None] * world
+            if world > 1:
+                dist.all_gather_object(handles, bytes(h), group=group)
+            else:
+                handles[0] = bytes(h)
+            self._mapped = []
+            bases = []
+            for r in range(world):
+                if r == rank:
+                    bases.append(self._own)
+                    continue
+                q = ctypes.c_void_p()
+                buf = (ctypes.c_ubyte * 64).from_buffer_copy(handles[r])
+                _lib.check(lib.omni_tp_ipc_open(buf, ctypes.byref(q)), "omni_tp_ipc_open (rank %d)" % r)
+                self._mapped.append(q.value)
+                bases.append(q.value)
+        self._data = (ctypes.c_void_p * world)(*bases)
+        self._flags = (ctypes.c_void_p * world)(*[b + self.data_bytes for b in bases])
+        self._mine = torch.as_tensor(self._Blob(self._own, self.nbytes), device=self.device)
+        self._call = 0
+        if world > 1:
+            dist.barrier(group=group)      # nobody publishes before every rank has mapped every buffer
+
+    def slot(self, numel, shape=None):
+        """fp16 view of this rank's slot for the NEXT collective (the projection's output tensor)."""
+        if numel > self.slot_elems:
+            raise ValueError("PeerComm: %d elements exceed the slot (%d)" % (numel, self.slot_elems))
+        off = (self._call & 1) * self.slot_elems * 2
+        t = self._mine[off: off + 2 * numel].view(torch.float16)
+        return t.view(shape) if shape is not None else t
+
+    def _next_slot_off(self):
+        off = (self._call & 1) * self.slot_elems
+        self._call += 1
+        return off
+
+    def all_reduce(self, out):
+        """out (fp16, contiguous, numel % 8 == 0) <- sum over ranks of their current slots."""
+        from . import _lib
+        n = out.numel()
+        rc = _lib.lib().omni_tp_allreduce_f16(out.data_ptr(), self._data, self._flags, self.rank, self.world,
+                                              self._next_slot_off(), n, _lib.current_stream())
+        _lib.check(rc, "omni_tp_allreduce_f16")
+
+    def add_rms_norm(self, out_i8, residual, weight, input_sum, scaling, epsilon):
+        """residual += sum over ranks of their slots; rms_norm_general[_fuse_sum](out_i8, residual, ...) (input_sum None:
+        no row sum) -- the all-reduce folded into the norm kernel."""
+        from . import _lib
+        hidden = residual.shape[-1]
+        tokens = residual.numel() // hidden
+        rc = _lib.lib().omni_tp_add_rms_norm_general_fuse_sum(
+            out_i8.data_ptr(), residual.data_ptr(), self._data, self._flags, self.rank, self.world, self._next_slot_off(),
+            weight.data_ptr(), None if input_sum is None else input_sum.data_ptr(), scaling.data_ptr(), float(epsilon),
+            tokens, hidden, _lib.current_stream())
+        _lib.check(rc, "omni_tp_add_rms_norm_general_fuse_sum")
+
+    def check_error(self):
+        words = self._mine[self.data_bytes:].view(torch.int32)
+        if int(words[18].item()) != 0:
+            raise RuntimeError("PeerComm: a wait for a peer timed out (rank %d)" % self.rank)
+
+    def close(self):
+        from . import _lib
+        lib = _lib.lib()
+        for q in self._mapped:
+            lib.omni_tp_ipc_close(q)
+        self._mapped = []
+        if self._own:
+            lib.omni_tp_free(self._own)
+            self._own = None

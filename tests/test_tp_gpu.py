@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _run_rank(rank, world, port, group_size, steps, ret):
+def _run_rank(rank, world, port, group_size, steps, ret, tp_comm=None, graph=False):
     import torch.distributed as dist
     from omniserve_amd.runtime import DecodeRunner, LlamaConfig
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -32,12 +32,16 @@ def _run_rank(rank, world, port, group_size, steps, ret):
     try:
         cfg = LlamaConfig.tiny()
         cfg.group_size = group_size
-        r = DecodeRunner(cfg, BATCH, 0, steps + 2, torch.device("cuda:0"), seed=5, use_graph=False, fused=1,
-                         tp_rank=rank, tp_size=world, shard_full=True)
+        r = DecodeRunner(cfg, BATCH, 0, steps + 2, torch.device("cuda:0"), seed=5, use_graph=graph, fused=1,
+                         tp_rank=rank, tp_size=world, shard_full=True, tp_comm=tp_comm)
         for _ in range(steps):
             r.step()
         torch.cuda.synchronize()
-        ret[(world, rank)] = (r.x.float().cpu().numpy(), r.tokens.cpu().numpy())
+        if r.comm is not None:
+            r.comm.check_error()
+        assert r.graph_error is None, r.graph_error
+        ret[(world, rank, tp_comm, graph)] = (r.x.float().cpu().numpy(), r.tokens.cpu().numpy())
+        ret[(world, rank)] = ret[(world, rank, tp_comm, graph)]
     finally:
         if world > 1:
             dist.destroy_process_group()
@@ -156,3 +160,104 @@ def test_row_parallel_projection_is_bit_exact_vs_sharded_oracle(group_size):
     for rk in range(2):
         got = ret[rk]
         assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), "rank %d differs from the sharded oracle" % rk
+
+
+def _spawn2(target, args_of_rank):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(rk, 2, port) + tuple(args_of_rank) + (ret,)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0, "rank failed (exit code %s)" % p.exitcode
+    return ret
+
+
+def _peer_allreduce_rank(rank, world, port, shapes, ret):
+    """PeerComm on its own: a sequence of all-reduces of different sizes, eagerly and from a replayed HIP graph."""
+    import torch.distributed as dist
+    from omniserve_amd import tp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        comm = tp.PeerComm(rank, world, max(shapes), dev)
+        outs = []
+        for rep, n in enumerate(shapes + shapes):                        # eager
+            g = torch.Generator(device="cpu").manual_seed(1000 * rep + 17 * n + rank)
+            comm.slot(n).copy_(torch.randn((n,), generator=g).half())
+            out = torch.empty((n,), dtype=torch.float16, device=dev)
+            comm.all_reduce(out)
+            outs.append(out.cpu().numpy())
+        # a captured pair of collectives, replayed: epochs live on the device, slot parity is baked per call
+        n = shapes[0]
+        src = torch.zeros((n,), dtype=torch.float16, device=dev)
+        o1 = torch.empty_like(src); o2 = torch.empty_like(src)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            pass
+        with torch.cuda.graph(graph):
+            comm.slot(n).copy_(src)
+            comm.all_reduce(o1)
+            comm.slot(n).copy_(o1)
+            comm.all_reduce(o2)
+        for it in range(3):
+            src.fill_(float(rank + 1 + it))
+            graph.replay()
+            torch.cuda.synchronize()
+            outs.append(o2.cpu().numpy().copy())
+        comm.check_error()
+        ret[rank] = outs
+        dist.barrier()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_allreduce_two_ranks_one_gpu():
+    """The library's own all-reduce over hipIpc-mapped peer buffers (tp.PeerComm), two processes on the one test GPU:
+    sums are bit-exact (f32 accumulate in rank order, one rounding) and identical on both ranks, eagerly and replayed from a
+    captured graph.  (On this rig the 'peer' memory is the same device: the synchronisation protocol, the slot
+    alternation and the graph capture are what is under test -- xGMI traffic is not.)"""
+    shapes = [4096, 8, 128 * 8192, 16 * 4096]
+    ret = _spawn2(_peer_allreduce_rank, (shapes,))
+    for rep, n in enumerate(shapes + shapes):
+        parts = []
+        for rk in range(2):
+            g = torch.Generator(device="cpu").manual_seed(1000 * rep + 17 * n + rk)
+            parts.append(torch.randn((n,), generator=g).half().float())
+        want = (parts[0] + parts[1]).half().numpy()
+        for rk in range(2):
+            assert np.array_equal(ret[rk][rep].view(np.uint16), want.view(np.uint16)), (rep, n, rk)
+    for it in range(3):     # graph: o1 = (1+it) + (2+it); o2 = 2 * o1
+        want = np.full((shapes[0],), 2.0 * (3 + 2 * it), np.float16)
+        for rk in range(2):
+            assert np.array_equal(ret[rk][len(shapes) * 2 + it], want), (it, rk)
+
+
+@pytest.mark.parametrize("group_size,graph", [(-1, False), (128, False), (-1, True)])
+def test_tp2_peer_comm_matches_the_collective_path_bitwise(group_size, graph):
+    """DecodeRunner(tp_comm="peer"): the two all-reduces per layer run on PeerComm, folded into the add + norm kernel
+    (one launch for all-reduce + residual add + norm + quant).  At world 2 the fp32-accumulated sum has one rounding, as
+    the host-staged gloo path of this rig and an fp16 RCCL ring have: hidden states and tokens must be bit-identical to
+    the torch.distributed path, on both ranks, eagerly and with the whole step in one HIP graph."""
+    steps = 3
+    ref = _spawn2(_run_rank, (group_size, steps))
+    got = _spawn2(_run_rank_peer, (group_size, steps, graph))
+    for rk in range(2):
+        xr, tr = ref[(2, rk)]
+        xg, tg = got[(2, rk)]
+        assert np.array_equal(xr, xg) and np.array_equal(tr, tg), "rank %d: peer collective differs" % rk
+    assert np.array_equal(got[(2, 0)][0], got[(2, 1)][0])
+
+
+def _run_rank_peer(rank, world, port, group_size, steps, graph, ret):
+    _run_rank(rank, world, port, group_size, steps, ret, tp_comm="peer", graph=graph)
