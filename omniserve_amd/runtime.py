@@ -132,9 +132,11 @@ class DecodeRunner:
         # tp_comm = "peer": the decode step's collectives run on the library's own peer-mapped all-reduce (tp.PeerComm: one
         # launch per collective, folded into the add + norm kernel where one follows) instead of torch.distributed / RCCL
         self.comm = None
-        if self.tp_size > 1 and (tp_comm if tp_comm is not None else os.environ.get("OMNI_TP_COMM", "")) == "peer":
+        tp_comm = tp_comm if tp_comm is not None else os.environ.get("OMNI_TP_COMM", "")
+        if self.tp_size > 1 and tp_comm in ("peer", "loopback"):      # "loopback": one process, all peers = this rank (timing only)
             from . import tp
-            self.comm = tp.PeerComm(self.tp_rank, self.tp_size, batch * cfg.hidden, device, tp_group)
+            self.comm = tp.PeerComm(self.tp_rank, self.tp_size, batch * cfg.hidden, device, tp_group,
+                                    loopback=tp_comm == "loopback")
         if cfg.heads % self.tp_size or cfg.kv_heads % self.tp_size or cfg.inter % (128 * self.tp_size):
             raise ValueError("heads / kv_heads / intermediate size not divisible by the TP degree")
         self.hl, self.kl, self.il = cfg.heads // self.tp_size, cfg.kv_heads // self.tp_size, cfg.inter // self.tp_size

@@ -89,12 +89,15 @@ class PeerComm:
         def __init__(self, ptr, nbytes):
             self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
-    def __init__(self, rank, world, max_elems, device, group=None):
+    def __init__(self, rank, world, max_elems, device, group=None, loopback=False):
+        """loopback=True (single process, measurements only): every "peer" is this rank's own buffer, so a collective of
+        `world` ranks runs with all flags raised by the caller itself -- the kernels' cost without any fabric traffic."""
         import ctypes
         import torch.distributed as dist
         from . import _lib
         if world > 8:
             raise ValueError("PeerComm supports up to 8 ranks")
+        self.loopback = bool(loopback)
         self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
         self.slot_elems = (int(max_elems) + 7) // 8 * 8
         self.data_bytes = 2 * self.slot_elems * 2
@@ -107,14 +110,14 @@ class PeerComm:
             h = (ctypes.c_ubyte * 64)()
             _lib.check(lib.omni_tp_ipc_handle(self._own, h), "omni_tp_ipc_handle")
             handles = [None] * world
-            if world > 1:
+            if world > 1 and not loopback:
                 dist.all_gather_object(handles, bytes(h), group=group)
             else:
                 handles[0] = bytes(h)
             self._mapped = []
             bases = []
             for r in range(world):
-                if r == rank:
+                if r == rank or loopback:
                     bases.append(self._own)
                     continue
                 q = ctypes.c_void_p()
@@ -123,10 +126,13 @@ class PeerComm:
                 self._mapped.append(q.value)
                 bases.append(q.value)
         self._data = (ctypes.c_void_p * world)(*bases)
-        self._flags = (ctypes.c_void_p * world)(*[b + self.data_bytes for b in bases])
+        if loopback:     # flag word [rank] of "peer" p = word p of the own array: the caller's publishing threads raise them all
+            self._flags = (ctypes.c_void_p * world)(*[self._own + self.data_bytes + 4 * (p - rank) for p in range(world)])
+        else:
+            self._flags = (ctypes.c_void_p * world)(*[b + self.data_bytes for b in bases])
         self._mine = torch.as_tensor(self._Blob(self._own, self.nbytes), device=self.device)
         self._call = 0
-        if world > 1:
+        if world > 1 and not loopback:
             dist.barrier(group=group)      # nobody publishes before every rank has mapped every buffer
 
     def slot(self, numel, shape=None):
