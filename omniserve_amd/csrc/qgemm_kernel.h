@@ -118,6 +118,8 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   // candidates of tools/lds_transpose_probe.hip whose write costs what a lane-linear one does (row ^ 4 piece: +23 %).
   constexpr bool W8C = MODE == MODE_W8 && OMNI_GEMM_W8_COALESCED;
   __shared__ __attribute__((aligned(16))) uint8_t wtr[W8C ? WAVES * 1024 : 16];
+  __shared__ __attribute__((aligned(16))) uint32_t epi_w[TO_SLAB ? 4 : 64 * WAVES];   // {wscale, w_sz} per channel of the tile
+  __shared__ uint32_t epi_a[TO_SLAB ? 4 : MT];                                          // {ascale, asum} per row of the tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -252,6 +254,25 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
     for (int j = 0; j < WL; ++j) wq[s][j] = load_w(k_begin + ks * KSTEP, j);
   }
   load_a(0, false);
+  // Epilogue operands -> LDS (published by the first chunk's barrier): the write-back reads them with LDS latency.  Round 2
+  // read them from global memory inside the write-back loop, per row block: 32 dependent memory round trips per wave = the
+  // time of ~5 K chunks per tile (K = 4096 ran at 0.44 of the int8 peak where K = 14336 reached 0.55).
+  if constexpr (!TO_SLAB) {
+    for (int i = tid; i < 64 * WAVES; i += NTHREADS) {
+      const int n = min(tile_n * 64 * WAVES + i, p.N - 1);
+      const uint32_t sw = __builtin_bit_cast(uint16_t, p.wscales[n]);
+      uint32_t sz = 0;
+      if constexpr (MODE == MODE_CHN) sz = __builtin_bit_cast(uint16_t, p.wsz[n]);
+      epi_w[i] = sw | (sz << 16);
+    }
+    for (int i = tid; i < MT; i += NTHREADS) {
+      const int m = min(m0 + i, p.M - 1);
+      const uint32_t sa = __builtin_bit_cast(uint16_t, p.ascales[m]);
+      uint32_t as = 0;
+      if constexpr (MODE == MODE_CHN) as = __builtin_bit_cast(uint16_t, p.asum[m]);
+      epi_a[i] = sa | (as << 16);
+    }
+  }
   store_a(0);
 
   // per-group second-level params for the current chunk (2 groups of 128 per chunk)
@@ -427,33 +448,38 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
     if (m >= p.M) continue;
     float sa = 0.f, as = 0.f;
     if constexpr (!TO_SLAB) {
-      sa = (float)p.ascales[m];
-      if constexpr (MODE == MODE_CHN) as = (float)p.asum[m];
+      const uint32_t av = epi_a[mb * 16 + mcol];
+      sa = (float)__builtin_bit_cast(half_t, (uint16_t)(av & 0xFFFFu));
+      as = (float)__builtin_bit_cast(half_t, (uint16_t)(av >> 16));
     }
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) {
-      int n;
-      if constexpr (MODE == MODE_W8) n = ng * 64 + ab * 16 + i0;
-      else n = ng * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
+      int n, nl;     // channel, and its index inside the workgroup's tile
+      if constexpr (MODE == MODE_W8) nl = wave * 64 + ab * 16 + i0;
+      else nl = wave * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
+      n = tile_n * 64 * WAVES + nl;
       const v4i a4 = acc[mb][ab];
       if constexpr (TO_SLAB) {
         int32_t* dst = p.slab + ((size_t)blockIdx.y * p.M + m) * p.N + n;
         *reinterpret_cast<v4i*>(dst) = a4;
       } else {
+        const uint4 w4 = *reinterpret_cast<const uint4*>(&epi_w[nl]);      // {wscale, w_sz} x 4 channels
+        const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
         half_t o[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sw = (float)p.wscales[n + r];
-          float sz = 0.f;
-          if constexpr (MODE == MODE_CHN) sz = (float)p.wsz[n + r];
-          o[r] = epilogue<MODE>(a4[r], sw, sa, sz, as);
-        }
+        for (int r = 0; r < 4; ++r)
+          o[r] = epilogue<MODE>(a4[r], (float)__builtin_bit_cast(half_t, (uint16_t)(wv[r] & 0xFFFFu)), sa,
+                                (float)__builtin_bit_cast(half_t, (uint16_t)(wv[r] >> 16)), as);
         *reinterpret_cast<uint2*>(p.out + (size_t)m * p.out_stride + n) =
             *reinterpret_cast<const uint2*>(o);
       }
     }
   }
 }
+
+}  // namespace omni
+#include "qgemm_exact.h"
+namespace omni {
 
 // Rider workgroup of the fp16-input GEMV (A16): activation row blockIdx.x.  Replays invoke_quant_fuse_sum's row sum --
 // thread t of min(K, 1024) virtual threads adds x[t], x[t + nv], ... in f32, then the 32-lane / 32-warp butterflies
@@ -1040,6 +1066,17 @@ static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st
   dim3 grid(b.tiles_n, 1, b.tiles_m);
   b.tiles_n = b.tiles_m = 0;
 #endif
+  // exact shapes (the models' projections at prefill): the straight-line kernel of qgemm_exact.h
+  static const int exact_mode = [] { const char* e = getenv("OMNI_GEMM_EXACT"); return e ? atoi(e) : 1; }();   // 0: off (A/B)
+  // (per-group mode stays on the generic kernel for now: its dequant temporaries spill in the exact form -- OMNI_GEMM_EXACT=3 forces it)
+  if (MB == 8 && WAVES == 4 && exact_mode != 0 && (MODE != MODE_GRP || exact_mode == 3) && a.M % 128 == 0 && a.N % 256 == 0 && a.K % KCHUNK == 0 && b.kslice >= a.K &&
+      (size_t)a.M * a.K < ((size_t)1 << 32)) {
+    if (OMNI_GEMM_EXACT_DMA && exact_mode != 2)
+      hipLaunchKernelGGL((w4a8_gemm_exact_kernel<MODE, true>), grid, dim3(256), 0, st, b);
+    else
+      hipLaunchKernelGGL((w4a8_gemm_exact_kernel<MODE, false>), grid, dim3(256), 0, st, b);
+    return;
+  }
   hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, false>), grid, dim3(64 * WAVES), 0, st, b);
 }
 
