@@ -52,3 +52,9 @@ extern "C" int omni_w4a8_per_chn_gemm_partial_f16(const void* act_f16, const voi
 }
 
 OMNI_CLK_READER(omni_debug_clocks_gemm_chn)
+#ifdef OMNI_DEBUG_CLOCKS
+// timeline probe of the exact prefill kernel (tools/gemm_timeline.py): 4 marks per workgroup
+extern "C" int omni_debug_timeline_gemm_chn(unsigned long long* out, int nwg) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(omni::omni_dbg_tl), (size_t)nwg * 5 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
+}
+#endif

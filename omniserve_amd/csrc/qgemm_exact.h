@@ -31,9 +31,13 @@ namespace omni {
 #define OMNI_GEMM_EXACT_PIN 1
 #endif
 
+#ifndef OMNI_GEMM_EXACT_SWP
+#define OMNI_GEMM_EXACT_SWP 0     // measured in the ISA only: the fence splits the B-read pipeline (read -> lgkmcnt(0) -> 4 MFMAs)
+#endif
+
 #ifdef OMNI_DEBUG_CLOCKS
 // timeline probe: per workgroup (wave 0) entry / first chunk / after the K loop / after the stores (100 MHz ticks)
-static __device__ unsigned long long omni_dbg_tl[4 * 8192];
+static __device__ unsigned long long omni_dbg_tl[5 * 8192];
 #endif
 
 // eight LDS-DMA pieces of one wave: piece i covers the 4 rows (i * 4 .. + 3) of the wave's 32, LDS image lane-linear
@@ -109,6 +113,10 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
   const int ng = tile_n * WAVES + wave;  // 64-channel group of this wave
   const int m0 = tile_m * MT;
   const int nchunks = p.K / KCHUNK;
+  // (Two workgroups share a CU, one wave of each per SIMD, and the arbiter strictly favours the OLDER wave: per-workgroup
+  // clocks show the first-dispatched workgroup of every CU running its K loop in 30 us and the second in 46, the last 16
+  // alone at 2/3 of the paired rate.  s_setprio flips or time-slices that at will -- and the pair finishes at the same
+  // time whatever the split: profiles/r03_d.  No priority code here.)
 
   // ---- weights: HBM / L2 -> VGPR ring (as w4a8_gemm_kernel) ---------------------------------------------
   const int lx = (lane >> 3) & 1, lc = lane & 7, le = lane >> 4;
@@ -261,16 +269,8 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
     __syncthreads();          // chunk c is visible in lds[c & 1]; everybody is done reading lds[(c + 1) & 1]
     const uint8_t* abuf = lds[c & 1];
 
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      // The next tile's DMA goes out HERE, not at the chunk's top: hipcc's counted waits for the weight ring do not see
-      // the eight DMA operations, so every vmcnt(N) it emits behind them also drains N-relative DMA pieces.  It unpacks the
-      // ring early in the chunk (waits in step 0): issued at the top, the DMA was waited for ~one MFMA later.  The
-      // statement orders LDS reads around it, but it lands behind step 0's last B read, three MFMA groups before the seam.
-      if constexpr (NEXT) {
-        if (s == 1) dma_chunk(c + 1, (c + 1) & 1);
-      }
-      v4i wa[4];
+    // unpack (+ lane transpose / per-group dequant) of k-step s into MFMA A operands
+    auto unpack = [&](int s, v4i (&wa)[4]) {
       if constexpr (W8C) {
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {      // LDS is in order within a wave: no wait between the write and the read
@@ -315,11 +315,36 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
             wa[a * 2 + b] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
           }
       }
-      // refill this step's weight registers with the step WRING ahead
+    };
+    // refill step s's weight registers with the step WRING ahead
+    auto refill = [&](int s) {
       if (NEXT || s + WRING < STEPS) {
 #pragma unroll
         for (int j = 0; j < WL; ++j) wq[s % WRING][j] = load_w(kc + (s + WRING) * KSTEP, j);
         if constexpr (NEXT && !ADMA) __builtin_amdgcn_sched_barrier(0x78F);
+      }
+    };
+    // Explicit one-step software pipeline (SWP): step s + 1 is unpacked inside step s, behind a VALU fence at the step
+    // seam (sched_barrier that lets everything but VALU cross).  Left alone hipcc unpacks ALL four steps in front of step 0:
+    // 64 operand registers live (the per-group kernel spilled on them) and a VALU burst in front of the first MFMAs.
+    constexpr bool SWP = OMNI_GEMM_EXACT_SWP != 0;
+    v4i wa[SWP ? 2 : 1][4];
+    if constexpr (SWP) { unpack(0, wa[0]); refill(0); }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      // The next tile's DMA goes out HERE, not at the chunk's top: hipcc's counted waits for the weight ring do not see
+      // the eight DMA operations, so every vmcnt(N) it emits behind them also drains N-relative DMA pieces.  Issued at the
+      // top, the DMA was waited for ~one MFMA later.  The statement orders LDS reads around it, but it lands behind step
+      // 0's last B read, three MFMA groups before the seam.
+      if constexpr (NEXT) {
+        if (s == 1) dma_chunk(c + 1, (c + 1) & 1);
+      }
+      if constexpr (SWP) {
+        __builtin_amdgcn_sched_barrier(0x3FC);
+        if (s + 1 < STEPS) { unpack(s + 1, wa[(s + 1) & 1]); refill(s + 1); }
+      } else {
+        unpack(s, wa[0]);
+        refill(s);
       }
       v4i bf[MB];
 #pragma unroll
@@ -331,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab)
-          acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf[mb], acc[mb][ab], 0, 0, 0);
+          acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[SWP ? (s & 1) : 0][ab], bf[mb], acc[mb][ab], 0, 0, 0);
     }
     if constexpr (OMNI_GEMM_PIPE_B && MODE == MODE_CHN) {   // B-operand reads three row blocks ahead over the whole chunk
       constexpr int PRE = 3;
@@ -343,6 +368,8 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
         // chunk of MFMAs ahead of its use: left alone the scheduler sinks all eight loads to the end of the chunk, ~200
         // cycles in front of the wait that needs them (ADMA only: the register-staged form has no registers for it)
         if (NEXT && ADMA && OMNI_GEMM_EXACT_PIN && (i % MB) == 0) __builtin_amdgcn_sched_group_barrier(0x020, WL, 0);
+        // (giving the unpack VALU slots in this pipeline -- sched_group_barrier(0x002, 4) per MFMA group -- makes the
+        // solver bunch the B reads of a step behind lgkmcnt(0) waits: profiles/r03_d; the compiler's own placement stays)
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * PRE, 0);
@@ -366,29 +393,58 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
   // W4: i = x * 8 + c, channel = ng * 64 + x * 32 + ab * 8 + c (4 consecutive channels per lane); W8: ng * 64 + ab * 16 + i.
   const int mcol = lane & 15;
   const int i0 = (lane >> 4) * 4;
-  auto finish4 = [&](const v4i a4, int ab, int mb) -> uint2 {     // 4 consecutive channels of one row -> 4 fp16
+  // The lane's 16 channels are the same for every row block: their scales are converted once (32 registers the K loop
+  // no longer needs); the arithmetic runs on float pairs (v_pk_mul_f32 / v_pk_add_f32: the reference's three products and one
+  // difference, each rounded to f32 -- -ffp-contract=off) and the pair is made opaque before the fp16 conversion (see
+  // epilogue_exact: no v_fma_mixlo_f16 folding).  ~3.5 VALU per output instead of ~10.
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+  v2f swf[4][2], szf[4][2];
+#pragma unroll
+  for (int ab = 0; ab < 4; ++ab) {
     int nl;
     if constexpr (MODE == MODE_W8) nl = wave * 64 + ab * 16 + i0;
     else nl = wave * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
     const uint4 w4 = *reinterpret_cast<const uint4*>(&epi_w[nl]);      // {wscale, w_sz} x 4 channels
     const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
-    const uint32_t av = epi_a[mb * 16 + mcol];                         // {ascale, asum} of the row
-    const float sa = (float)__builtin_bit_cast(half_t, (uint16_t)(av & 0xFFFFu));
-    const float as = (float)__builtin_bit_cast(half_t, (uint16_t)(av >> 16));
-    half_t o[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      o[r] = epilogue_exact<MODE>(a4[r], (float)__builtin_bit_cast(half_t, (uint16_t)(wv[r] & 0xFFFFu)), sa,
-                                  (float)__builtin_bit_cast(half_t, (uint16_t)(wv[r] >> 16)), as);
-    return *reinterpret_cast<const uint2*>(o);
+    for (int h = 0; h < 2; ++h) {
+      swf[ab][h] = (v2f){(float)__builtin_bit_cast(half_t, (uint16_t)(wv[2 * h] & 0xFFFFu)),
+                         (float)__builtin_bit_cast(half_t, (uint16_t)(wv[2 * h + 1] & 0xFFFFu))};
+      szf[ab][h] = (v2f){(float)__builtin_bit_cast(half_t, (uint16_t)(wv[2 * h] >> 16)),
+                         (float)__builtin_bit_cast(half_t, (uint16_t)(wv[2 * h + 1] >> 16))};
+    }
+  }
+  auto finish4 = [&](const v4i a4, int ab, float sa, float as) -> uint2 {     // 4 consecutive channels of one row -> 4 fp16
+    uint32_t o[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const v2f f = (v2f){(float)a4[2 * h], (float)a4[2 * h + 1]};
+      v2f r;
+      if constexpr (MODE == MODE_CHN) {
+        v2f t = f * swf[ab][h];
+        t = t * sa;
+        const v2f c = szf[ab][h] * as;
+        r = t - c;
+      } else {
+        const v2f sc = swf[ab][h] * sa;
+        r = f * sc;
+      }
+      asm volatile("" : "+v"(r));
+      o[h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, v2h));
+    }
+    return make_uint2(o[0], o[1]);
   };
   const int odd = (lane >> 4) & 1;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m = m0 + mb * 16 + mcol;
+    const uint32_t av = epi_a[mb * 16 + mcol];                         // {ascale, asum} of the row
+    const float sa = (float)__builtin_bit_cast(half_t, (uint16_t)(av & 0xFFFFu));
+    const float as = (float)__builtin_bit_cast(half_t, (uint16_t)(av >> 16));
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
-      const uint2 x = finish4(acc[mb][2 * pr], 2 * pr, mb), y = finish4(acc[mb][2 * pr + 1], 2 * pr + 1, mb);
+      const uint2 x = finish4(acc[mb][2 * pr], 2 * pr, sa, as), y = finish4(acc[mb][2 * pr + 1], 2 * pr + 1, sa, as);
       const auto lo = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
       const auto hi = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
       int n8;
@@ -400,10 +456,13 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
   }
 #ifdef OMNI_DEBUG_CLOCKS
   if (tid == 0 && blockIdx.x < 8192) {
-    omni_dbg_tl[blockIdx.x * 4 + 0] = tl0;
-    omni_dbg_tl[blockIdx.x * 4 + 1] = tl1;
-    omni_dbg_tl[blockIdx.x * 4 + 2] = tl2;
-    omni_dbg_tl[blockIdx.x * 4 + 3] = wall_clock64();
+    uint32_t hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    omni_dbg_tl[blockIdx.x * 5 + 0] = tl0;
+    omni_dbg_tl[blockIdx.x * 5 + 1] = tl1;
+    omni_dbg_tl[blockIdx.x * 5 + 2] = tl2;
+    omni_dbg_tl[blockIdx.x * 5 + 3] = wall_clock64();
+    omni_dbg_tl[blockIdx.x * 5 + 4] = ((unsigned long long)xcc_id() << 32) | hwid;   // (wave 0's: slot bits 3:0, SIMD 5:4, CU 11:8)
   }
 #endif
 }
