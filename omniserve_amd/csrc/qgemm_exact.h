@@ -308,9 +308,9 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
             if constexpr (MODE == MODE_GRP) {
               const int h = s >> 1;  // group inside the chunk
               const uint32_t sc = (gs[h] >> (8 * (a * 2 + b))) & 0xFFu;
-              const uint32_t zr = ((gz[h] >> (8 * (a * 2 + b))) & 0xFFu) * 0x01010101u;
 #pragma unroll
-              for (int q = 0; q < 4; ++q) u[q] = vadd4(u[q] * sc, zr);
+              for (int q = 0; q < 4; ++q) u[q] = u[q] * sc;
+              vadd4_zbyte_x4(u, gz[h], a * 2 + b);
             }
             wa[a * 2 + b] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
           }

@@ -64,6 +64,117 @@ static inline int gemv_dbg_flags() {
 __device__ __forceinline__ uint32_t vadd4(uint32_t x, uint32_t y) {
   return ((x & 0x7f7f7f7fu) + (y & 0x7f7f7f7fu)) ^ ((x ^ y) & 0x80808080u);
 }
+// __vadd4(x, z * 0x01010101) with z = byte ZB of `zw` -- the second-level zero point of one (group, channel), four of which
+// sit in one dword of the permuted parameter array: four SDWA byte adds (each keeps the low byte of x.byte_j + z and leaves
+// the other bytes alone) instead of extracting z, replicating it with a quarter-rate multiply and the six-operation
+// carry-free add.  The per-group kernels are VALU bound (184 op-equivalents per 64-k step against 32 MFMAs).
+#ifndef OMNI_GRP_SDWA
+#define OMNI_GRP_SDWA 1
+#endif
+// Four words at a time, byte by byte across the words: on gfx950 a VALU result written with dst_sel != DWORD may not be read
+// by the very next VALU instruction (one wait state; hipcc pads its own code, not the inside of an asm statement) -- the first
+// version, four byte adds per word back to back, returned wrong bytes.  Interleaved, three instructions separate the writes
+// of one register; the statement's outputs are read by compiler code, which gets hipcc's boundary pad.
+template <int ZB>
+__device__ __forceinline__ void vadd4_zbyte_x4(uint32_t (&u)[4], uint32_t zw) {
+#if OMNI_GRP_SDWA
+  uint32_t r0, r1, r2, r3;
+  if constexpr (ZB == 0) {
+    asm("v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_0"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(zw));
+  }
+  else if constexpr (ZB == 1) {
+    asm("v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_1"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(zw));
+  }
+  else if constexpr (ZB == 2) {
+    asm("v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_2\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_2"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(zw));
+  }
+  else {
+    asm("v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
+        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(zw));
+  }
+  u[0] = r0; u[1] = r1; u[2] = r2; u[3] = r3;
+#else
+  const uint32_t zr = ((zw >> (8 * ZB)) & 0xFFu) * 0x01010101u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) u[q] = vadd4(u[q], zr);
+#endif
+}
+// (zb is a constant after unrolling: one statement survives)
+__device__ __forceinline__ void vadd4_zbyte_x4(uint32_t (&u)[4], uint32_t zw, int zb) {
+  switch (zb) {
+    case 0: vadd4_zbyte_x4<0>(u, zw); break;
+    case 1: vadd4_zbyte_x4<1>(u, zw); break;
+    case 2: vadd4_zbyte_x4<2>(u, zw); break;
+    default: vadd4_zbyte_x4<3>(u, zw); break;
+  }
+}
 
 template <int MODE>
 __device__ __forceinline__ half_t epilogue(int acc, float sw, float sa, float sz, float asum) {
@@ -356,9 +467,9 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
               if constexpr (MODE == MODE_GRP) {
                 const int h = s >> 1;  // group inside the chunk
                 const uint32_t sc = (gs[h] >> (8 * (a * 2 + b))) & 0xFFu;
-                const uint32_t zr = ((gz[h] >> (8 * (a * 2 + b))) & 0xFFu) * 0x01010101u;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) u[q] = vadd4(u[q] * sc, zr);
+                for (int q = 0; q < 4; ++q) u[q] = u[q] * sc;
+                vadd4_zbyte_x4(u, gz[h], a * 2 + b);
               }
               wa[a * 2 + b] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
             }
@@ -528,6 +639,9 @@ __device__ __forceinline__ void a16_rider(const GemmArgs& p, float* xs, float* r
 #ifndef OMNI_GEMV_AR_MB4
 #define OMNI_GEMV_AR_MB4 2      // k-steps per activation round of the 64-row tile: 2 = 8-KiB rounds, four K parts per
 #endif                          // workgroup, two waves per SIMD (measured 10-15 % faster at M = 64 than 4 = 16-KiB rounds, two parts)
+#ifndef OMNI_GEMV_FENCE_REFILL
+#define OMNI_GEMV_FENCE_REFILL 1
+#endif
 #ifndef OMNI_GEMV_ABLATE
 #define OMNI_GEMV_ABLATE 0      // timing experiments (wrong results): 1 no activation reloads, 2 a quarter of the MFMAs,
 #endif                          // 4 no weight reloads, 8 no LDS publication of the next activation round
@@ -771,9 +885,9 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
           for (int q = 0; q < 4; ++q) u[q] = (d[b][q] >> (4 * a)) & 0x0F0F0F0Fu;
           if constexpr (MODE == MODE_GRP) {
             const uint32_t sc = (sc4 >> (8 * (a * 2 + b))) & 0xFFu;
-            const uint32_t zr = ((zr4 >> (8 * (a * 2 + b))) & 0xFFu) * 0x01010101u;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) u[q] = vadd4(u[q] * sc, zr);
+            for (int q = 0; q < 4; ++q) u[q] = u[q] * sc;
+            vadd4_zbyte_x4(u, zr4, a * 2 + b);
           }
           wa[a * 2 + b] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
         }
@@ -843,6 +957,11 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
             gs[slot] = load_gp(p.s2s, kn);
             gz[slot] = load_gp(p.s2z, kn);
           }
+          // 32-/64-row tiles: fence the refill in place.  Left alone hipcc sinks every refill of the round behind the
+          // round's last MFMA -- the ISA then waits vmcnt(7..0) at the top of the next round for loads issued a few
+          // cycles earlier: one exposed HBM round trip per round, covered only by the other wave of the SIMD (the M <= 16
+          // kernel, eight steps per round, keeps its refills where they are written).
+          if constexpr (OMNI_GEMV_FENCE_REFILL && MB > 1) __builtin_amdgcn_sched_barrier(0);
           mma_step(wa, abuf, s);
         }
 #if !(OMNI_GEMV_ABLATE & 8)
@@ -1068,8 +1187,7 @@ static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st
 #endif
   // exact shapes (the models' projections at prefill): the straight-line kernel of qgemm_exact.h
   static const int exact_mode = [] { const char* e = getenv("OMNI_GEMM_EXACT"); return e ? atoi(e) : 1; }();   // 0: off (A/B)
-  // (per-group mode stays on the generic kernel for now: its dequant temporaries spill in the exact form -- OMNI_GEMM_EXACT=3 forces it)
-  if (MB == 8 && WAVES == 4 && exact_mode != 0 && (MODE != MODE_GRP || exact_mode == 3) && a.M % 128 == 0 && a.N % 256 == 0 && a.K % KCHUNK == 0 && b.kslice >= a.K &&
+  if (MB == 8 && WAVES == 4 && exact_mode != 0 && a.M % 128 == 0 && a.N % 256 == 0 && a.K % KCHUNK == 0 && b.kslice >= a.K &&
       (size_t)a.M * a.K < ((size_t)1 << 32)) {
     if (OMNI_GEMM_EXACT_DMA && exact_mode != 2)
       hipLaunchKernelGGL((w4a8_gemm_exact_kernel<MODE, true>), grid, dim3(256), 0, st, b);
