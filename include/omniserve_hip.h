@@ -108,6 +108,19 @@ int omni_rms_norm_general_fuse_sum(void* out_i8, const void* in_f16, const void*
  *   (kernels/csrc/activation_kernels.cu:10-30,84-97): in fp16 [tokens, 2d] -> out [tokens, d]. */
 int omni_silu_and_mul(void* out_f16, const void* in_f16, int tokens, int d, void* stream);
 
+/* bf16 / fp32 element types of the four functions above (csrc/row_dtypes.hip).  Upstream dispatches them over float, half
+ * and bfloat16 (VLLM_DISPATCH_FLOATING_TYPES, kernels/csrc/dispatch_utils.h:7-14; launches fused_kernels.cu:212-272,
+ * layernorm_kernels.cu:408-513, activation_kernels.cu:84-97); the entry points above are the `half` case.  dtype: 1 = bf16,
+ * 2 = fp32 (0 = fp16 is rejected here: use the entry points above).  in / weight / out (rms_norm, silu_and_mul) are of that
+ * type; scales and sums stay fp16 (`at::Half` upstream), quantised outputs int8.  sum_f16_or_null selects the _fuse_sum form.
+ * Rounding points follow T as upstream: the general norm rounds y, its running maximum and its per-thread running sum to T. */
+int omni_quant_dt(void* out_i8, const void* in, void* sum_f16_or_null, void* scale_f16, int tokens, int hidden, int dtype,
+                  void* stream);
+int omni_rms_norm_general_dt(void* out_i8, const void* in, const void* weight, void* sum_f16_or_null, void* scale_f16,
+                             float eps, int tokens, int hidden, int dtype, void* stream);
+int omni_rms_norm_dt(void* out, const void* in, const void* weight, float eps, int tokens, int hidden, int dtype, void* stream);
+int omni_silu_and_mul_dt(void* out, const void* in, int tokens, int d, int dtype, void* stream);
+
 /* ---- Overloads of the same three modules that the Llama W4A8 / W8A8 model code does not call --------
  * (csrc/offpath.hip).  `float scale` arguments bound to `at::Half` parameters upstream are rounded to fp16
  * inside.  Rows: hidden (d) % 8 == 0; the three norms additionally need hidden <= 16256 and, where the

@@ -35,6 +35,10 @@ PROTOTYPES = {
     "omni_rms_norm_general": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "omni_rms_norm_general_fuse_sum": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "omni_silu_and_mul": (_i, [_vp, _vp, _i, _i, _vp]),
+    "omni_quant_dt": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "omni_rms_norm_general_dt": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp]),
+    "omni_rms_norm_dt": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _vp]),
+    "omni_silu_and_mul_dt": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "omni_quant_static": (_i, [_vp, _vp, _f, _i, _i, _vp]),
     "omni_dequant": (_i, [_vp, _vp, _f, _i, _i, _c.c_longlong, _c.c_longlong, _vp]),
     "omni_dequant_add_residual": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
@@ -129,6 +133,18 @@ def current_stream() -> int:
     if _raw_stream is not None:
         return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+def elem_dtype(t, what: str) -> int:
+    """0 / 1 / 2 for fp16 / bf16 / fp32 tensors (the element types the reference's row kernels are dispatched over,
+    kernels/csrc/dispatch_utils.h:7-14); anything else raises like AT_DISPATCH would."""
+    if t.dtype == torch.float16:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    if t.dtype == torch.float32:
+        return 2
+    raise RuntimeError('"%s" not implemented for \'%s\'' % (what, str(t.dtype).replace("torch.", "")))
 
 
 def require_cuda(*tensors) -> None:

@@ -9,6 +9,12 @@ def silu_and_mul(out, input):
     _lib.require_cuda(out, input)
     d = input.shape[-1] // 2
     tokens = input.numel() // input.shape[-1]
+    dt = _lib.elem_dtype(input, "silu_and_mul_kernel")      # fp16 (hot path) | bf16 | fp32, as the reference dispatches
+    if out.dtype != input.dtype:
+        raise RuntimeError("silu_and_mul: out and input must have the same dtype")
+    if dt != 0:
+        rc = _lib.lib().omni_silu_and_mul_dt(out.data_ptr(), input.data_ptr(), tokens, d, dt, _lib.current_stream())
+        return _lib.check(rc, "activation_ops.silu_and_mul")
     rc = _lib.lib().omni_silu_and_mul(out.data_ptr(), input.data_ptr(), tokens, d, _lib.current_stream())
     _lib.check(rc, "activation_ops.silu_and_mul")
 

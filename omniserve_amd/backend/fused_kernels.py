@@ -31,6 +31,11 @@ def invoke_quant(out, input, scale):
     tokens, hidden = _shape(out, input)
     if tokens == 0:
         return
+    dt = _lib.elem_dtype(input, "quant_kernel")       # fp16 (hot path) | bf16 | fp32, as the reference dispatches
+    if dt != 0:
+        rc = _lib.lib().omni_quant_dt(out.data_ptr(), input.data_ptr(), None, scale.data_ptr(), tokens, hidden, dt,
+                                      _lib.current_stream())
+        return _lib.check(rc, "fused_kernels.invoke_quant")
     rc = _lib.lib().omni_quant(out.data_ptr(), input.data_ptr(), scale.data_ptr(), tokens, hidden,
                                _lib.current_stream())
     _lib.check(rc, "fused_kernels.invoke_quant")
@@ -46,6 +51,11 @@ def invoke_quant_fuse_sum(out, input, input_sum, scale):
     tokens, hidden = _shape(out, input)
     if tokens == 0:
         return
+    dt = _lib.elem_dtype(input, "quant_kernel_fuse_sum")
+    if dt != 0:
+        rc = _lib.lib().omni_quant_dt(out.data_ptr(), input.data_ptr(), input_sum.data_ptr(), scale.data_ptr(), tokens,
+                                      hidden, dt, _lib.current_stream())
+        return _lib.check(rc, "fused_kernels.invoke_quant_fuse_sum")
     rc = _lib.lib().omni_quant_fuse_sum(out.data_ptr(), input.data_ptr(), input_sum.data_ptr(),
                                         scale.data_ptr(), tokens, hidden, _lib.current_stream())
     _lib.check(rc, "fused_kernels.invoke_quant_fuse_sum")

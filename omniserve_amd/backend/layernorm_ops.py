@@ -18,6 +18,17 @@ def rms_norm(out, input, weight, epsilon, use_quant=False):
         raise RuntimeError("rms_norm(use_quant=True): int8 output expected")
     if use_quant and tokens == 0:
         return
+    dt = _lib.elem_dtype(input, "rms_norm_kernel")      # fp16 (hot path) | bf16 | fp32, as the reference dispatches
+    if weight.dtype != input.dtype:
+        raise RuntimeError("rms_norm: weight and input must have the same dtype")
+    if dt != 0:
+        if use_quant:
+            raise NotImplementedError("rms_norm(use_quant=True) is built for fp16 inputs only (no caller upstream)")
+        if out.dtype != input.dtype:
+            raise RuntimeError("rms_norm: out and input must have the same dtype")
+        rc = _lib.lib().omni_rms_norm_dt(out.data_ptr(), input.data_ptr(), weight.data_ptr(), float(epsilon), tokens, hidden, dt,
+                                         _lib.current_stream())
+        return _lib.check(rc, "layernorm_ops.rms_norm")
     rc = fn(out.data_ptr(), input.data_ptr(), weight.data_ptr(), float(epsilon), tokens, hidden, _lib.current_stream())
     _lib.check(rc, "layernorm_ops.rms_norm")
 
@@ -30,6 +41,15 @@ def rms_norm_general(out, input, weight, scaling, epsilon, use_per_token_quant=F
     fn = _lib.lib().omni_rms_norm_general if use_per_token_quant else _lib.lib().omni_rms_norm_general_static
     if tokens == 0 and not use_per_token_quant:
         return
+    dt = _lib.elem_dtype(input, "generalLayerNorm")
+    if weight.dtype != input.dtype:
+        raise RuntimeError("rms_norm_general: weight and input must have the same dtype")
+    if dt != 0:
+        if not use_per_token_quant:
+            raise NotImplementedError("rms_norm_general (per-tensor scale) is built for fp16 inputs only (no caller upstream)")
+        rc = _lib.lib().omni_rms_norm_general_dt(out.data_ptr(), input.data_ptr(), weight.data_ptr(), None, scaling.data_ptr(),
+                                                 float(epsilon), tokens, hidden, dt, _lib.current_stream())
+        return _lib.check(rc, "layernorm_ops.rms_norm_general")
     rc = fn(out.data_ptr(), input.data_ptr(), weight.data_ptr(), scaling.data_ptr(), float(epsilon), tokens, hidden,
             _lib.current_stream())
     _lib.check(rc, "layernorm_ops.rms_norm_general")
@@ -41,6 +61,13 @@ def rms_norm_general_fuse_sum(out, input, weight, input_sum, scaling, epsilon, u
                              "(the reference asserts here too, layernorm_kernels.cu:499-501)")
     _lib.require_cuda(out, input, weight, input_sum, scaling)
     tokens, hidden = _shape(input)
+    dt = _lib.elem_dtype(input, "generalLayerNorm_fuse_sum")
+    if weight.dtype != input.dtype:
+        raise RuntimeError("rms_norm_general_fuse_sum: weight and input must have the same dtype")
+    if dt != 0:
+        rc = _lib.lib().omni_rms_norm_general_dt(out.data_ptr(), input.data_ptr(), weight.data_ptr(), input_sum.data_ptr(),
+                                                 scaling.data_ptr(), float(epsilon), tokens, hidden, dt, _lib.current_stream())
+        return _lib.check(rc, "layernorm_ops.rms_norm_general_fuse_sum")
     rc = _lib.lib().omni_rms_norm_general_fuse_sum(out.data_ptr(), input.data_ptr(), weight.data_ptr(),
                                                    input_sum.data_ptr(), scaling.data_ptr(),
                                                    float(epsilon), tokens, hidden, _lib.current_stream())

@@ -25,6 +25,44 @@ F32 = np.float32
 F16 = np.float16
 
 
+# Element types the reference dispatches its row kernels over (kernels/csrc/dispatch_utils.h:7-14).  bf16 arrays travel as
+# uint16 bit patterns (numpy has no bfloat16); `_load` widens a T array to float32 (exact), `_rt` rounds a float32 array to T
+# (round to nearest even) and returns it widened again, `_store` gives the T array a kernel would have written.
+def _round_bf16_bits(f: np.ndarray) -> np.ndarray:
+    u = np.ascontiguousarray(f, dtype=F32).view(np.uint32).astype(np.uint64)
+    nan = (u & 0x7FFFFFFF) > 0x7F800000
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    return np.where(nan, ((u >> 16) | 0x40).astype(np.uint16), r)
+
+
+def _load(x, dtype: str) -> np.ndarray:
+    if dtype == "f16":
+        return np.asarray(x, dtype=F16).astype(F32)
+    if dtype == "bf16":
+        return (np.asarray(x, dtype=np.uint16).astype(np.uint32) << 16).view(F32)
+    if dtype == "f32":
+        return np.asarray(x, dtype=F32)
+    raise ValueError(dtype)
+
+
+def _rt(f: np.ndarray, dtype: str) -> np.ndarray:
+    f = np.asarray(f, dtype=F32)
+    if dtype == "f16":
+        return f.astype(F16).astype(F32)
+    if dtype == "bf16":
+        return (_round_bf16_bits(f).astype(np.uint32) << 16).view(F32)
+    return f
+
+
+def _store(f: np.ndarray, dtype: str) -> np.ndarray:
+    f = np.asarray(f, dtype=F32)
+    if dtype == "f16":
+        return f.astype(F16)
+    if dtype == "bf16":
+        return _round_bf16_bits(f)
+    return f
+
+
 def rni_sat_s8(x: np.ndarray) -> np.ndarray:
     """cvt.rni.sat.s8.f32: round-half-even, saturate, NaN -> 0 (utils.cuh:79-84)."""
     x = np.asarray(x, dtype=F32)
@@ -70,15 +108,16 @@ def _thread_partials(x: np.ndarray, nthreads: int, fn, init):
     return acc
 
 
-def quant_per_token(x_h: np.ndarray, fuse_sum: bool):
+def quant_per_token(x_h: np.ndarray, fuse_sum: bool, dtype: str = "f16"):
     """invoke_quant / invoke_quant_fuse_sum, tensor-scale overloads.
 
     x fp16 [tokens, hidden] -> (q int8, scale fp16[tokens], sum fp16[tokens] | None).
     block = min(hidden,1024); amax starts at 0 (no floor: an all-zero row
     divides by zero exactly as the reference does); scale = h(amax/127);
     q = rni_sat(x * (127/amax)); sum = h(tree_sum(per-thread f32 sums)).
+    `dtype` = element type of x ("f16" | "bf16" as uint16 bits | "f32"): it only enters through the load; scale / sum are fp16.
     """
-    x = np.asarray(x_h, dtype=F16).astype(F32)
+    x = _load(x_h, dtype)
     tokens, hidden = x.shape
     nt = min(hidden, 1024)
     amax = np.abs(x).max(axis=1).astype(F32)
@@ -96,7 +135,7 @@ def quant_per_token(x_h: np.ndarray, fuse_sum: bool):
     return q, scale, s
 
 
-def rms_norm_general(x_h, gamma_h, eps: float, fuse_sum: bool):
+def rms_norm_general(x_h, gamma_h, eps: float, fuse_sum: bool, dtype: str = "f16"):
     """generalLayerNorm[_fuse_sum]<half, at::Half>, per-token path, use_shmem=false.
 
     y = (x - mean) * rsqrt(mean(x^2) + eps) * gamma in f32  [mean IS subtracted
@@ -105,9 +144,11 @@ def rms_norm_general(x_h, gamma_h, eps: float, fuse_sum: bool):
     accumulates yh in fp16 (`T_scalar sum`, :280,291) then the f32 block tree;
     q = rni_sat( y_f32 * (127/amax) ) recomputed from f32 (:308-318);
     scale = h(amax/127).   block = roundup32(min(hidden,1024)).
+    For T = bf16 / float (`dtype`) the roundings marked h() above that belong to T -- y, the running maximum, the per-thread
+    running sum (`T_scalar amax`, `T_scalar sum`) -- are roundings to T; scale and sum outputs stay fp16 (at::Half).
     """
-    x = np.asarray(x_h, dtype=F16).astype(F32)
-    g = np.asarray(gamma_h, dtype=F16).astype(F32)
+    x = _load(x_h, dtype)
+    g = _load(gamma_h, dtype)
     tokens, hidden = x.shape
     nt = ((min(hidden, 1024) + 31) // 32) * 32
     eps = F32(eps)
@@ -123,30 +164,29 @@ def rms_norm_general(x_h, gamma_h, eps: float, fuse_sum: bool):
 
     y = ((x - mean[:, None]).astype(F32) * rstd[:, None]).astype(F32)
     y = (y * g[None, :]).astype(F32)
-    yh = y.astype(F16)
-    amax_h = np.maximum(np.abs(yh).max(axis=1), F16(1e-6)).astype(F16)
-    amax = amax_h.astype(F32)
+    yh = _rt(y, dtype)                       # float32 holding T values
+    amax = np.maximum(np.abs(yh).max(axis=1), _rt(np.asarray([1e-6], F32), dtype)[0]).astype(F32)
     scale = (amax / F32(127.0)).astype(F32).astype(F16)
     dyn = (F32(127.0) / amax).astype(F32)
     q = rni_sat_s8((y * dyn[:, None]).astype(F32))
     s = None
     if fuse_sum:
-        # fp16 per-thread accumulation: sum = h(f32(sum) + f32(yh))
-        part = np.zeros((tokens, nt), F16)
+        # per-thread accumulation in T: sum = T(f32(sum) + f32(yh))
+        part = np.zeros((tokens, nt), F32)
         for start in range(0, hidden, nt):
             c = yh[:, start:start + nt]
             n = c.shape[1]
-            part[:, :n] = (part[:, :n].astype(F32) + c.astype(F32)).astype(F32).astype(F16)
-        s = ref_tree_sum(part.astype(F32)).astype(F16)
+            part[:, :n] = _rt((part[:, :n] + c).astype(F32), dtype)
+        s = ref_tree_sum(part).astype(F16)
     return q, scale, s
 
 
-def rms_norm(x_h, weight_h, eps: float):
+def rms_norm(x_h, weight_h, eps: float, dtype: str = "f16"):
     """rms_norm_kernel<half, half, false> (layernorm_kernels.cu:335-365):
     out = h( f32( h(x * rstd) ) * f32(w) )  -- `((scalar_t)(x*s_variance)) * weight`
-    with c10::Half operator* (float multiply, rounded to half)."""
-    x = np.asarray(x_h, dtype=F16).astype(F32)
-    w = np.asarray(weight_h, dtype=F16).astype(F32)
+    with c10::Half operator* (float multiply, rounded to half).  `dtype`: the same with T = bf16 (uint16 bits) / float."""
+    x = _load(x_h, dtype)
+    w = _load(weight_h, dtype)
     tokens, hidden = x.shape
     nt = min(hidden, 1024)
     ntp = ((nt + 31) // 32) * 32
@@ -155,20 +195,20 @@ def rms_norm(x_h, weight_h, eps: float):
         pvar = np.concatenate([pvar, np.zeros((tokens, ntp - nt), F32)], axis=1)
     var = ref_tree_sum(pvar)
     rstd = (F32(1.0) / np.sqrt(((var / F32(hidden)).astype(F32) + F32(eps)).astype(F32))).astype(F32)
-    t = (x * rstd[:, None]).astype(F32).astype(F16).astype(F32)
-    return (t * w[None, :]).astype(F32).astype(F16)
+    t = _rt((x * rstd[:, None]).astype(F32), dtype)
+    return _store((t * w[None, :]).astype(F32), dtype)
 
 
-def silu_and_mul(x_h):
+def silu_and_mul(x_h, dtype: str = "f16"):
     """silu_and_mul_kernel (activation_kernels.cu:10-30):
     out = h( f32( h( x / (1 + exp(-x)) ) ) * f32(y) ), input [..., 2d]."""
-    x = np.asarray(x_h, dtype=F16)
+    x = _load(x_h, dtype)
     d = x.shape[-1] // 2
-    a = x[..., :d].astype(F32)
-    b = x[..., d:].astype(F32)
+    a = x[..., :d]
+    b = x[..., d:]
     e = np.exp((-a).astype(F32)).astype(F32)
-    s = (a / (F32(1.0) + e).astype(F32)).astype(F32).astype(F16).astype(F32)
-    return (s * b).astype(F32).astype(F16)
+    s = _rt((a / (F32(1.0) + e).astype(F32)).astype(F32), dtype)
+    return _store((s * b).astype(F32), dtype)
 
 
 # ------------------------------------------------------------------------------------------------------------

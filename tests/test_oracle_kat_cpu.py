@@ -235,3 +235,31 @@ def test_dequant_silu_quant_known_answers():            # activation_kernels.cu:
     assert np.allclose(tmp[0], want, rtol=1e-6) and np.isclose(scale[0], np.abs(want).max() / 127, rtol=1e-6)
     assert q[0].tolist() == [0, int(np.rint(want[1] / scale[0])), int(np.rint(want[2] / scale[0])), -127]
     assert oe.dequant_silu_and_mul_quant(acc, 1e-4, 1e-4, 0.01)[0].tolist() == [0, 127, -24, -128]
+
+
+def test_bf16_oracle_paths_match_torch_bfloat16():
+    """The oracle's bf16 element type (uint16 bit patterns): its rounding is torch's float32 -> bfloat16 conversion, and
+    rms_norm / silu_and_mul with dtype="bf16" equal the same formulas evaluated with torch.bfloat16 roundings."""
+    import torch
+    from oracle import elementwise as oe
+    rng = np.random.default_rng(11)
+    f = np.concatenate([(rng.standard_normal(4096) * 10.0 ** rng.integers(-6, 6, 4096)).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, 1.00390625, 1.01171875, 3.3895314e38, np.inf, -np.inf], np.float32)])
+    want = torch.from_numpy(f).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(oe._round_bf16_bits(f), want)
+    x = oe._round_bf16_bits((rng.standard_normal((3, 512)) * 2).astype(np.float32))
+    w = oe._round_bf16_bits(rng.standard_normal(512).astype(np.float32))
+    xt = torch.from_numpy(x.view(np.int16)).view(torch.bfloat16)
+    wt = torch.from_numpy(w.view(np.int16)).view(torch.bfloat16)
+    # rms_norm: T(f32(T(x * rstd)) * f32(w)); rstd from the oracle's own reduction tree (pinned elsewhere)
+    xf = xt.float().numpy()
+    part = oe._thread_partials((xf * xf).astype(np.float32), 512, lambda a, c: (a + c).astype(np.float32), 0.0)
+    rstd = (np.float32(1.0) / np.sqrt((oe.ref_tree_sum(part) / np.float32(512)).astype(np.float32) + np.float32(1e-5))).astype(np.float32)
+    t = torch.from_numpy((xf * rstd[:, None]).astype(np.float32)).to(torch.bfloat16)
+    ref = (t.float() * wt.float()).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(oe.rms_norm(x, w, 1e-5, dtype="bf16"), ref)
+    # general norm: int8 codes must agree with an independent evaluation that rounds y to bfloat16 through torch
+    q, scale, ssum = oe.rms_norm_general(x, w, 1e-5, True, dtype="bf16")
+    assert q.dtype == np.int8 and scale.dtype == np.float16 and ssum.dtype == np.float16
+    qf, scf, _ = oe.rms_norm_general(oe._load(x, "bf16"), oe._load(w, "bf16"), 1e-5, False, dtype="f32")
+    assert np.abs(q.astype(np.int32) - qf.astype(np.int32)).max() <= 1      # bf16 amax vs f32 amax: at most one code apart
