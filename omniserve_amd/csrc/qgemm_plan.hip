@@ -65,7 +65,8 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
     auto part = [&](int s) { return K / (s * kw); };
     auto fits = [&](int s) { return ok(s) && ((K / s) % (kw * kalign)) == 0; };
     // W8A8 rows are twice the bytes per k: the deferred (slab-only) plan halves the k per wave (same bytes per wave)
-    const int part_target = (deferred && w8) ? 256 : 512;
+    static const int part_w4_deferred = [] { const char* e = getenv("OMNI_DEFERRED_PART"); return e ? atoi(e) : 512; }();   // (A/B knob)
+    const int part_target = (deferred && w8) ? 256 : (deferred ? part_w4_deferred : 512);
     // W8A8 rows are twice the bytes per k: with few channel groups (qkv at batch 1: 96 workgroups streaming 256 KiB each)
     // a split to 512 k per wave + the slab epilogue launch beats the single kernel (OMNI_W8_SMALL_SPLIT=0: off, A/B)
     static const int w8_small_split = [] { const char* e = getenv("OMNI_W8_SMALL_SPLIT"); return e ? atoi(e) : 1; }();

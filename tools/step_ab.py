@@ -15,7 +15,7 @@ from omniserve_amd.runtime import DecodeRunner, LlamaConfig  # noqa: E402
 
 dev = torch.device("cuda:0")
 for gs, bs in ((-1, 16), (128, 64)):
-    r = DecodeRunner(LlamaConfig.llama3_8b(gs), bs, 1024, 200, dev, seed=0, fused=2)
+    r = DecodeRunner(LlamaConfig.llama3_8b(gs), bs, 1024, 200, dev, seed=0, fused=int(os.environ.get('OMNI_FUSED', '3' if bs <= 16 else '2')))
     for _ in range(8):
         r.step()
     torch.cuda.synchronize()
