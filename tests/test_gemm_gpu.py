@@ -123,6 +123,29 @@ def test_w8a8_4096_cubed():
     _run_w8(4096, 4096, 4096)
 
 
+# Exact-shape prefill kernel (csrc/qgemm_exact.h: M % 128 == N % 256 == K % 256 == 0; activations by LDS-DMA into the swizzled
+# row image, lane transpose of the packed int4 registers, last chunk without prefetch, packed 16-B stores) against the oracle:
+# one tile x one chunk (no steady loop: prologue -> last chunk), two chunks (one steady iteration), several tiles in both
+# directions incl. a partly filled 8 x 8 super-block, a long K, and the per-group wrap set (byte products above 255).
+EXACT_SHAPES = [(128, 256, 256), (256, 512, 512), (384, 256, 1024), (128, 768, 2048), (1152, 2304, 256), (640, 512, 4096)]
+
+
+@pytest.mark.parametrize("M,N,K", EXACT_SHAPES)
+def test_per_chn_exact_shapes(M, N, K):
+    _run_chn(M, N, K, seed=M + N + K)
+
+
+@pytest.mark.parametrize("wrap", [False, True])
+@pytest.mark.parametrize("M,N,K", EXACT_SHAPES)
+def test_per_group_exact_shapes(M, N, K, wrap):
+    _run_grp(M, N, K, wrap)
+
+
+@pytest.mark.parametrize("M,N,K", EXACT_SHAPES)
+def test_w8a8_exact_shapes(M, N, K):
+    _run_w8(M, N, K)
+
+
 # Llama-2-70B TP=8 shard shapes (BASELINE.json configs[4], bs up to 128): qkv (64+16)/8 heads x 128 = 1280 x 8192,
 # o 8192 x 1024, gate_up 2 x 28672/8 = 7168 x 8192, down 8192 x 3584 -- the M = 65..128 decode tile with split-K slabs.
 LLAMA2_70B_TP8 = [(1280, 8192), (8192, 1024), (7168, 8192), (8192, 3584)]
