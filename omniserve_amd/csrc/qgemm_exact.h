@@ -62,22 +62,6 @@ __device__ __forceinline__ void lds_dma16_x8(const void* sbase0, const void* sba
       : "memory", "scc");
 }
 
-// epilogue<MODE> with the f32 product materialised before the fp16 conversion: in this kernel's write-back hipcc otherwise
-// folds `(half)(f32(acc) * s)` into v_fma_mixlo_f16 -- ONE rounding to fp16 where the reference rounds to f32 first --
-// and a handful of elements per million differ by one fp16 ulp (caught by the cross-build checksum of tools/gemm_ab.py).
-template <int MODE>
-__device__ __forceinline__ half_t epilogue_exact(int acc, float sw, float sa, float sz, float asum) {
-  if constexpr (MODE == MODE_CHN) {
-    float t = (float)acc * sw;
-    t = t * sa;
-    const float c = sz * asum;
-    return (half_t)rounded_f32(t - c);
-  } else {
-    const float s = sw * sa;
-    return (half_t)rounded_f32((float)acc * s);
-  }
-}
-
 template <int MODE, bool ADMA>
 __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
   constexpr int MB = 8, MT = 128, WAVES = 4, NTHREADS = 256, A_LOADS = 8;
@@ -395,8 +379,10 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
   const int i0 = (lane >> 4) * 4;
   // The lane's 16 channels are the same for every row block: their scales are converted once (32 registers the K loop
   // no longer needs); the arithmetic runs on float pairs (v_pk_mul_f32 / v_pk_add_f32: the reference's three products and one
-  // difference, each rounded to f32 -- -ffp-contract=off) and the pair is made opaque before the fp16 conversion (see
-  // epilogue_exact: no v_fma_mixlo_f16 folding).  ~3.5 VALU per output instead of ~10.
+  // difference, each rounded to f32 -- -ffp-contract=off) and the pair is made opaque before the fp16 conversion: hipcc
+  // otherwise folds `(half)(f32 * f32)` into v_fma_mixlo_f16 -- ONE rounding to fp16 where the reference rounds to f32 first --
+  // and a handful of outputs per million differ by one fp16 ulp (caught by the cross-build checksum of tools/gemm_ab.py).
+  // ~3.5 VALU per output instead of ~10.
   typedef float v2f __attribute__((ext_vector_type(2)));
   typedef _Float16 v2h __attribute__((ext_vector_type(2)));
   v2f swf[4][2], szf[4][2];
