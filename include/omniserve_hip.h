@@ -255,6 +255,13 @@ int omni_w4a8_per_group_gemm_partial_f16(const void* act_f16, const void* amax_s
                                          void* sum_f16, void* scale_f16, int M, int N, int K, int* sk_out, void* stream);
 int omni_attn_merge_f16_amax(void* out_f16, const void* part_ml_f32, const void* part_o_f32, int nsplit,
                              void* amax_slots_u32, int batch, int num_heads, void* stream);
+/* The W8A8 forms (LServe models: w8a8_gemm_forward_cuda -> silu_and_mul -> invoke_quant -> w8a8_gemm_forward_cuda,
+ * llama_w8a8_unpad.py:94-111; attention -> invoke_quant -> o_proj, :329-335): no zero-point term, so no row sums --
+ * the riders of omni_w8a8_gemm_partial_f16 write scale_f16 only (any K).  Bit-identical to the reference sequence. */
+int omni_w8a8_gemm_silu(const void* in_feats, const void* weight, const void* wscales, const void* ascales,
+                        void* act_f16, void* amax_slots_u32, int M, int N, int K, void* stream);
+int omni_w8a8_gemm_partial_f16(const void* act_f16, const void* amax_slots_u32, const void* weight, void* slab_i32,
+                               size_t slab_bytes, void* scale_f16, int M, int N, int K, int* sk_out, void* stream);
 
 /* The same split for the LServe decode attention (retrieval / streaming heads, optional page list; KV4 pages when both
  * scale pointers are NULL, per-tensor KV8 pages otherwise): partials only, finished by omni_attn_merge_quant_fuse_sum. */

@@ -166,10 +166,12 @@ def decode_attention_fine_grained(q, k, v, retrieval_kv_pointers, streaming_kv_p
                                   sink_block_num, local_block_num, num_retrieval_kv_heads, num_streaming_kv_heads,
                                   timestep, rotary_embedding_dim, rotary_base, rope_scale, neox, int4, zeros,
                                   tokens_per_sub_chunk, what, kv_scale_quant_orig=None, kv_scale_orig_quant=None,
-                                  per_tensor=False, merge_quant=None):
+                                  per_tensor=False, merge_quant=None, merge_f16=None):
     """per_tensor=True: the KV8 family (both scale tensors fp32 [2] on the device).
     merge_quant = (out_i8 [B, Hq*D], input_sum fp16 [B], scale fp16 [B]): fused extension -- the flash-decoding merge is
-    done by the per-token quantiser that follows upstream (invoke_quant[_fuse_sum]); returns None."""
+    done by the per-token quantiser that follows upstream (invoke_quant[_fuse_sum]); returns None.
+    merge_f16 = (out_f16 [B, Hq*D], amax slots): fused extension -- the merge as the wide kernel that also raises the row
+    maxima of |out| (omni_attn_merge_f16_amax); returns None."""
     _lib.require_cuda(q, k, v, lengths, retrieval_head_flags, head_rank_table)
     B, Hq, D = q.shape
     Hkv = k.shape[1]
@@ -208,10 +210,16 @@ def decode_attention_fine_grained(q, k, v, retrieval_kv_pointers, streaming_kv_p
     need = _lib.lib().omni_kv4_decode_workspace_bytes(
         B, Hq, D, max(max_ctx, ndyn * int(tokens_per_block), int(sink_token_num) + int(local_token_num)))
     ws = _lib.workspace(need, q.device, "attn")
-    if merge_quant is not None:
+    if merge_quant is not None or merge_f16 is not None:
         import ctypes
-        out_i8, input_sum, scale = merge_quant
-        _lib.require_cuda(out_i8, input_sum, scale)
+        if merge_quant is not None:
+            out_i8, input_sum, scale = merge_quant
+            _lib.require_cuda(out_i8, input_sum, scale)
+        else:
+            out_f16, amax = merge_f16
+            _lib.require_cuda(out_f16, amax)
+            if out_f16.dtype != torch.float16 or out_f16.numel() != B * Hq * D or not out_f16.is_contiguous():
+                raise RuntimeError("%s: out_f16 must be a contiguous fp16 [B, Hq*D] tensor" % what)
         ns = ctypes.c_int(0)
         rc = _lib.lib().omni_kv_decode_attention_fine_grained_partial(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0),
@@ -222,6 +230,11 @@ def decode_attention_fine_grained(q, k, v, retrieval_kv_pointers, streaming_kv_p
             max_ctx, table.data_ptr(), table.shape[0], ws.data_ptr(), ws.numel(), ctypes.byref(ns), _lib.current_stream())
         _lib.check(rc, what + " (partials)")
         ml_bytes = B * Hq * ns.value * 2 * 4
+        if merge_f16 is not None:
+            rc = _lib.lib().omni_attn_merge_f16_amax(out_f16.data_ptr(), ws.data_ptr(), ws.data_ptr() + ml_bytes, ns.value,
+                                                     amax.data_ptr(), B, Hq, _lib.current_stream())
+            _lib.check(rc, what + " (merge)")
+            return None
         rc = _lib.lib().omni_attn_merge_quant_fuse_sum(out_i8.data_ptr(), ws.data_ptr(), ws.data_ptr() + ml_bytes, ns.value,
                                                        None if input_sum is None else input_sum.data_ptr(),
                                                        scale.data_ptr(), B, Hq, _lib.current_stream())

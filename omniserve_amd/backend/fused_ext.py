@@ -214,6 +214,36 @@ def gemm_partial_f16_per_group(act, amax, qweight, s2_zeros, s2_scales, slab, su
     return sk.value
 
 
+def gemm_silu_w8a8(in_feats, weight, wscales, ascales, act, amax):
+    """The W8A8 form of gemm_silu_per_chn (LServe models: gate_up_proj -> silu*mul, llama_w8a8_unpad.py:94-105): act fp16
+    [M, N/2] bit for bit what w8a8_gemm_forward_cuda -> silu_and_mul leave, row maxima of |act| raised in `amax`.  M <= 16."""
+    _lib.require_cuda(in_feats, weight, wscales, ascales, act, amax)
+    M, K = in_feats.shape
+    N = weight.shape[0]
+    if act.dtype != torch.float16 or tuple(act.shape) != (M, N // 2) or not act.is_contiguous():
+        raise RuntimeError("gemm_silu_w8a8: act must be a contiguous fp16 [M, N/2] tensor")
+    rc = _lib.lib().omni_w8a8_gemm_silu(in_feats.data_ptr(), weight.data_ptr(), wscales.data_ptr(), ascales.data_ptr(),
+                                        act.data_ptr(), amax.data_ptr(), M, N, K, _lib.current_stream())
+    _lib.check(rc, "fused_ext.gemm_silu_w8a8")
+
+
+def gemm_partial_f16_w8a8(act, amax, weight, slab, scale_out):
+    """The W8A8 form of gemm_partial_f16_per_chn: slabs of gemm_partial_w8a8 on the codes invoke_quant(act) would produce,
+    scale_out = invoke_quant's scales (no row sums: W8A8 has no zero-point term).  M <= 16, any K."""
+    import ctypes
+    _lib.require_cuda(act, amax, weight, slab, scale_out)
+    M, K = act.shape
+    N = weight.shape[0]
+    if act.dtype != torch.float16 or not act.is_contiguous():
+        raise RuntimeError("gemm_partial_f16_w8a8: act must be a contiguous fp16 [M, K] tensor")
+    sk = ctypes.c_int(0)
+    rc = _lib.lib().omni_w8a8_gemm_partial_f16(act.data_ptr(), amax.data_ptr(), weight.data_ptr(), slab.data_ptr(),
+                                               slab.numel() * slab.element_size(), scale_out.data_ptr(), M, N, K,
+                                               ctypes.byref(sk), _lib.current_stream())
+    _lib.check(rc, "fused_ext.gemm_partial_f16_w8a8")
+    return sk.value
+
+
 def decode_attention_f16_amax(out_f16, amax, q, k, v, kv_pointers, lengths, tokens_per_block, timestep, rotary_base):
     """single_query_attention (KV4 + zeros, neox RoPE): the split partials, then the merge as a wide kernel writing the
     fp16 [B, Hq*Dh] output (the values single_query_attention returns) into out_f16 and raising the row maxima of |out|
@@ -282,6 +312,27 @@ def sparse_decode_attention_quant(out_i8, input_sum, scale, q, k, v, retrieval_k
         int(timestep), D, rotary_base, 1.0 / float(rotary_embedding_scale), True, not per_tensor, not per_tensor,
         tokens_per_sub_chunk, "fused_ext.sparse_decode_attention_quant", kv_scale_quant_orig=kv_scale_quant_orig,
         kv_scale_orig_quant=kv_scale_orig_quant, per_tensor=per_tensor, merge_quant=(out_i8, input_sum, scale))
+
+
+def sparse_decode_attention_f16_amax(out_f16, amax, q, k, v, retrieval_kv_pointers, streaming_kv_pointers,
+                                     retrieval_head_flags, head_rank_table, dynamic_sparse_page_idxes, lengths,
+                                     tokens_per_block, size_per_retrieval_token, size_per_streaming_token, sink_token_num,
+                                     local_token_num, sink_block_num, local_block_num, num_retrieval_kv_heads,
+                                     num_streaming_kv_heads, timestep, rotary_base, rotary_embedding_scale,
+                                     tokens_per_sub_chunk, kv_scale_quant_orig=None, kv_scale_orig_quant=None):
+    """LServe decode attention (as sparse_decode_attention_quant) with the merge as the wide kernel of
+    decode_attention_f16_amax: out_f16 [B, Hq*Dh] = the values single_query_attention returns, row maxima of |out| raised
+    in `amax` -- the input pair of gemm_partial_f16_w8a8 (o_proj quantises on the fly: no quantiser row kernel)."""
+    from ._attn_common import decode_attention_fine_grained
+    per_tensor = kv_scale_quant_orig is not None
+    D = q.shape[-1]
+    decode_attention_fine_grained(
+        q, k, v, retrieval_kv_pointers, streaming_kv_pointers, retrieval_head_flags, head_rank_table,
+        dynamic_sparse_page_idxes, lengths, tokens_per_block, size_per_retrieval_token, size_per_streaming_token,
+        sink_token_num, local_token_num, sink_block_num, local_block_num, num_retrieval_kv_heads, num_streaming_kv_heads,
+        int(timestep), D, rotary_base, 1.0 / float(rotary_embedding_scale), True, not per_tensor, not per_tensor,
+        tokens_per_sub_chunk, "fused_ext.sparse_decode_attention_f16_amax", kv_scale_quant_orig=kv_scale_quant_orig,
+        kv_scale_orig_quant=kv_scale_orig_quant, per_tensor=per_tensor, merge_f16=(out_f16, amax))
 
 
 def embed_rows(out, table, idx):

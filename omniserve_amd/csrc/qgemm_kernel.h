@@ -605,6 +605,10 @@ __device__ __forceinline__ void a16_rider(const GemmArgs& p, float* xs, float* r
   const int t = threadIdx.x;
   const half_t* x = p.A16 + (size_t)row * p.K;
   const float rowmax = amax_rows_wave(p.amax);      // (every wave reads all 16 rows; lane `row` of each holds this row's)
+  if (!p.sum_out) {       // nobody reads a row sum downstream (per-group, W8A8: no zero-point term): the scale alone
+    if (t == row) p.scale_out[row] = (half_t)(rowmax / 127.0f);
+    return;
+  }
   for (int i = t * VT; i < hidden; i += NTHR * VT) {
     const v8h v = *reinterpret_cast<const v8h*>(x + i);
     *reinterpret_cast<v4f*>(xs + i) = (v4f){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
@@ -685,7 +689,7 @@ struct GemvCfg {
 template <int MB, int MODE, bool TO_SLAB, int KW = 1, bool NT = true, int MZ = 1, int EPI = 0, bool A16 = false, int VAR = 0>
 __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((MB == 4 && KW == 4 && MZ == 1) || A16 || VAR == 1) ? 2 : 1)) void w4a8_gemv_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
-  static_assert(EPI == 0 || (MODE != MODE_W8 && !TO_SLAB && MZ == 1), "SiLU epilogue: int4 tile layout, in-kernel epilogue");
+  static_assert(EPI == 0 || (!TO_SLAB && MZ == 1), "SiLU epilogue: in-kernel epilogue, one row tile");
   static_assert(!A16 || (TO_SLAB && MZ == 1 && MB == 1 && GemvCfg<MB, MODE, VAR>::WAVES == 1), "fp16-input form: slab output, one 16-row single-wave tile");
   static_assert(EPI == 0 || MB == 1, "row-maximum hand-off covers 16 rows");
   constexpr int WAVES = GemvCfg<MB, MODE, VAR>::WAVES;
@@ -736,11 +740,16 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
   // tile row (32 channels) this lane streams: two consecutive rows of the 64-channel group, or (EPI = 1) row ngc of the
   // gate half and row ngc of the up half
   const int trow = EPI == 1 ? (lx ? p.N / 64 + ngc : ngc) : 2 * ngc + lx;
-  if constexpr (MODE == MODE_W8) wbase = p.W + (size_t)(ngc * 64 + (lane & 15)) * p.K + (lane >> 4) * 16;
+  // (W8A8, EPI = 1: 16-row block j of the wave = gate channels ngc * 32 + 8 j + (0..7) in operand rows 0..7 and the
+  //  matching up channels in rows 8..15, so that -- as in the int4 layout -- lanes < 32 finish gate outputs and lanes
+  //  >= 32 the up outputs of the same (row, 4 channels))
+  if constexpr (MODE == MODE_W8 && EPI == 1)
+    wbase = p.W + (size_t)(((lane & 8) ? p.N / 2 : 0) + ngc * 32 + (lane & 7)) * p.K + (lane >> 4) * 16;
+  else if constexpr (MODE == MODE_W8) wbase = p.W + (size_t)(ngc * 64 + (lane & 15)) * p.K + (lane >> 4) * 16;
   else wbase = p.W + ((size_t)trow * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
   auto load_w = [&](int k, int j) -> uint4 {
     const uint8_t* ptr;
-    if constexpr (MODE == MODE_W8) ptr = wbase + (size_t)j * 16 * p.K + k;
+    if constexpr (MODE == MODE_W8) ptr = wbase + (size_t)j * (EPI == 1 ? 8 : 16) * p.K + k;
     else ptr = wbase + (size_t)(k / 32 + j) * 512;
     v4i v;
     if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(ptr));
@@ -847,8 +856,8 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
   const int mcol = lane & 15;
   const int i0 = (lane >> 4) * 4;
   auto chan = [&](int ab) -> int {
-    if constexpr (MODE == MODE_W8) return ng * 64 + ab * 16 + i0;
-    else if constexpr (EPI == 1) return (i0 >> 3) * (p.N / 2) + ng * 32 + ab * 8 + (i0 & 7);   // gate | up channel
+    if constexpr (EPI == 1) return (i0 >> 3) * (p.N / 2) + ng * 32 + ab * 8 + (i0 & 7);   // gate | up channel
+    else if constexpr (MODE == MODE_W8) return ng * 64 + ab * 16 + i0;
     else return ng * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
   };
   uint2 swv[ABW], szv[ABW];
@@ -1312,7 +1321,7 @@ template <int MODE>
 static int launch_gemm_silu(GemmArgs a, hipStream_t st) {
   if (a.M < 1 || a.M > 16 || a.N % 128 != 0 || a.K % 64 != 0 || a.K < 64 || !a.amax || !a.out) return OMNI_EINVAL;
   if (MODE == MODE_GRP && a.K % 128 != 0) return OMNI_EINVAL;
-  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64, false, false);
+  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64, false, MODE == MODE_W8);
   if (pl.sk != 1 || pl.mb != 1) return OMNI_EINVAL;
   a.kslice = pl.kslice;
   a.dbg = gemv_dbg_flags();
@@ -1340,9 +1349,9 @@ static int launch_gemm_partial_f16(GemmArgs a, void* slab, size_t slab_bytes, in
     return OMNI_EINVAL;
   if (MODE == MODE_GRP && a.K % 128 != 0) return OMNI_EINVAL;
   if (a.N / 64 < a.M) return OMNI_EINVAL;                                   // one rider per row in a grid row of N/64
-  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64, true, false);
+  GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64, true, MODE == MODE_W8);
   if (pl.mb != 1 || pl.kw < 2) return OMNI_EINVAL;
-  if ((size_t)a.K * sizeof(float) > (size_t)pl.kw * 2 * 16 * GemvCfg<1, MODE>::AR * KSTEP) return OMNI_EINVAL;   // rider LDS
+  if (a.sum_out && (size_t)a.K * sizeof(float) > (size_t)pl.kw * 2 * 16 * GemvCfg<1, MODE>::AR * KSTEP) return OMNI_EINVAL;   // rider LDS (ordered row sum only)
   if (slab_bytes < (size_t)pl.sk * a.M * a.N * sizeof(int32_t)) return OMNI_ENOMEM;
   a.slab = static_cast<int32_t*>(slab);
   a.kslice = pl.kslice;

@@ -62,10 +62,14 @@ class LServeDecodeRunner:
                  streaming_ratio=0.5, sink=128, local=256, budget_tokens=4096, selector_interval=4,
                  sub_chunk_per_block=4, use_graph=True, fused=True, prefetch_mb=None, ctx_sink=128, ctx_local=8192):
         """fused: use the opt-in fused entry points (residual add + norm + quant, silu*mul + quant) -- bit-identical to the
-        reference call sequence, three launches fewer per layer."""
+        reference call sequence, three launches fewer per layer.  fused=True (or 3) also takes the
+        row-kernel-free forms where they apply (batch <= 16: the attention merge leaves fp16 + row maxima, gate_up runs
+        with the SiLU*mul epilogue, o_proj / down_proj quantise on the fly -- runtime.py's fusion level 3 for the W8A8
+        layers); fused=2 keeps the quantiser row kernels."""
         c = cfg
         self.cfg, self.B, self.device = cfg, batch, device
         self.fused = bool(fused)
+        level = 3 if fused is True else int(fused)
         # L2 weight prefetch riding on the row kernels (see omniserve_amd/runtime.py; a hint, results unaffected)
         import os
         if prefetch_mb is None:
@@ -165,6 +169,12 @@ class LServeDecodeRunner:
         # fused: o_proj / down_proj leave int32 split-K slabs; the next add+norm kernel applies the GEMM epilogue
         self.defer = self.fused and os.environ.get("OMNI_LSERVE_DEFER", "1") != "0"
         self.slab = torch.empty((16 << 20,), dtype=torch.uint8, device=device) if self.defer else None
+        # row-kernel-free decode layer (fused level 3): needs the deferred epilogue (slab consumers) and <= 16 rows
+        self.rowfree = (self.defer and level >= 3 and B <= 16 and Hq % 4 == 0 and
+                        os.environ.get("OMNI_LSERVE_ROWFREE", "1") != "0")
+        if self.rowfree:
+            self.attn_f16 = torch.empty((B, Hq * d), dtype=f16, device=device)
+            self.amax = torch.zeros((c.layers, 2, fused_ext.AMAX_WORDS), dtype=torch.int32, device=device)
         self.qkv_buf = torch.empty((B, qkv_n), dtype=f16, device=device)
         self.proj_buf = torch.empty((B, c.hidden), dtype=f16, device=device)
         self.gate_up_buf = torch.empty((B, 2 * c.inter), dtype=f16, device=device)
@@ -204,6 +214,9 @@ class LServeDecodeRunner:
         size_r, size_s = self.nr * self.row, self.ns * self.row
         total_pages = hist // self.tpb + 1
         sm = None          # W8A8: nobody reads a row sum (rms_norm_general / invoke_quant upstream): the fused kernels skip it
+        rowfree = self.rowfree
+        if rowfree:
+            self.amax.zero_()
         for li, L in enumerate(self.layers):
             self._arm(L["qkv"])
             if pending is not None:       # residual += down_proj(previous layer) [deferred epilogue], norm + quant
@@ -238,7 +251,14 @@ class LServeDecodeRunner:
             common = (self.tpb, size_r, size_s, self.sink, self.local, self.sink_blocks, self.local_blocks, self.nr,
                       self.ns, hist + 1, d, c.rope_theta, 1.0, True, not self.kv8, not self.kv8, self.sub, self.nr * d,
                       2048)
-            if self.fused:      # merge of the KV splits fused into the per-token quantiser (one launch less)
+            if rowfree:         # merge as a wide kernel (fp16 + row maxima); o_proj quantises on the fly
+                self._arm(L["o"], True)
+                fused_ext.sparse_decode_attention_f16_amax(
+                    self.attn_f16, self.amax[li, 0], q, k, v, self.retr_tables[li], self.strm_tables[li], self.flags,
+                    self.rank, self.page_idx[li], self.lengths, self.tpb, size_r, size_s, self.sink, self.local,
+                    self.sink_blocks, self.local_blocks, self.nr, self.ns, hist + 1, c.rope_theta, 1.0, self.sub,
+                    self.kv_qo if self.kv8 else None, self.kv_oq if self.kv8 else None)
+            elif self.fused:    # merge of the KV splits fused into the per-token quantiser (one launch less)
                 self._arm(L["o"], self.defer)
                 fused_ext.sparse_decode_attention_quant(
                     self.q_attn, sm, sq, q, k, v, self.retr_tables[li], self.strm_tables[li], self.flags, self.rank,
@@ -255,11 +275,14 @@ class LServeDecodeRunner:
                                                   *common)
             if not self.fused:
                 fused_kernels.invoke_quant(self.q_attn, out.view(B, Hq * d), sq)
-            if self.defer:
+            if rowfree:
+                sk = fused_ext.gemm_partial_f16_w8a8(self.attn_f16, self.amax[li, 0], L["o"].weight, self.slab, sq)
+            elif self.defer:
                 sk = fused_ext.gemm_partial_w8a8(self.q_attn, L["o"].weight, self.slab)
             else:
                 L["o"].forward(self.q_attn, sq, self.proj_buf)
-            self._arm(L["gate_up"])
+            if not (rowfree and li < nl - 1):     # (the SiLU-epilogue form pairs gate / up rows: no prefetch descriptor)
+                self._arm(L["gate_up"])
             if self.defer:
                 fused_ext.splitk_w8_add_rms_norm_general_fuse_sum(self.q_hidden, self.x, self.slab, sk,
                                                                   L["o"].dequant_scale, sq, L["ln2"], sm, sc, c.eps)
@@ -268,6 +291,12 @@ class LServeDecodeRunner:
             else:
                 self.x.add_(self.proj_buf)
                 layernorm_ops.rms_norm_general(self.q_hidden, self.x, L["ln2"], sc, c.eps, True)
+            if rowfree and li < nl - 1:     # gate_up with the SiLU*mul epilogue; down_proj quantises on the fly
+                G = L["gate_up"]
+                fused_ext.gemm_silu_w8a8(self.q_hidden, G.weight, G.dequant_scale, sc, self.mlp_act, self.amax[li, 1])
+                pending = (fused_ext.gemm_partial_f16_w8a8(self.mlp_act, self.amax[li, 1], L["down"].weight, self.slab,
+                                                           sq), L["down"])
+                continue
             L["gate_up"].forward(self.q_hidden, sc, self.gate_up_buf)
             self._arm(L["down"], self.defer and li < nl - 1)
             if self.fused:

@@ -14,8 +14,10 @@ pytestmark = pytest.mark.gpu
 def test_lserve_decode_graph_matches_eager(kv_format):
     dev = torch.device("cuda:0")
     cfg = LlamaConfig.tiny()
-    toks = []
-    for use_graph, fused in ((False, False), (True, True)):     # reference call sequence eagerly vs fused entry points in a graph
+    toks, hidden, pools = [], [], []
+    # reference call sequence eagerly | fused entry points with the quantiser row kernels (level 2) in a graph | the
+    # row-kernel-free layer (level 3: wide merge + row maxima, SiLU epilogue, o / down quantising on the fly) in a graph
+    for use_graph, fused in ((False, False), (True, 2), (True, True)):
         r = LServeDecodeRunner(cfg, batch=2, context=700, max_new=16, device=dev, seed=11, kv_format=kv_format,
                                sink=64, local=128, budget_tokens=256, selector_interval=4, use_graph=use_graph,
                                fused=fused)
@@ -28,5 +30,12 @@ def test_lserve_decode_graph_matches_eager(kv_format):
         assert int(r.lengths[0]) == 709
         # the newest page is always the last selected entry
         assert int(r.page_idx[0][0, 0, -1]) == 708 // 64
+        assert r.rowfree == (fused is True)
         toks.append(torch.stack(seq).cpu())
-    assert torch.equal(toks[0], toks[1])
+        hidden.append(r.x.view(torch.int16).cpu())
+        pools.append([p.cpu() for layer in r.pools for p in layer])
+    for i in (1, 2):
+        assert torch.equal(toks[0], toks[i])
+        assert torch.equal(hidden[0], hidden[i]), "residual stream differs (bitwise) from the reference call sequence"
+        for a, b in zip(pools[0], pools[i]):
+            assert torch.equal(a, b), "KV pages differ from the reference call sequence"

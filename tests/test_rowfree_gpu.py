@@ -209,3 +209,82 @@ def test_decode_attention_f16_amax(hist, Hq, Hk):
     assert np.array_equal(_row_amax(amax, B), want.reshape(B, -1).float().abs().max(dim=1).values.cpu().numpy())
     for a, b in zip(g1.pools(), g2.pools()):
         assert np.array_equal(a, b)
+
+
+# ---- W8A8 forms (LServe models): same hand-off, no zero-point term, no row sums ---------------------------------------
+def _w8(N, K, seed):
+    rng = np.random.default_rng(seed)
+    w = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+    sw = rng.uniform(0.001, 0.01, size=(N,)).astype(np.float16)
+    return w, sw
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 28672, 4096), (16, 28672, 4096), (7, 2048, 512), (5, 256, 128), (16, 16384, 960),
+                                   (3, 16384, 2048)])   # (256 x 128: leftover steps only; 960: ring rounds + leftovers)
+def test_gemm_silu_w8a8(M, N, K):
+    """act == w8a8_gemm_forward_cuda -> silu_and_mul bit for bit; row maxima == max |act|; GEMM half vs the oracle."""
+    import omniserve_backend.activation_ops as act_ops
+    import omniserve_backend.qgemm_w8a8 as gemm
+    from omniserve_amd.backend import fused_ext
+    w, sw = _w8(N, K, M + N)
+    a, sa, _ = oe.quant_per_token(_x(M, K, 5 + M, 1.0), False)
+    w_d, sw_d, a_d, sa_d = map(to_dev, (w, sw, a, sa))
+    gu = torch.empty((M, N), dtype=torch.float16, device=dev())
+    gemm.w8a8_gemm_forward_cuda(a_d, w_d, sw_d, sa_d, gu)
+    want_act = torch.empty((M, N // 2), dtype=torch.float16, device=dev())
+    act_ops.silu_and_mul(want_act, gu)
+    act = torch.full((M, N // 2), 7.0, dtype=torch.float16, device=dev())
+    amax = fused_ext.new_amax_slots(M, dev())
+    fused_ext.gemm_silu_w8a8(a_d, w_d, sw_d, sa_d, act, amax)
+    torch.cuda.synchronize()
+    assert torch.equal(act.view(torch.int16), want_act.view(torch.int16))
+    assert np.array_equal(_row_amax(amax, M), want_act.float().abs().max(dim=1).values.cpu().numpy())
+    assert_f16_equal(gu, w4a8.gemm_w8a8(a, w, sw, sa), "gate_up W8A8 GEMM vs oracle")
+
+
+def test_gemm_silu_w8a8_rejects_a_plan_with_a_grid_level_split():
+    from omniserve_amd.backend import fused_ext
+    M, N, K = 4, 1024, 8192
+    a = torch.zeros((M, K), dtype=torch.int8, device=dev())
+    w = torch.zeros((N, K), dtype=torch.int8, device=dev())
+    h = lambda n: torch.ones((n,), dtype=torch.float16, device=dev())  # noqa: E731
+    with pytest.raises(RuntimeError):
+        fused_ext.gemm_silu_w8a8(a, w, h(N), h(M), torch.empty((M, N // 2), dtype=torch.float16, device=dev()),
+                                 fused_ext.new_amax_slots(M, dev()))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 14336), (16, 4096, 14336), (1, 4096, 4096), (16, 4096, 4096), (5, 512, 1024),
+                                   (4, 512, 512), (9, 1024, 4096 + 512), (2, 1024, 28672)])
+@pytest.mark.parametrize("edge", [False, True])
+def test_gemm_partial_f16_w8a8(M, N, K, edge):
+    """Slabs == invoke_quant -> gemm_partial_w8a8; scales == invoke_quant's (also vs the oracle); K beyond the int4 forms'
+    16384 limit (no ordered row sum to stage).  edge: all-zero row, +-65504 row, constant row."""
+    import omniserve_backend.fused_kernels as fk
+    from omniserve_amd.backend import fused_ext
+    w, _ = _w8(N, K, 3 + M)
+    x = _x(M, K, 11 + K, 2.0)
+    if edge:
+        x[0] = 0
+        if M > 2:
+            x[1, 0::2] = np.float16(65504.0); x[1, 1::2] = np.float16(-65504.0)
+            x[2] = np.float16(900.0)
+    x_d, w_d = to_dev(x), to_dev(w)
+    slab1 = torch.empty((64 << 20,), dtype=torch.uint8, device=dev())
+    slab2 = torch.zeros((64 << 20,), dtype=torch.uint8, device=dev())
+    q = torch.empty((M, K), dtype=torch.int8, device=dev())
+    sc1 = torch.empty((M,), dtype=torch.float16, device=dev())
+    fk.invoke_quant(q, x_d, sc1)
+    sk1 = fused_ext.gemm_partial_w8a8(q, w_d, slab1)
+    sc2 = torch.full((M,), -1.0, dtype=torch.float16, device=dev())
+    sk2 = fused_ext.gemm_partial_f16_w8a8(x_d, _amax_from(x, M, K), w_d, slab2, sc2)
+    torch.cuda.synchronize()
+    assert sk1 == sk2 >= 1
+    n = sk1 * M * N * 4
+    assert torch.equal(slab1[:n], slab2[:n]), "int32 slabs differ"
+    assert torch.equal(sc1.view(torch.int16), sc2.view(torch.int16)), "scales"
+    with np.errstate(all="ignore"):
+        qo, so, _ = oe.quant_per_token(x, False)
+    assert np.array_equal(q.cpu().numpy(), qo)
+    assert np.array_equal(sc2.cpu().numpy().view(np.uint16), so.view(np.uint16))
+    acc = slab2[:n].view(torch.int32).view(sk2, M, N).sum(dim=0).cpu().numpy()
+    assert np.array_equal(acc, qo.astype(np.int32) @ w.astype(np.int32).T)
