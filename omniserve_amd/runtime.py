@@ -248,6 +248,11 @@ class DecodeRunner:
         # the down projection of the level-3 path has no row kernel in front of it to carry an L2 prefetch: its weights
         # are streamed with non-temporal loads whatever the step's policy says
         self.down_nt = int(os.environ.get("OMNI_DOWN_NT", "1"))
+        # level 3: the norm in front of gate_up prefetches ALL of DOWN's weights (29.6 MB fit the 32 MB of L2s) instead of
+        # the head of gate_up's 58.7 MB; gate_up then streams cold with non-temporal loads (they do not displace the
+        # prefetched lines) and down reads L2: 2.322-2.334 -> 2.294-2.314 ms per step on the same box (profiles/r03_g;
+        # OMNI_L3_PF_DOWN=0: round 3's first arrangement, 2: gate_up with plain loads -- slower, 2.35)
+        self.pf_down = int(os.environ.get("OMNI_L3_PF_DOWN", "1"))
         self.normed = torch.empty((B, c.hidden), dtype=f16, device=device)
         self.lengths = torch.full((B,), context, dtype=torch.int32, device=device)
         self.tokens = torch.randint(0, c.vocab, (B,), device=device, generator=gen)
@@ -395,7 +400,10 @@ class DecodeRunner:
                     sk = self._partial_f16(self.attn_f16, self.amax[li, 0], L["o"], mA, sA)
                 else:
                     sk = self._partial(self._q_attn, L["o"])
-                self._arm(L["gate_up"], silu=self.fused >= 3 and li < nl - 1)
+                if self.fused >= 3 and li < nl - 1 and self.pf_down:
+                    self._arm(L["down"], deferred=True)
+                else:
+                    self._arm(L["gate_up"], silu=self.fused >= 3 and li < nl - 1)
                 self._consume(qa_h, sk, L["o"], sA, mA, L["ln2"], mB, sB)
             else:
                 peer = self.comm is not None and self.fused
@@ -417,13 +425,17 @@ class DecodeRunner:
             if self.fused >= 3 and li < nl - 1:
                 # gate_up with silu_and_mul in its epilogue -> fp16 activation + row maxima; down_proj quantises on the fly
                 G = L["gate_up"]
+                if self.pf_down == 1 and self.weight_policy:
+                    fused_ext.set_weight_policy(0)
                 if per_chn:
                     fused_ext.gemm_silu_per_chn(qa_h, G.qweight, G.s1_scales, sB, G.s1_szeros, mB, self.mlp_act,
                                                 self.amax[li, 1])
                 else:
                     fused_ext.gemm_silu_per_group(qa_h, G.qweight, G.s2_zeros, G.s2_scales, G.s1_scales, sB,
                                                   self.mlp_act, self.amax[li, 1])
-                if self.down_nt and self.weight_policy:
+                if self.pf_down:
+                    fused_ext.set_weight_policy(self.weight_policy)
+                elif self.down_nt and self.weight_policy:
                     fused_ext.set_weight_policy(0)
                 pending = (self._partial_f16(self.mlp_act, self.amax[li, 1], L["down"], mA, sA), L["down"])
                 if self.down_nt and self.weight_policy:
