@@ -422,7 +422,15 @@ struct SrcAttnMerge {  // merged decode-attention output (flash-decoding partial
     float M = -1e30f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) M = __builtin_fmaxf(M, r.m[s]);
-    for (int s = NS; s < nsplit; ++s) M = __builtin_fmaxf(M, part_ml[(bh * nsplit + s) * 2]);
+    // (splits beyond the first NS: batches of NS whose loads are issued together -- a plain loop made every split a
+    //  dependent memory round trip: 16 splits of the LServe sparse attention cost the merge 7.1 us instead of 4.7)
+    for (int s0 = NS; s0 < nsplit; s0 += NS) {
+      float mm[NS];
+#pragma unroll
+      for (int u = 0; u < NS; ++u) mm[u] = part_ml[(bh * nsplit + (s0 + u < nsplit ? s0 + u : 0)) * 2];
+#pragma unroll
+      for (int u = 0; u < NS; ++u) M = __builtin_fmaxf(M, s0 + u < nsplit ? mm[u] : -1e30f);
+    }
     float l = 0.0f;
     float o[VT];
 #pragma unroll
@@ -436,13 +444,25 @@ struct SrcAttnMerge {  // merged decode-attention output (flash-decoding partial
         for (int e = 0; e < VT; ++e) o[e] += w * (e < 4 ? r.a[s][e] : r.b[s][e - 4]);
       }
     }
-    for (int s = NS; s < nsplit; ++s) {
-      const float w = __expf(part_ml[(bh * nsplit + s) * 2] - M);
-      l += w * part_ml[(bh * nsplit + s) * 2 + 1];
-      const v4f a = *reinterpret_cast<const v4f*>(part_o + (bh * nsplit + s) * 128 + d);
-      const v4f b = *reinterpret_cast<const v4f*>(part_o + (bh * nsplit + s) * 128 + d + 4);
+    for (int s0 = NS; s0 < nsplit; s0 += NS) {
+      float2 ml[NS];
+      v4f a[NS], b[NS];
 #pragma unroll
-      for (int e = 0; e < VT; ++e) o[e] += w * (e < 4 ? a[e] : b[e - 4]);
+      for (int u = 0; u < NS; ++u) {   // branch-free: splits >= nsplit re-read split 0 and are skipped below
+        const size_t pi = bh * nsplit + (s0 + u < nsplit ? s0 + u : 0);
+        ml[u] = *reinterpret_cast<const float2*>(part_ml + pi * 2);
+        a[u] = *reinterpret_cast<const v4f*>(part_o + pi * 128 + d);
+        b[u] = *reinterpret_cast<const v4f*>(part_o + pi * 128 + d + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        if (s0 + u < nsplit) {
+          const float w = __expf(ml[u].x - M);
+          l += w * ml[u].y;
+#pragma unroll
+          for (int e = 0; e < VT; ++e) o[e] += w * (e < 4 ? a[u][e] : b[u][e - 4]);
+        }
+      }
     }
     const float inv = 1.0f / (l + 1e-6f);
 #pragma unroll

@@ -12,7 +12,8 @@ res = {}
 in_step = None
 for line in open(by_grid):
     # the level-3 gate_up kernel: w4a8_gemv_kernel<1, 0, false, 4, false, 1, 1, false> on 448 workgroups
-    if "w4a8_gemv_kernel<1, 0, false, 4, false, 1, 1, false>" in line and "| 448,1,1 |" in line:
+    # (NT = true since the norm in front of it prefetches down_proj's weights and gate_up streams cold)
+    if re.search(r"w4a8_gemv_kernel<1, 0, false, 4, (true|false), 1, 1, false", line) and "| 448,1,1 |" in line:
         in_step = float(line.split("|")[4])
 fetch = write = None
 for line in open(pmc_log):
