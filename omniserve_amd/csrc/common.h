@@ -9,6 +9,7 @@ namespace omni {
 typedef _Float16 half_t;
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 

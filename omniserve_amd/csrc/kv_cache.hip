@@ -332,6 +332,15 @@ constexpr int FVTILE = 32 * FVROW;
 #ifndef OMNI_FLASH_MIN_BLOCKS
 #define OMNI_FLASH_MIN_BLOCKS 2
 #endif
+#ifndef OMNI_FLASH_FB
+#define OMNI_FLASH_FB 1        // 32-token tiles per wave whose K and V bytes are requested together.  1: 148 VGPRs (three
+                               // workgroups per CU by registers); 2: 197 VGPRs, two per CU.  Isolated launches time the same
+                               // (15 / 25 / 88 us at 16 x 1 K, 64 x 1 K, 8 x 32 K); inside the decode step 1 is 1-2 % faster per
+                               // STEP at bs = 16 and bs = 64 (2.31 -> 2.26-2.29 ms, 3.59 -> 3.53-3.54 ms, profiles/r03_h)
+#endif
+#ifndef OMNI_FLASH_SLOTS
+#define OMNI_FLASH_SLOTS 512   // workgroups the chip holds at a time (256 CUs x workgroups per CU): the split planner's round size
+#endif
 // KV8: per-tensor int8 pages (fused_attention_per_tensor): rows of Dh bytes, dequant h(kv_qo * f32(int8)) with the static
 // scales kv_qo[0] (K) / kv_qo[1] (V), natural element order (q is not reordered), append with kv_oq, no tail write.
 template <int G, bool DIRECT, bool FG = false, bool KV8 = false>
@@ -385,6 +394,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   const int64_t* vtab = ktab + tab_blocks;
   const int pool_bytes_per_seq = hpool * lay.tpb * RB;
   const float inv_sqrt_dh = 0.08838834764831845f;
+  const float sm_scale2 = 0.12751743075284304f;   // log2(e) / sqrt(Dh): the tile sweep keeps its running maxima in log2 units
   const int vt0 = split * p.split_tokens;
   const int page0 = (FG && streaming) ? 0 : (vt0 >> lay.tpb_log2);
   const bool owns_cur = split == p.nsplit - 1;
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   // One sweep over the split (flash-decoding inside the workgroup): wave w owns the 32-token tiles w, w+4, ... and
   // for each runs Q.K^T -> online softmax in registers -> P.V; a batch of FB tiles' K AND V bytes is in flight
   // while the previous batch is consumed.  No workgroup barrier until the four waves' (max, sum, O) are combined.
-  constexpr int FB = 2;
+  constexpr int FB = OMNI_FLASH_FB;
   uint4 kraw[FB][2][NQ], vraw[FB][2][NQ];
   half_t ksc[FB][2], kze[FB][2], vsc[FB][2], vze[FB][2];   // KV4 only
   // safe token of an out-of-range lane: the split's first token, or (empty split) slot 0 of window entry 0
@@ -629,22 +639,32 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
           acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qb[sidx], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {   // acc[r] = q[head l15] . K[token tbase + 16h + 4*l4 + r]
-          const int ti = tbase + 16 * h + 4 * l4 + r;
-          x[4 * h + r] = ti < nt ? acc[r] * inv_sqrt_dh : -1e30f;
-          tmax = __builtin_fmaxf(tmax, x[4 * h + r]);
+        for (int r = 0; r < 4; ++r)     // acc[r] = q[head l15] . K[token tbase + 16h + 4*l4 + r]; scores in the exp2 domain
+          x[4 * h + r] = acc[r] * sm_scale2;
+      }
+      if (tbase + 32 > nt) {   // wave-uniform: only the last tile of a split has token slots to mask (118 -> ~50 softmax VALU per
+#pragma unroll                 //  full tile: the sweep is VALU-issue bound at every batch size, profiles/r03_h)
+        for (int e = 0; e < 8; ++e) {
+          const int ti = tbase + 16 * (e >> 2) + 4 * l4 + (e & 3);
+          x[e] = ti < nt ? x[e] : -1e30f;
         }
       }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tmax = __builtin_fmaxf(tmax, x[e]);
       tmax = rows4_max(tmax);
-      const float m_new = __builtin_fmaxf(m_run, tmax);
-      const float alpha = __expf(m_run - m_new);
+      const float m_new = __builtin_fmaxf(m_run, tmax);      // (a tile holds >= 1 real token: m_new is a real score)
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.0f;
       v8h pb;   // k-slots of the P.V step: tokens 4*l4+r of group 0, then of group 1 (as the V^T operand below)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const half_t ph = x[e] > -1e29f ? (half_t)__expf(x[e] - m_new) : (half_t)0.0f;
-        pb[e] = ph;
-        psum += (float)ph;
+      for (int e = 0; e < 8; e += 2) {
+        // masked slots: exp2(-1e30 - m_new) = 0.  The row sum takes the unrounded exponentials (as upstream sums them);
+        // the P.V operand is their fp16 rounding
+        const v2f pp = {__builtin_amdgcn_exp2f(x[e] - m_new), __builtin_amdgcn_exp2f(x[e + 1] - m_new)};
+        psum += pp[0] + pp[1];
+        const v2h ph = __builtin_convertvector(pp, v2h);
+        pb[e] = ph[0];
+        pb[e + 1] = ph[1];
       }
       l_run = l_run * alpha + psum;
       if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
@@ -693,7 +713,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
     for (int c = 0; c < 8; ++c)
       *reinterpret_cast<v4f*>(xbuf + ((size_t)wave * G + l15) * DH + c * 16 + 4 * l4) = oacc[c];
     if (l4 == 0) {
-      mlbuf[(wave * G + l15) * 2 + 0] = m_run;
+      mlbuf[(wave * G + l15) * 2 + 0] = m_run * 0.6931471805599453f;    // back to natural units for the combine / merge
       mlbuf[(wave * G + l15) * 2 + 1] = l_run;
     }
   }
@@ -859,7 +879,7 @@ static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int ma
   int s = s_lo;
   long long best = -1;
   for (int n = s_lo; n <= s_hi; ++n) {
-    const long long rounds = ((long long)wgs_per_split * n + 511) / 512;
+    const long long rounds = ((long long)wgs_per_split * n + OMNI_FLASH_SLOTS - 1) / OMNI_FLASH_SLOTS;
     const long long cost = rounds * (split_tokens(n) + 192);
     if (best < 0 || cost < best) { best = cost; s = n; }
   }
