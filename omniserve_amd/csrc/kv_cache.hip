@@ -506,7 +506,9 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   // One sweep over the split (flash-decoding inside the workgroup): wave w owns the 32-token tiles w, w+4, ... and
   // for each runs Q.K^T -> online softmax in registers -> P.V; a batch of FB tiles' K AND V bytes is in flight
   // while the previous batch is consumed.  No workgroup barrier until the four waves' (max, sum, O) are combined.
-  constexpr int FB = OMNI_FLASH_FB;
+  // (fine-grained instantiations keep two tiles per batch: at batch 1 / 256 K tokens the launch has few workgroups and
+  //  lives on loads in flight per wave -- 93 vs 98 us for the dense 4 + 4 head mix; sparse decode times the same)
+  constexpr int FB = FG ? 2 : OMNI_FLASH_FB;
   uint4 kraw[FB][2][NQ], vraw[FB][2][NQ];
   half_t ksc[FB][2], kze[FB][2], vsc[FB][2], vze[FB][2];   // KV4 only
   // safe token of an out-of-range lane: the split's first token, or (empty split) slot 0 of window entry 0

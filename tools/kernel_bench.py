@@ -9,6 +9,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omniserve_amd import _lib  # noqa: E402
+
+if os.environ.get("OMNI_TUNE_LIB"):     # A/B against a library variant (tools/build_variant.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["OMNI_TUNE_LIB"])
 import omniserve_backend.activation_ops as act  # noqa: E402
 import omniserve_backend.fused_attention_ctx_pool as ctx_pool  # noqa: E402
 import omniserve_backend.fused_attention_fine_grained_dense as fgd  # noqa: E402
