@@ -209,6 +209,12 @@ int omni_splitk_w8_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f1
                                                  const void* wscales_f16, const void* ascales_in_f16,
                                                  const void* weight_f16, void* sum_f16, void* scale_f16, float eps,
                                                  int tokens, int hidden, void* stream);
+/* ... and for the LAST decoder layer: its down projection's slabs consumed by the model's final norm --
+ * residual += fp16(epilogue(sum_k slab[k])), out_f16 = omni_rms_norm(residual) (llama_w4a8_unpad.py:484).  w_szs_f16 and
+ * a_ssums_in_f16 both NULL: the W8A8 / per-group epilogue; both given: the per-channel W4A8 one. */
+int omni_splitk_add_rms_norm(void* out_f16, void* residual_f16, const void* slab_i32, int sk, const void* wscales_f16,
+                             const void* ascales_in_f16, const void* w_szs_f16, const void* a_ssums_in_f16,
+                             const void* weight_f16, float eps, int tokens, int hidden, void* stream);
 
 /* Decode attention with the flash-decoding merge fused into the following activation quantisation
  * (llama_w4a8_unpad.py:354): omni_kv4_decode_attention_partial = omni_kv4_decode_attention without its
@@ -287,6 +293,12 @@ int omni_argmax_f16(void* out_i64, const void* logits_f16, int64_t row_stride, i
  * idx int64 [rows] on the device; cols % 8 == 0; ids outside [0, table_rows) leave their row untouched. */
 int omni_gather_rows_f16(void* out_f16, const void* table_f16, const void* idx_i64, int rows, int cols,
                          int64_t table_rows, void* stream);
+/* First launch of a decode step in ONE kernel (decode drivers; not a reference kernel): the embedding lookup of
+ * omni_gather_rows_f16 + lengths_i32[0 .. n_lengths) += 1 (the drivers' `lengths.add_(1)`) + zero_u32[0 .. zero_words) = 0 (the
+ * step's row-maximum slots of the row-kernel-free layer).  n_lengths / zero_words may be 0 (then the pointer may be NULL). */
+int omni_decode_step_begin(void* out_f16, const void* table_f16, const void* idx_i64, int rows, int cols,
+                           int64_t table_rows, void* lengths_i32, int n_lengths, void* zero_u32, long long zero_words,
+                           void* stream);
 
 /* omni_silu_and_mul followed by omni_quant_fuse_sum without materialising the fp16 product
  * (activation.py:54-64 calls them back to back).  in fp16 [tokens, 2d] -> out int8 [tokens, d]. */

@@ -106,6 +106,38 @@ def splitk_w8_add_rms_norm_general_fuse_sum(out, residual, slab, sk, wscales, as
     _lib.check(rc, "fused_ext.splitk_w8_add_rms_norm_general_fuse_sum")
 
 
+def splitk_add_rms_norm(out, residual, slab, sk, wscales, ascales_in, w_szs, a_ssums_in, weight, epsilon):
+    """The LAST layer's deferred down projection consumed by the model's final norm: residual += fp16(GEMM epilogue(sum of
+    sk slabs)); out fp16 = rms_norm(residual) (layernorm_ops.rms_norm, no quantisation).  w_szs / a_ssums_in both None: the
+    W8A8 / per-group epilogue; both given: the per-channel W4A8 one.  Bit-identical to GEMM -> add -> rms_norm."""
+    _lib.require_cuda(out, residual, slab, wscales, ascales_in, w_szs, a_ssums_in, weight)
+    hidden = residual.shape[-1]
+    tokens = residual.numel() // hidden
+    rc = _lib.lib().omni_splitk_add_rms_norm(out.data_ptr(), residual.data_ptr(), slab.data_ptr(), int(sk),
+                                             wscales.data_ptr(), ascales_in.data_ptr(), _ptr(w_szs), _ptr(a_ssums_in),
+                                             weight.data_ptr(), float(epsilon), tokens, hidden, _lib.current_stream())
+    _lib.check(rc, "fused_ext.splitk_add_rms_norm")
+
+
+def decode_step_begin(out, table, idx, lengths=None, zero=None):
+    """First launch of a decode step: out = table[idx] (embed_rows), lengths += 1 (int32), zero[...] = 0 (int32 / uint32
+    words: the step's row-maximum slots) in one kernel instead of three."""
+    _lib.require_cuda(out, table, idx, lengths, zero)
+    if table.dtype != torch.float16 or out.dtype != torch.float16 or table.dim() != 2 or not table.is_contiguous() or \
+            not out.is_contiguous() or out.shape[-1] != table.shape[1]:
+        raise RuntimeError("decode_step_begin: contiguous fp16 table [V, cols] and out [rows, cols] expected")
+    if idx.dtype != torch.int64 or not idx.is_contiguous() or idx.numel() != out.numel() // table.shape[1]:
+        raise RuntimeError("decode_step_begin: idx must be a contiguous int64 tensor with one id per output row")
+    if lengths is not None and (lengths.dtype != torch.int32 or not lengths.is_contiguous()):
+        raise RuntimeError("decode_step_begin: lengths must be a contiguous int32 tensor")
+    if zero is not None and (zero.element_size() != 4 or not zero.is_contiguous()):
+        raise RuntimeError("decode_step_begin: zero must be a contiguous tensor of 32-bit words")
+    rc = _lib.lib().omni_decode_step_begin(out.data_ptr(), table.data_ptr(), idx.data_ptr(), idx.numel(), table.shape[1],
+                                           table.shape[0], _ptr(lengths), 0 if lengths is None else lengths.numel(),
+                                           _ptr(zero), 0 if zero is None else zero.numel(), _lib.current_stream())
+    _lib.check(rc, "fused_ext.decode_step_begin")
+
+
 def decode_attention_quant_fuse_sum(out_i8, q, k, v, kv_pointers, lengths, tokens_per_block, timestep,
                                     rotary_base, input_sum, scale):
     """single_query_attention (KV4 + zeros, neox RoPE) followed by invoke_quant_fuse_sum of its

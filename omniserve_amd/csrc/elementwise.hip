@@ -324,9 +324,21 @@ struct SrcSlabAddT {  // residual += h(GEMM epilogue(sum of split-K slabs)), in 
         s1 += k < sk ? t1[k] : (v4i){0, 0, 0, 0};
       }
     }
-    for (int k = 8; k < sk; ++k) {
-      s0 += *reinterpret_cast<const v4i*>(slab + (size_t)k * sstride + i);
-      s1 += *reinterpret_cast<const v4i*>(slab + (size_t)k * sstride + i + 4);
+    // slabs beyond 8 (the W8A8 down projection of the LServe driver leaves 14): further batches of 8 -- a plain loop made
+    // every slab a dependent round trip for the one workgroup of a batch-1 row.  Integer sums: any order is exact.
+    for (int k0 = 8; k0 < sk; k0 += 8) {
+      v4i t0[8], t1[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const size_t off = (size_t)(k0 + k < sk ? k0 + k : 0) * sstride + i;
+        t0[k] = *reinterpret_cast<const v4i*>(slab + off);
+        t1[k] = *reinterpret_cast<const v4i*>(slab + off + 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s0 += k0 + k < sk ? t0[k] : (v4i){0, 0, 0, 0};
+        s1 += k0 + k < sk ? t1[k] : (v4i){0, 0, 0, 0};
+      }
     }
     r.s0 = s0; r.s1 = s1;
   }
@@ -664,28 +676,35 @@ __global__ __launch_bounds__(RT) void tp_add_norm_v2_kernel(int8_t* __restrict__
 }
 
 // rms_norm (fp16 out): NV = min(hidden,1024)
-template <int RT, int RV>
-__global__ __launch_bounds__(RT) void rms_norm_v2_kernel(half_t* __restrict__ out, const half_t* __restrict__ in,
+// Src: SrcPlain (the reference's rms_norm) or a split-K slab consumer (fused extension: the LAST layer's down projection
+// deferred into the model's final norm, omni_splitk_add_rms_norm)
+template <int RT, int RV, typename Src = SrcPlain>
+__global__ __launch_bounds__(RT) void rms_norm_v2_kernel(half_t* __restrict__ out, Src src0,
                                                           const half_t* __restrict__ weight, float eps, int hidden, int nv) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   __shared__ float red[96];
   const int p = threadIdx.x;
-  const SrcPlain src{in + (size_t)blockIdx.x * hidden, hidden};
+  const Src src = src0.at_row(blockIdx.x);
   float x[RV][VT];
-  SrcPlain::Raw raw[RV];
+  typename Src::Raw raw[Src::BATCH ? RV : 1];
   v8h w8[RV];
 #pragma unroll
   for (int it = 0; it < RV; ++it) {
     const int i = (p + it * RT) * VT;
     const int ic = i < hidden ? i : 0;
-    src.fetch(ic, raw[it]);
+    if constexpr (Src::BATCH) src.fetch(ic, raw[it]);
     w8[it] = *reinterpret_cast<const v8h*>(weight + ic);
   }
 #pragma unroll
   for (int it = 0; it < RV; ++it) {
     const int i = (p + it * RT) * VT;
     if (i < hidden) {
-      src.finish(i, raw[it], x[it]);
+      if constexpr (Src::BATCH) {
+        src.finish(i, raw[it], x[it]);
+      } else {
+        src.fetch(i, raw[0]);
+        src.finish(i, raw[0], x[it]);
+      }
       *reinterpret_cast<v4f*>(xs + i) = (v4f){x[it][0], x[it][1], x[it][2], x[it][3]};
       *reinterpret_cast<v4f*>(xs + i + 4) = (v4f){x[it][4], x[it][5], x[it][6], x[it][7]};
     }
@@ -822,7 +841,7 @@ extern "C" int omni_rms_norm(void* out_f16, const void* in_f16, const void* weig
     if (v2_ok(hidden, nv)) {
       #undef KQ_
       #define KQ_(RT_, RV_) rms_norm_v2_kernel<RT_, RV_>
-      OMNI_V2_LAUNCH_PLAIN(KQ_, tokens, hidden, hidden, (half_t*)out_f16, (const half_t*)in_f16,
+      OMNI_V2_LAUNCH_PLAIN(KQ_, tokens, hidden, hidden, (half_t*)out_f16, SrcPlain{(const half_t*)in_f16, hidden},
                            (const half_t*)weight_f16, eps, hidden, nv);
       return omni_launch_status();
     }
@@ -1061,6 +1080,37 @@ extern "C" int omni_splitk_w8_add_rms_norm_general_fuse_sum(void* out_i8, void* 
   return omni_launch_status();
 }
 
+// Fused extension: the LAST decoder layer's down projection deferred into the model's final norm -- residual += fp16(GEMM
+// epilogue(sum of the split-K slabs)), then rms_norm (layernorm_kernels.cu rms_norm_kernel; llama_w4a8_unpad.py:484 self.norm).
+// w_szs_f16 / a_ssums_in_f16 == NULL: the W8A8 / per-group epilogue acc * (sw * sa); else the per-channel one.
+extern "C" int omni_splitk_add_rms_norm(void* out_f16, void* residual_f16, const void* slab_i32, int sk,
+                                        const void* wscales_f16, const void* ascales_in_f16, const void* w_szs_f16,
+                                        const void* a_ssums_in_f16, const void* weight_f16, float eps, int tokens, int hidden,
+                                        void* stream) {
+  if (!out_f16 || !residual_f16 || !slab_i32 || !wscales_f16 || !ascales_in_f16 || !weight_f16 || tokens < 0 || hidden < 1 ||
+      sk < 1 || ((w_szs_f16 == nullptr) != (a_ssums_in_f16 == nullptr)))
+    return OMNI_EINVAL;
+  const int nv = norm_block(hidden, false);
+  if (!v2_ok(hidden, nv)) return OMNI_EINVAL;
+  if (tokens == 0) return OMNI_OK;
+  if (w_szs_f16) {
+    SrcSlabAddChn src{(half_t*)residual_f16, (const int32_t*)slab_i32, (size_t)tokens * hidden, sk, hidden,
+                      (const half_t*)wscales_f16, (const half_t*)w_szs_f16, (const half_t*)ascales_in_f16,
+                      (const half_t*)a_ssums_in_f16, 0.f, 0.f};
+    #undef KQ_
+    #define KQ_(RT_, RV_) rms_norm_v2_kernel<RT_, RV_, SrcSlabAddChn>
+    OMNI_V2_LAUNCH_PLAIN(KQ_, tokens, hidden, hidden, (half_t*)out_f16, src, (const half_t*)weight_f16, eps, hidden, nv);
+  } else {
+    SrcSlabAddW8 src{(half_t*)residual_f16, (const int32_t*)slab_i32, (size_t)tokens * hidden, sk, hidden,
+                     (const half_t*)wscales_f16, (const half_t*)nullptr, (const half_t*)ascales_in_f16,
+                     (const half_t*)nullptr, 0.f, 0.f};
+    #undef KQ_
+    #define KQ_(RT_, RV_) rms_norm_v2_kernel<RT_, RV_, SrcSlabAddW8>
+    OMNI_V2_LAUNCH_PLAIN(KQ_, tokens, hidden, hidden, (half_t*)out_f16, src, (const half_t*)weight_f16, eps, hidden, nv);
+  }
+  return omni_launch_status();
+}
+
 // Fused extension: kv4_decode_merge_kernel + omni_quant_fuse_sum in one kernel (one workgroup per token).
 extern "C" int omni_attn_merge_quant_fuse_sum(void* out_i8, const void* part_ml_f32, const void* part_o_f32, int nsplit,
                                               void* sum_f16, void* scale_f16, int batch, int num_heads, void* stream) {
@@ -1260,6 +1310,37 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(half_t* __restrict__ o
   }
   const uint4* src = reinterpret_cast<const uint4*>(table + (size_t)r * cols);
   for (int i = threadIdx.x; i < cols / 8; i += 256) dst[i] = src[i];
+}
+
+// Decode drivers, first launch of a step: the embedding lookup + lengths[b] += 1 + the zeroing of the step's row-maximum
+// slots in ONE launch (three dependent ~4.7-us launches otherwise: lengths.add_(1), amax.zero_(), the lookup).
+__global__ __launch_bounds__(256) void decode_step_begin_kernel(half_t* __restrict__ out, const half_t* __restrict__ table,
+                                                                const int64_t* __restrict__ idx, int cols, int64_t table_rows,
+                                                                int* __restrict__ lengths, int n_lengths,
+                                                                uint32_t* __restrict__ zero, long long zero_words) {
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < n_lengths; i += 256) lengths[i] += 1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_words; i += (long long)gridDim.x * 256) zero[i] = 0u;
+  const int64_t r = idx[blockIdx.x];
+  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * cols);
+  if (r < 0 || r >= table_rows) {     // (see gather_rows_kernel)
+    for (int i = threadIdx.x; i < cols / 8; i += 256) dst[i] = make_uint4(0x7E007E00u, 0x7E007E00u, 0x7E007E00u, 0x7E007E00u);
+    return;
+  }
+  const uint4* src = reinterpret_cast<const uint4*>(table + (size_t)r * cols);
+  for (int i = threadIdx.x; i < cols / 8; i += 256) dst[i] = src[i];
+}
+
+extern "C" int omni_decode_step_begin(void* out_f16, const void* table_f16, const void* idx_i64, int rows, int cols,
+                                      int64_t table_rows, void* lengths_i32, int n_lengths, void* zero_u32,
+                                      long long zero_words, void* stream) {
+  if (!out_f16 || !table_f16 || !idx_i64 || rows < 1 || cols < 8 || cols % 8 || table_rows < 1 || n_lengths < 0 ||
+      zero_words < 0 || (n_lengths > 0 && !lengths_i32) || (zero_words > 0 && !zero_u32))
+    return OMNI_EINVAL;
+  hipLaunchKernelGGL(decode_step_begin_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (half_t*)out_f16,
+                     (const half_t*)table_f16, (const int64_t*)idx_i64, cols, table_rows, (int*)lengths_i32, n_lengths,
+                     (uint32_t*)zero_u32, zero_words);
+  return omni_launch_status();
 }
 
 extern "C" int omni_gather_rows_f16(void* out_f16, const void* table_f16, const void* idx_i64, int rows, int cols,

@@ -201,10 +201,10 @@ class LServeDecodeRunner:
         `self.lengths`; `hist` only sizes RoPE tables, split plans and the selector's padded output)."""
         c, B = self.cfg, self.B
         Hq, Hk, d = c.heads, c.kv_heads, c.head_dim
-        self.lengths.add_(1)
-        if self.fused:
-            fused_ext.embed_rows(self.x, self.embed, self.tokens)
+        if self.fused:     # embedding rows + lengths += 1 + the step's row-maximum slots zeroed: one launch
+            fused_ext.decode_step_begin(self.x, self.embed, self.tokens, self.lengths, self.amax if self.rowfree else None)
         else:
+            self.lengths.add_(1)
             torch.index_select(self.embed, 0, self.tokens, out=self.x)
         sc = self.act_scale                      # scales written by the norm kernels
         sq = self.act_scale2 if self.fused else sc   # ... by the quantisers (kept apart: a deferred epilogue reads them)
@@ -215,8 +215,6 @@ class LServeDecodeRunner:
         total_pages = hist // self.tpb + 1
         sm = None          # W8A8: nobody reads a row sum (rms_norm_general / invoke_quant upstream): the fused kernels skip it
         rowfree = self.rowfree
-        if rowfree:
-            self.amax.zero_()
         for li, L in enumerate(self.layers):
             self._arm(L["qkv"])
             if pending is not None:       # residual += down_proj(previous layer) [deferred epilogue], norm + quant

@@ -253,6 +253,10 @@ class DecodeRunner:
         # prefetched lines) and down reads L2: 2.322-2.334 -> 2.294-2.314 ms per step on the same box (profiles/r03_g;
         # OMNI_L3_PF_DOWN=0: round 3's first arrangement, 2: gate_up with plain loads -- slower, 2.35)
         self.pf_down = int(os.environ.get("OMNI_L3_PF_DOWN", "1"))
+        # level 3 also in the LAST layer: its down projection's slabs are consumed by the model's final norm
+        # (fused_ext.splitk_add_rms_norm) instead of GEMV epilogue + residual add + rms_norm (OMNI_L3_LAST=0: off, A/B)
+        self.last_l3 = (self.fused >= 3 and self.tp_size == 1 and self.comm is None and
+                        os.environ.get("OMNI_L3_LAST", "1") != "0")
         self.normed = torch.empty((B, c.hidden), dtype=f16, device=device)
         self.lengths = torch.full((B,), context, dtype=torch.int32, device=device)
         self.tokens = torch.randint(0, c.vocab, (B,), device=device, generator=gen)
@@ -345,12 +349,11 @@ class DecodeRunner:
     def _eager_step_body(self):
         # one decoder layer at decode shape = llama_w4a8_unpad.py:406-438
         c = self.cfg
-        self.lengths.add_(1)
-        if self.fused >= 3:
-            self.amax.zero_()
-        if self.fused:     # (level >= 1: one short kernel; torch's index_select takes 12.6 us for 16 rows)
-            fused_ext.embed_rows(self.x, self.embed, self.tokens)
+        if self.fused:     # one launch: embedding rows (torch's index_select takes 12.6 us for 16 rows) + lengths += 1 + the
+            fused_ext.decode_step_begin(self.x, self.embed, self.tokens, self.lengths,      # step's row-maximum slots zeroed
+                                        self.amax if self.fused >= 3 else None)
         else:
+            self.lengths.add_(1)
             torch.index_select(self.embed, 0, self.tokens, out=self.x)
         B = self.B
         hq, hk, d = self.hl, self.kl, c.head_dim     # this rank's heads
@@ -363,6 +366,7 @@ class DecodeRunner:
         nl = len(self.layers)
         for li, L in enumerate(self.layers):
             qa_h, qa_i = self._q_hidden, self._q_inter
+            l3 = self.fused >= 3 and (li < nl - 1 or self.last_l3)     # row-kernel-free MLP half in this layer
             self._arm(L["qkv"])
             if pending is not None:     # residual += down_proj(prev layer) [deferred epilogue], norm + quant
                 sk, lin = pending
@@ -400,10 +404,10 @@ class DecodeRunner:
                     sk = self._partial_f16(self.attn_f16, self.amax[li, 0], L["o"], mA, sA)
                 else:
                     sk = self._partial(self._q_attn, L["o"])
-                if self.fused >= 3 and li < nl - 1 and self.pf_down:
+                if l3 and self.pf_down:
                     self._arm(L["down"], deferred=True)
                 else:
-                    self._arm(L["gate_up"], silu=self.fused >= 3 and li < nl - 1)
+                    self._arm(L["gate_up"], silu=l3)
                 self._consume(qa_h, sk, L["o"], sA, mA, L["ln2"], mB, sB)
             else:
                 peer = self.comm is not None and self.fused
@@ -422,7 +426,7 @@ class DecodeRunner:
                         layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln2"], mB, sB, c.eps, True)
                     else:
                         layernorm_ops.rms_norm_general(qa_h, self.x, L["ln2"], sB, c.eps, True)
-            if self.fused >= 3 and li < nl - 1:
+            if l3:
                 # gate_up with silu_and_mul in its epilogue -> fp16 activation + row maxima; down_proj quantises on the fly
                 G = L["gate_up"]
                 if self.pf_down == 1 and self.weight_policy:
@@ -462,7 +466,12 @@ class DecodeRunner:
                     self._all_reduce(self.proj_buf)     # (peer: consumed by the next layer's add + norm)
                 if not self.fused or li == nl - 1:
                     self.x.add_(self.proj_buf)
-        layernorm_ops.rms_norm(self.normed, self.x, self.final_norm, c.eps, False)
+        if pending is not None:     # the last layer's down projection: epilogue + residual add inside the final norm
+            sk, lin = pending
+            fused_ext.splitk_add_rms_norm(self.normed, self.x, self.slab, sk, lin.s1_scales, sA,
+                                          lin.s1_szeros if per_chn else None, mA if per_chn else None, self.final_norm, c.eps)
+        else:
+            layernorm_ops.rms_norm(self.normed, self.x, self.final_norm, c.eps, False)
         logits = torch.matmul(self.normed, self.lm_head.t())
         if self.fused:
             fused_ext.argmax(self.tokens, logits)      # same result as torch.argmax, 6 us instead of 47

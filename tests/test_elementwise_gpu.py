@@ -298,3 +298,83 @@ def test_fused_entry_points_without_the_row_sum():
         outs.append((q.cpu().numpy(), sc.cpu().numpy(), r.cpu().numpy(), q2.cpu().numpy(), sc2.cpu().numpy()))
     for a, b in zip(*outs):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+@pytest.mark.parametrize("flavour,M,N,K", [("chn", 16, 4096, 14336), ("chn", 3, 2048, 4096), ("w8", 1, 4096, 14336),
+                                           ("w8", 16, 4096, 4096), ("grp", 16, 4096, 14336)])
+def test_deferred_splitk_final_rms_norm_matches_gemm_then_add_norm(flavour, M, N, K):
+    """The LAST layer's down projection consumed by the model's final norm: partial GEMM + splitk_add_rms_norm == GEMM ->
+    residual add -> rms_norm (llama_w4a8_unpad.py:484 / llama_w8a8_unpad.py), bit for bit, and against the oracle."""
+    import omniserve_backend.layernorm_ops as ln
+    from omniserve_amd.backend import fused_ext
+    from oracle import w4a8
+    resid = _x(M, N, 6, 2.0)
+    g = (1.0 + 0.1 * np.random.default_rng(1).standard_normal(N)).astype(np.float16)
+    g_d = to_dev(g)
+    proj = torch.empty((M, N), dtype=torch.float16, device=dev())
+    slab = torch.empty((64 << 20,), dtype=torch.uint8, device=dev())
+    if flavour == "chn":
+        import omniserve_backend.qgemm_w4a8_per_chn as gemm
+        u, z, s1 = w4a8.synth_per_channel(N, K, 3)
+        qw, s1h, szh = w4a8.pack_per_channel(u, z, s1)
+        a, sa, asum = oe.quant_per_token(_x(M, K, 5, 1.0), True)
+        qw_d, s1_d, sz_d, a_d, sa_d, as_d = map(to_dev, (qw, s1h, szh, a, sa, asum))
+        gemm.gemm_forward_cuda(a_d, qw_d, s1_d, sa_d, sz_d, as_d, proj)
+        sk = fused_ext.gemm_partial_per_chn(a_d, qw_d, slab)
+        args = (s1_d, sa_d, sz_d, as_d)
+        want = w4a8.gemm_per_chn(a, qw, s1h, sa, szh, asum)
+    elif flavour == "w8":
+        import omniserve_backend.qgemm_w8a8 as gemm
+        rng = np.random.default_rng(M + K)
+        w = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+        sw = rng.uniform(0.0002, 0.0014, size=(N,)).astype(np.float16)
+        a, sa, _ = oe.quant_per_token(_x(M, K, 5, 1.0), False)
+        w_d, sw_d, a_d, sa_d = map(to_dev, (w, sw, a, sa))
+        gemm.w8a8_gemm_forward_cuda(a_d, w_d, sw_d, sa_d, proj)
+        sk = fused_ext.gemm_partial_w8a8(a_d, w_d, slab)
+        args = (sw_d, sa_d, None, None)
+        want = w4a8.gemm_w8a8(a, w, sw, sa)
+    else:
+        import omniserve_backend.qgemm_w4a8_per_group as gemm
+        u, z, s2, s1 = w4a8.synth_per_group(N, K, seed=M + 1)
+        qw, s1h, s2s, s2z = w4a8.pack_per_group(u, z, s2, s1)
+        a, sa, _ = oe.quant_per_token(_x(M, K, 5, 1.0), False)
+        qw_d, s1_d, s2s_d, s2z_d, a_d, sa_d = map(to_dev, (qw, s1h, s2s, s2z, a, sa))
+        gemm.gemm_forward_cuda(a_d, qw_d, s2z_d, s2s_d, s1_d, sa_d, proj)
+        sk = fused_ext.gemm_partial_per_group(a_d, qw_d, s2z_d, s2s_d, slab)
+        args = (s1_d, sa_d, None, None)
+        want = w4a8.gemm_per_group(a, qw, s2z, s2s, s1h, sa)
+    x1 = to_dev(resid); x1.add_(proj)
+    o1 = torch.empty((M, N), dtype=torch.float16, device=dev())
+    ln.rms_norm(o1, x1, g_d, 1e-5, False)
+    x2 = to_dev(resid)
+    o2 = torch.full((M, N), 7.0, dtype=torch.float16, device=dev())
+    fused_ext.splitk_add_rms_norm(o2, x2, slab, sk, *args, g_d, 1e-5)
+    torch.cuda.synchronize()
+    assert sk >= 1
+    assert torch.equal(x1.view(torch.int16), x2.view(torch.int16)), "residual"
+    assert torch.equal(o1.view(torch.int16), o2.view(torch.int16)), "final norm output"
+    xs = (resid.astype(np.float32) + want.astype(np.float32)).astype(np.float16)
+    assert_f16_equal(x2, xs, "residual vs oracle")
+    assert_f16_equal(o2, oe.rms_norm(xs, g, 1e-5), "rms_norm vs oracle")
+
+
+def test_decode_step_begin_is_three_torch_ops():
+    from omniserve_amd.backend import fused_ext
+    g = torch.Generator(device="cpu").manual_seed(5)
+    table = torch.randn((1000, 4096), generator=g).half().to(dev())
+    idx = torch.randint(0, 1000, (16,), generator=g).to(dev())
+    lengths = torch.arange(100, 116, dtype=torch.int32, device=dev())
+    amax = torch.full((32, 2, 1024), 0x3F800000, dtype=torch.int32, device=dev())
+    out = torch.zeros((16, 4096), dtype=torch.float16, device=dev())
+    fused_ext.decode_step_begin(out, table, idx, lengths, amax)
+    torch.cuda.synchronize()
+    assert torch.equal(out, torch.index_select(table, 0, idx))
+    assert torch.equal(lengths.cpu(), torch.arange(101, 117, dtype=torch.int32))
+    assert int(amax.abs().sum()) == 0
+    # optional parts; a bad id fills its row with NaN as embed_rows does
+    idx[3] = 5000
+    fused_ext.decode_step_begin(out, table, idx)
+    torch.cuda.synchronize()
+    assert torch.isnan(out[3].float()).all() and torch.equal(out[4], table[idx[4]])
+    assert torch.equal(lengths.cpu(), torch.arange(101, 117, dtype=torch.int32))
