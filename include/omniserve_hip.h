@@ -300,6 +300,18 @@ int omni_decode_step_begin(void* out_f16, const void* table_f16, const void* idx
                            int64_t table_rows, void* lengths_i32, int n_lengths, void* zero_u32, long long zero_words,
                            void* stream);
 
+/* Fused extension: the NEXT decode-attention launch of the calling thread (omni_kv4_decode_attention[_partial],
+ * omni_kv4_decode_attention_fine_grained, omni_kv8_decode_attention_per_tensor, omni_kv_decode_attention_fine_grained_partial;
+ * one shot) takes the current token's q / k / v rows from the qkv projection's int32 split-K slabs
+ * (omni_*_gemm_partial: slab [sk][M][N]) and applies the projection's epilogue in its first load trip -- the values are the
+ * fp16 the GEMM would have stored, so attention output and appended cache rows are bit-identical; the slab epilogue launch
+ * between the projection and the attention disappears.  col_q / col_k / col_v: first output channel of the three blocks of a
+ * row (the reference's fused qkv layout: 0, Hq*128, (Hq+Hkv)*128).  w_szs / a_ssums: both given = per-channel W4A8 epilogue,
+ * both NULL = W8A8 / per-group.  The q / k / v pointers of the launch are then only validated, not read.  slab NULL disarms. */
+int omni_decode_arm_qkv_slabs(const void* slab_i32, int sk, int M, int N, int col_q, int col_k, int col_v,
+                              const void* wscales_f16, const void* ascales_f16, const void* w_szs_f16,
+                              const void* a_ssums_f16);
+
 /* omni_silu_and_mul followed by omni_quant_fuse_sum without materialising the fp16 product
  * (activation.py:54-64 calls them back to back).  in fp16 [tokens, 2d] -> out int8 [tokens, d]. */
 int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, void* sum_f16, void* scale_f16,

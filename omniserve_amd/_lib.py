@@ -56,6 +56,7 @@ PROTOTYPES = {
     "omni_w4a8_per_group_gemm_partial_f16": (_i, [_vp] * 6 + [_sz, _vp, _vp, _i, _i, _i, _c.POINTER(_i), _vp]),
     "omni_attn_merge_f16_amax": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "omni_splitk_add_rms_norm": (_i, [_vp, _vp, _vp, _i] + [_vp] * 5 + [_f, _i, _i, _vp]),
+    "omni_decode_arm_qkv_slabs": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "omni_decode_step_begin": (_i, [_vp, _vp, _vp, _i, _i, _c.c_int64, _vp, _i, _vp, _c.c_longlong, _vp]),
     "omni_w8a8_gemm_silu": (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
     "omni_w8a8_gemm_partial_f16": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _c.POINTER(_i), _vp]),

@@ -119,6 +119,22 @@ def splitk_add_rms_norm(out, residual, slab, sk, wscales, ascales_in, w_szs, a_s
     _lib.check(rc, "fused_ext.splitk_add_rms_norm")
 
 
+def decode_arm_qkv_slabs(slab, sk, rows, width, col_q, col_k, col_v, wscales, ascales, w_szs=None, a_ssums=None):
+    """The next decode-attention call of this thread reads the current token's q / k / v from the qkv projection's int32
+    split-K slabs (gemm_partial_*: slab [sk][rows][width]) and applies the projection's epilogue itself: no slab epilogue
+    launch between the projection and the attention, same bits.  col_*: first channel of the q / k / v blocks of a row.
+    w_szs / a_ssums: per-channel W4A8 zero term (both) or None (W8A8 / per-group).  slab=None disarms."""
+    if slab is None:
+        _lib.check(_lib.lib().omni_decode_arm_qkv_slabs(None, 0, 0, 0, 0, 0, 0, None, None, None, None),
+                   "fused_ext.decode_arm_qkv_slabs")
+        return
+    _lib.require_cuda(slab, wscales, ascales, w_szs, a_ssums)
+    rc = _lib.lib().omni_decode_arm_qkv_slabs(slab.data_ptr(), int(sk), int(rows), int(width), int(col_q), int(col_k),
+                                              int(col_v), wscales.data_ptr(), ascales.data_ptr(), _ptr(w_szs),
+                                              _ptr(a_ssums))
+    _lib.check(rc, "fused_ext.decode_arm_qkv_slabs")
+
+
 def decode_step_begin(out, table, idx, lengths=None, zero=None):
     """First launch of a decode step: out = table[idx] (embed_rows), lengths += 1 (int32), zero[...] = 0 (int32 / uint32
     words: the step's row-maximum slots) in one kernel instead of three."""

@@ -272,6 +272,20 @@ __device__ __forceinline__ void kv8_dequant16(const uint4 raw, float s, v2h out[
   }
 }
 
+// Fused extension: the q / k / v rows of the current token as the qkv projection's int32 split-K slabs (the projection's
+// GEMM epilogue -- qgemm_kernel.h epilogue<> -- is applied by the attention kernel's first load trip instead of by a slab
+// epilogue launch between the two).  slab == nullptr: plain fp16 q / k / v.
+struct QkvSlabSrc {
+  const int32_t* slab;     // [sk][M][N] int32 partial sums of the qkv projection (omni_*_gemm_partial)
+  long long sstride;       // M * N
+  int sk, n;               // slabs, row width N
+  int col_q, col_k, col_v; // first output channel of the q / k / v blocks inside a row
+  const half_t* wscales;   // [N]
+  const half_t* wsz;       // [N] per-channel W4A8 zero term, or nullptr (W8A8 / per-group epilogue)
+  const half_t* ascales;   // [M] scales (and sums) of the projection's int8 input
+  const half_t* asum;      // nullptr with wsz
+};
+
 struct DecodeArgs {
   half_t* out;             // [B,Hq,128]
   const half_t* q;         // row stride q_stride
@@ -291,6 +305,7 @@ struct DecodeArgs {
   FgArgs fg;               // fine-grained (retrieval / streaming) extension, used by the FG instantiations
   const float* kv_qo;      // KV8 instantiations: device fp32 [2] kv_scale_quant_orig (K, V) ...
   const float* kv_oq;      // ... and kv_scale_orig_quant
+  QkvSlabSrc qs;           // q / k / v from the projection's slabs (slab != nullptr)
 };
 
 constexpr int DEC_MAX_SPLITS = 1024;   // KV splits per (sequence, head group): contexts up to 1024 x 2048 tokens
@@ -424,17 +439,70 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   const int64_t dummy_ptr = tid < 80 ? (tid < 40 ? ktab : vtab)[0] : 0;
   constexpr int QIT = ((G + 1) * 64 + DEC_THREADS - 1) / DEC_THREADS;
   half_t qa[QIT], qbv[QIT];
-#pragma unroll
-  for (int j = 0; j < QIT; ++j) {
-    const int idx = tid + j * DEC_THREADS;
-    const int h = idx >> 6, i = idx & 63;
-    const half_t* src = h < G ? p.q + (size_t)b * p.q_stride + (size_t)(hq0 + h) * DH
-                              : p.k + (size_t)b * p.kv_stride + (size_t)hk * DH;   // h > G (idle slots): k again
-    qa[j] = src[i];
-    qbv[j] = src[i + 64];
-  }
   half_t vcur_r = (half_t)0.0f;
-  if (tid < DH) vcur_r = p.v[(size_t)b * p.kv_stride + (size_t)hk * DH + tid];
+  if (p.qs.slab == nullptr) {
+#pragma unroll
+    for (int j = 0; j < QIT; ++j) {
+      const int idx = tid + j * DEC_THREADS;
+      const int h = idx >> 6, i = idx & 63;
+      const half_t* src = h < G ? p.q + (size_t)b * p.q_stride + (size_t)(hq0 + h) * DH
+                                : p.k + (size_t)b * p.kv_stride + (size_t)hk * DH;   // h > G (idle slots): k again
+      qa[j] = src[i];
+      qbv[j] = src[i + 64];
+    }
+    if (tid < DH) vcur_r = p.v[(size_t)b * p.kv_stride + (size_t)hk * DH + tid];
+  } else {
+    // the qkv projection left int32 split-K slabs: sum them and apply its epilogue here (same arithmetic and operation
+    // order as qgemm_kernel.h epilogue<>: the values are the fp16 the slab epilogue launch would have stored)
+    const QkvSlabSrc qs = p.qs;
+    // all loads of the thread's 2 QIT + 1 channels first (up to four slabs each in one batch: a plain loop over the slabs
+    // made every slab a dependent L2 round trip in front of everything else the kernel does), then the arithmetic
+    constexpr int NE = 2 * QIT + 1, SB = 4;
+    int nch[NE];
+#pragma unroll
+    for (int j = 0; j < QIT; ++j) {
+      const int idx = tid + j * DEC_THREADS;
+      const int h = idx >> 6, i = idx & 63;
+      const int n0 = h < G ? qs.col_q + (hq0 + h) * DH : qs.col_k + hk * DH;
+      nch[2 * j] = n0 + i;
+      nch[2 * j + 1] = n0 + i + 64;
+    }
+    nch[NE - 1] = qs.col_v + hk * DH + (tid < DH ? tid : 0);
+    int part[NE][SB];
+    half_t swh[NE], szh[NE];
+    const half_t sah = qs.ascales[b];
+    const half_t ash = qs.asum ? qs.asum[b] : (half_t)0.0f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int32_t* src = qs.slab + (size_t)b * qs.n + nch[e];
+#pragma unroll
+      for (int k = 0; k < SB; ++k) part[e][k] = src[(size_t)(k < qs.sk ? k : 0) * qs.sstride];
+      swh[e] = qs.wscales[nch[e]];
+      szh[e] = qs.wsz ? qs.wsz[nch[e]] : (half_t)0.0f;
+    }
+    const float sa = (float)sah, as = (float)ash;
+    half_t val[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      int acc = 0;
+#pragma unroll
+      for (int k = 0; k < SB; ++k) acc += k < qs.sk ? part[e][k] : 0;
+      for (int k = SB; k < qs.sk; ++k) acc += qs.slab[(size_t)k * qs.sstride + (size_t)b * qs.n + nch[e]];
+      const float sw = (float)swh[e];
+      if (qs.wsz) {
+        float t = (float)acc * sw;
+        t = t * sa;
+        const float c = (float)szh[e] * as;
+        val[e] = (half_t)(t - c);
+      } else {
+        const float sc = sw * sa;
+        val[e] = (half_t)((float)acc * sc);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < QIT; ++j) { qa[j] = val[2 * j]; qbv[j] = val[2 * j + 1]; }
+    if (tid < DH) vcur_r = val[NE - 1];
+  }
 
   // (sparse) the last selected page is the newest one: requested with trip 1, it bounds the attended tokens below
   int dyn_last = 0;
@@ -1056,11 +1124,36 @@ extern "C" size_t omni_kv4_decode_workspace_bytes(int batch, int num_heads, int 
   return (size_t)batch * num_heads * (size_t)s * (DH + 2) * sizeof(float);
 }
 
+// Fused extension: arm the slab source for the NEXT decode-attention launch of this thread (any flavour; one shot).
+static thread_local QkvSlabSrc g_armed_qkv_slabs = {};
+static QkvSlabSrc take_armed_qkv_slabs() {
+  const QkvSlabSrc q = g_armed_qkv_slabs;
+  g_armed_qkv_slabs = QkvSlabSrc{};
+  return q;
+}
+extern "C" int omni_decode_arm_qkv_slabs(const void* slab_i32, int sk, int M, int N, int col_q, int col_k, int col_v,
+                                         const void* wscales_f16, const void* ascales_f16, const void* w_szs_f16,
+                                         const void* a_ssums_f16) {
+  g_armed_qkv_slabs = QkvSlabSrc{};
+  if (!slab_i32) return OMNI_OK;      // disarm
+  if (sk < 1 || M < 1 || N < 1 || col_q < 0 || col_k < 0 || col_v < 0 || !wscales_f16 || !ascales_f16 ||
+      ((w_szs_f16 == nullptr) != (a_ssums_f16 == nullptr)))
+    return OMNI_EINVAL;
+  QkvSlabSrc q{};
+  q.slab = (const int32_t*)slab_i32; q.sstride = (long long)M * N; q.sk = sk; q.n = N;
+  q.col_q = col_q; q.col_k = col_k; q.col_v = col_v;
+  q.wscales = (const half_t*)wscales_f16; q.wsz = (const half_t*)w_szs_f16;
+  q.ascales = (const half_t*)ascales_f16; q.asum = (const half_t*)a_ssums_f16;
+  g_armed_qkv_slabs = q;
+  return OMNI_OK;
+}
+
 static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride,
                          int64_t kv_stride, const void* kv_pointers_i64, const void* lengths_i32, int batch,
                          int max_blocks, int num_heads, int num_kv_heads, int head_dim, int tokens_per_block,
                          int max_context, const void* rope_cos_sin_f32, int rope_max_pos, void* workspace,
                          size_t workspace_bytes, void* stream, bool partials_only, int* nsplit_out) {
+  const QkvSlabSrc armed_qs = take_armed_qkv_slabs();     // (first: an early return must not leave it armed)
   if ((!out_f16 && !partials_only) || !q_f16 || !k_f16 || !v_f16 || !kv_pointers_i64 || !lengths_i32 ||
       !rope_cos_sin_f32 || !workspace)
     return OMNI_EINVAL;
@@ -1086,6 +1179,10 @@ static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, co
   a.part_o = a.part_ml + (size_t)batch * num_heads * pl.nsplit * 2;
   a.fg = FgArgs{};
   a.kv_qo = nullptr; a.kv_oq = nullptr;
+  a.qs = armed_qs;
+  if (a.qs.slab && (a.qs.sstride != (long long)batch * a.qs.n || a.qs.col_q + num_heads * DH > a.qs.n ||
+                    a.qs.col_k + num_kv_heads * DH > a.qs.n || a.qs.col_v + num_kv_heads * DH > a.qs.n))
+    return OMNI_EINVAL;
   dim3 grid(pl.nsplit, num_kv_heads * (group / pl.g), batch);
   hipStream_t st = (hipStream_t)stream;
   if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;
@@ -1153,6 +1250,7 @@ static int decode_fg_common(
     int sink_blocks, int local_blocks, int max_context, const void* rope_cos_sin_f32, int rope_max_pos,
     void* workspace, size_t workspace_bytes, void* stream, const float* kv_qo, const float* kv_oq,
     bool partials_only = false, int* nsplit_out = nullptr) {
+  const QkvSlabSrc armed_qs = take_armed_qkv_slabs();     // (first: an early return must not leave it armed)
   if ((!out_f16 && !partials_only) || !q_f16 || !k_f16 || !v_f16 || !lengths_i32 || !rope_cos_sin_f32 || !workspace)
     return OMNI_EINVAL;
   if (head_dim != DH || batch < 1 || num_heads < 1 || num_kv_heads < 1 || num_heads % num_kv_heads != 0 ||
@@ -1162,6 +1260,7 @@ static int decode_fg_common(
   const int group = num_heads / num_kv_heads;
   if (group != 1 && group != 2 && group % 4 != 0) return OMNI_EINVAL;
   DecodeArgs a;
+  a.qs = armed_qs;
   int rc = fill_fg(&a.fg, streaming_kv_pointers_i64, retrieval_head_flags_i32, head_rank_table_i32, streaming_blocks,
                    num_kv_heads, num_retrieval_kv_heads, num_streaming_kv_heads, sink_tokens, local_tokens,
                    sink_blocks, local_blocks);
@@ -1200,6 +1299,9 @@ static int decode_fg_common(
   dim3 grid(pl.nsplit, num_kv_heads * (group / pl.g), batch);
   hipStream_t st = (hipStream_t)stream;
   a.kv_qo = kv_qo; a.kv_oq = kv_oq;
+  if (a.qs.slab && (a.qs.sstride != (long long)batch * a.qs.n || a.qs.col_q + num_heads * DH > a.qs.n ||
+                    a.qs.col_k + num_kv_heads * DH > a.qs.n || a.qs.col_v + num_kv_heads * DH > a.qs.n))
+    return OMNI_EINVAL;
 #define OMNI_LAUNCH_FG(G_)                                                                              \
   do {                                                                                                  \
     if (kv_qo)                                                                                          \

@@ -169,6 +169,9 @@ class LServeDecodeRunner:
         # fused: o_proj / down_proj leave int32 split-K slabs; the next add+norm kernel applies the GEMM epilogue
         self.defer = self.fused and os.environ.get("OMNI_LSERVE_DEFER", "1") != "0"
         self.slab = torch.empty((16 << 20,), dtype=torch.uint8, device=device) if self.defer else None
+        # the qkv projection as slabs consumed by the attention kernel (fused_ext.decode_arm_qkv_slabs) on the steps
+        # without a selector refresh: no slab epilogue launch behind the (96, 2)-workgroup qkv GEMV
+        self.qkv_slabs = self.defer and os.environ.get("OMNI_QKV_SLABS", "1") != "0"
         # row-kernel-free decode layer (fused level 3): needs the deferred epilogue (slab consumers) and <= 16 rows
         self.rowfree = (self.defer and level >= 3 and B <= 16 and Hq % 4 == 0 and
                         os.environ.get("OMNI_LSERVE_ROWFREE", "1") != "0")
@@ -225,7 +228,12 @@ class LServeDecodeRunner:
                 fused_ext.add_rms_norm_general_fuse_sum(self.q_hidden, self.x, self.proj_buf, L["ln1"], sm, sc, c.eps)
             else:
                 layernorm_ops.rms_norm_general(self.q_hidden, self.x, L["ln1"], sc, c.eps, True)
-            L["qkv"].forward(self.q_hidden, sc, self.qkv_buf)
+            if self.qkv_slabs and not select:   # slabs only: the attention applies the projection's epilogue (the page
+                lin = L["qkv"]                  # selector of a refresh step reads fp16 q / k: regular GEMM there)
+                sk_q = fused_ext.gemm_partial_w8a8(self.q_hidden, lin.weight, self.slab)
+                fused_ext.decode_arm_qkv_slabs(self.slab, sk_q, B, lin.n, 0, Hq * d, (Hq + Hk) * d, lin.dequant_scale, sc)
+            else:
+                L["qkv"].forward(self.q_hidden, sc, self.qkv_buf)
             q = self.qkv_buf[:, : Hq * d].view(B, Hq, d)
             k = self.qkv_buf[:, Hq * d:(Hq + Hk) * d].view(B, Hk, d)
             v = self.qkv_buf[:, (Hq + Hk) * d:].view(B, Hk, d)

@@ -236,6 +236,7 @@ class DecodeRunner:
         self.act_scale2 = torch.empty((B,), dtype=f16, device=device)  # written by quant kernels
         self.act_sum2 = torch.empty((B,), dtype=f16, device=device)
         need = max(int(_lib.lib().omni_gemm_workspace_bytes(B, c.hidden, k)) for k in (hl * c.head_dim, il))
+        need = max(need, int(_lib.lib().omni_gemm_workspace_bytes(B, qkv_n, c.hidden)))     # (qkv slabs, see qkv_slabs)
         self.slab = torch.empty((max(need, 1 << 20),), dtype=torch.uint8, device=device)  # deferred split-K partial sums
         self.qkv_buf = torch.empty((B, qkv_n), dtype=f16, device=device)
         self.proj_buf = torch.empty((B, c.hidden), dtype=f16, device=device)
@@ -255,6 +256,12 @@ class DecodeRunner:
         self.pf_down = int(os.environ.get("OMNI_L3_PF_DOWN", "1"))
         # level 3 also in the LAST layer: its down projection's slabs are consumed by the model's final norm
         # (fused_ext.splitk_add_rms_norm) instead of GEMV epilogue + residual add + rms_norm (OMNI_L3_LAST=0: off, A/B)
+        # fused level >= 2: the qkv projection leaves int32 split-K slabs and the decode attention applies its epilogue in
+        # its first load trip (fused_ext.decode_arm_qkv_slabs): no slab epilogue launch between the two where the plan
+        # splits K (batch > 16: (96, 2) workgroups + a 4.9-us epilogue launch per layer).  "auto": on where it measured
+        # faster (batch > 16); OMNI_QKV_SLABS=0 / 1 forces it off / on (A/B)
+        qs = os.environ.get("OMNI_QKV_SLABS", "auto")
+        self.qkv_slabs = self.fused >= 2 and (batch > 16 if qs == "auto" else qs != "0")
         self.last_l3 = (self.fused >= 3 and self.tp_size == 1 and self.comm is None and
                         os.environ.get("OMNI_L3_LAST", "1") != "0")
         self.normed = torch.empty((B, c.hidden), dtype=f16, device=device)
@@ -367,7 +374,7 @@ class DecodeRunner:
         for li, L in enumerate(self.layers):
             qa_h, qa_i = self._q_hidden, self._q_inter
             l3 = self.fused >= 3 and (li < nl - 1 or self.last_l3)     # row-kernel-free MLP half in this layer
-            self._arm(L["qkv"])
+            self._arm(L["qkv"], deferred=self.qkv_slabs)
             if pending is not None:     # residual += down_proj(prev layer) [deferred epilogue], norm + quant
                 sk, lin = pending
                 self._consume(qa_h, sk, lin, sA, mA, L["ln1"], mB, sB)
@@ -380,7 +387,13 @@ class DecodeRunner:
                 layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln1"], mB, sB, c.eps, True)
             else:
                 layernorm_ops.rms_norm_general(qa_h, self.x, L["ln1"], sB, c.eps, True)
-            L["qkv"].forward(qa_h, sB, mB, self.qkv_buf)
+            if self.qkv_slabs:      # slabs only; the attention kernel reads q / k / v from them (qkv_buf: shapes only)
+                lin = L["qkv"]
+                fused_ext.decode_arm_qkv_slabs(self.slab, self._partial(qa_h, lin), B, lin.n, 0, hq * d, (hq + hk) * d,
+                                               lin.s1_scales, sB, lin.s1_szeros if per_chn else None,
+                                               mB if per_chn else None)
+            else:
+                L["qkv"].forward(qa_h, sB, mB, self.qkv_buf)
             q = self.qkv_buf[:, : hq * d].view(B, hq, d)
             k = self.qkv_buf[:, hq * d:(hq + hk) * d].view(B, hk, d)
             v = self.qkv_buf[:, (hq + hk) * d:].view(B, hk, d)

@@ -288,3 +288,83 @@ def test_gemm_partial_f16_w8a8(M, N, K, edge):
     assert np.array_equal(sc2.cpu().numpy().view(np.uint16), so.view(np.uint16))
     acc = slab2[:n].view(torch.int32).view(sk2, M, N).sum(dim=0).cpu().numpy()
     assert np.array_equal(acc, qo.astype(np.int32) @ w.astype(np.int32).T)
+
+
+# ---- q / k / v of the current token straight from the qkv projection's split-K slabs ---------------------------------------
+def _kv_pools(B, hist, Hk, rng):
+    from oracle import kv4
+    from tests.util import GpuPagedKV
+    D = 128
+    pages = (max(hist) + 64) // 64 + 1
+    n_pages = B * pages
+    kc, vc = kv4.PagedKV4(n_pages, Hk, D), kv4.PagedKV4(n_pages, Hk, D)
+    for c in (kc, vc):
+        c.pool[:] = rng.integers(0, 256, c.pool.shape, dtype=np.uint8)
+        for p in range(n_pages):
+            c.scales(p)[:] = (0.05 + 0.15 * rng.random((Hk, 64))).astype(np.float16)
+            c.zeros(p)[:] = (6.0 + 3.0 * rng.random((Hk, 64))).astype(np.float16)
+    kidx = rng.permutation(n_pages).reshape(B, pages)
+    vidx = rng.permutation(n_pages).reshape(B, pages)
+    return GpuPagedKV(kc, vc, kidx, vidx), GpuPagedKV(kc, vc, kidx, vidx)
+
+
+@pytest.mark.parametrize("flavour,hist,Hq,Hk,K", [("chn", [200, 17, 130, 1, 700], 32, 8, 4096), ("chn", [63, 64, 65], 8, 2, 512),
+                                                  ("grp", [1500, 1030], 32, 8, 4096), ("w8", [90, 33, 300], 4, 1, 2048)])
+def test_decode_attention_reads_qkv_from_the_projections_slabs(flavour, hist, Hq, Hk, K):
+    """qkv GEMM -> single_query_attention   ==   qkv partial GEMM (int32 slabs) -> decode_arm_qkv_slabs -> attention:
+    output and KV pages byte-identical; the fp16 q / k / v buffer is not read (filled with NaN)."""
+    import omniserve_backend.fused_attention_pure_dense as fa
+    from omniserve_amd.backend import fused_ext
+    D, BASE = 128, 500000.0
+    rng = np.random.default_rng(sum(hist) + Hq + K)
+    B = len(hist)
+    N = (Hq + 2 * Hk) * D
+    g1, g2 = _kv_pools(B, hist, Hk, rng)
+    lens = to_dev(np.asarray(hist, np.int32) + 1)
+    slab = torch.empty((64 << 20,), dtype=torch.uint8, device=dev())
+    qkv = torch.empty((B, N), dtype=torch.float16, device=dev())
+    if flavour == "chn":
+        import omniserve_backend.qgemm_w4a8_per_chn as gemm
+        u, z, s1 = w4a8.synth_per_channel(N, K, 3)
+        qw, s1h, szh = w4a8.pack_per_channel(u, z, s1)
+        a, sa, asum = oe.quant_per_token(_x(B, K, 5, 1.0), True)
+        qw_d, s1_d, sz_d, a_d, sa_d, as_d = map(to_dev, (qw, s1h, szh, a, sa, asum))
+        gemm.gemm_forward_cuda(a_d, qw_d, s1_d, sa_d, sz_d, as_d, qkv)
+        sk = fused_ext.gemm_partial_per_chn(a_d, qw_d, slab)
+        epi = (s1_d, sa_d, sz_d, as_d)
+    elif flavour == "grp":
+        import omniserve_backend.qgemm_w4a8_per_group as gemm
+        u, z, s2, s1 = w4a8.synth_per_group(N, K, seed=4)
+        qw, s1h, s2s, s2z = w4a8.pack_per_group(u, z, s2, s1)
+        a, sa, _ = oe.quant_per_token(_x(B, K, 5, 1.0), False)
+        qw_d, s1_d, s2s_d, s2z_d, a_d, sa_d = map(to_dev, (qw, s1h, s2s, s2z, a, sa))
+        gemm.gemm_forward_cuda(a_d, qw_d, s2z_d, s2s_d, s1_d, sa_d, qkv)
+        sk = fused_ext.gemm_partial_per_group(a_d, qw_d, s2z_d, s2s_d, slab)
+        epi = (s1_d, sa_d, None, None)
+    else:
+        import omniserve_backend.qgemm_w8a8 as gemm
+        w, sw = _w8(N, K, 6)
+        a, sa, _ = oe.quant_per_token(_x(B, K, 5, 1.0), False)
+        w_d, sw_d, a_d, sa_d = map(to_dev, (w, sw, a, sa))
+        gemm.w8a8_gemm_forward_cuda(a_d, w_d, sw_d, sa_d, qkv)
+        sk = fused_ext.gemm_partial_w8a8(a_d, w_d, slab)
+        epi = (sw_d, sa_d, None, None)
+    views = lambda t: (t[:, : Hq * D].view(B, Hq, D), t[:, Hq * D:(Hq + Hk) * D].view(B, Hk, D),  # noqa: E731
+                       t[:, (Hq + Hk) * D:].view(B, Hk, D))
+    T = max(hist) + 1
+    q, k, v = views(qkv)
+    want = fa.single_query_attention(q, k, v, g1.table, lens, None, 65536, 64, Hk * D // 2, T, D, BASE, True, True, True)
+    junk = torch.full((B, N), float("nan"), dtype=torch.float16, device=dev())
+    q2, k2, v2 = views(junk)
+    fused_ext.decode_arm_qkv_slabs(slab, sk, B, N, 0, Hq * D, (Hq + Hk) * D, *epi)
+    got = fa.single_query_attention(q2, k2, v2, g2.table, lens, None, 65536, 64, Hk * D // 2, T, D, BASE, True, True, True)
+    torch.cuda.synchronize()
+    assert sk >= 1
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    for x, y in zip(g1.pools(), g2.pools()):
+        assert np.array_equal(x, y)
+    # one shot: the next call reads its fp16 arguments again
+    g3, _ = _kv_pools(B, hist, Hk, np.random.default_rng(sum(hist) + Hq + K))
+    again = fa.single_query_attention(q, k, v, g3.table, lens, None, 65536, 64, Hk * D // 2, T, D, BASE, True, True, True)
+    torch.cuda.synchronize()
+    assert torch.equal(again.view(torch.int16), want.view(torch.int16))
