@@ -407,7 +407,7 @@ def tp_rank_leg(device, tp=8, batch=128, context=1024, steps=16, warmup=4):
     from omniserve_amd.runtime import DecodeRunner, LlamaConfig
     cfg = LlamaConfig.llama2_70b(-1)
     def run(tp_comm):
-        r = DecodeRunner(cfg, batch, context, steps + warmup + 4, device, seed=3, fused=1, tp_rank=0, tp_size=tp, tp_comm=tp_comm)
+        r = DecodeRunner(cfg, batch, context, steps + warmup + 4, device, seed=3, tp_rank=0, tp_size=tp, tp_comm=tp_comm)   # (level drops to 1 under TP; the attention-side fusions stay)
         for _ in range(warmup):
             r.step()
         torch.cuda.synchronize()

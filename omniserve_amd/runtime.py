@@ -149,6 +149,9 @@ class DecodeRunner:
         # leaves fp16 + row maxima, and o_proj / down_proj quantise their input on the fly (fused_ext.gemm_silu_*,
         # decode_attention_f16_amax, gemm_partial_f16_*): 7 kernels per layer instead of 9, same bits.
         self.fused = 3 if fused is True else int(fused)
+        # the attention-side fusions of level 2 (split merge inside the quantiser, q / k / v from the qkv projection's slabs)
+        # involve no row-parallel projection, so they also apply under tensor parallelism, where the level drops to 1
+        self.l2_attn = self.fused >= 2 and batch <= 128 and os.environ.get("OMNI_TP_L2_ATTN", "1") != "0"
         if (self.tp_size > 1 or batch > 128) and self.fused > 1:
             # tensor parallel: the all-reduce needs the fp16 projection; batch > 128: the projections run through the
             # prefill tile, which has no slab-only form -- no deferred epilogue in either case
@@ -261,7 +264,7 @@ class DecodeRunner:
         # splits K (batch > 16: (96, 2) workgroups + a 4.9-us epilogue launch per layer).  "auto": on where it measured
         # faster (batch > 16); OMNI_QKV_SLABS=0 / 1 forces it off / on (A/B)
         qs = os.environ.get("OMNI_QKV_SLABS", "auto")
-        self.qkv_slabs = self.fused >= 2 and (batch > 16 if qs == "auto" else qs != "0")
+        self.qkv_slabs = (self.fused >= 2 or self.l2_attn) and (batch > 16 if qs == "auto" else qs != "0")
         self.last_l3 = (self.fused >= 3 and self.tp_size == 1 and self.comm is None and
                         os.environ.get("OMNI_L3_LAST", "1") != "0")
         self.normed = torch.empty((B, c.hidden), dtype=f16, device=device)
@@ -401,7 +404,7 @@ class DecodeRunner:
             if self.fused >= 3:     # merge as a wide kernel (fp16 + row maxima); o_proj quantises on the fly
                 fused_ext.decode_attention_f16_amax(self.attn_f16, self.amax[li, 0], q, k, v, self.block_tables[li],
                                                     self.lengths, self.tpb, self.max_context, c.rope_theta)
-            elif self.fused >= 2:   # attention with its split merge fused into the activation quant
+            elif self.fused >= 2 or self.l2_attn:   # attention with its split merge fused into the activation quant
                 fused_ext.decode_attention_quant_fuse_sum(self._q_attn, q, k, v, self.block_tables[li], self.lengths,
                                                           self.tpb, self.max_context, c.rope_theta, mA, sA)
             else:

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _run_rank(rank, world, port, group_size, steps, ret, tp_comm=None, graph=False):
+def _run_rank(rank, world, port, group_size, steps, ret, tp_comm=None, graph=False, fused=1):
     import torch.distributed as dist
     from omniserve_amd.runtime import DecodeRunner, LlamaConfig
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -32,8 +32,9 @@ def _run_rank(rank, world, port, group_size, steps, ret, tp_comm=None, graph=Fal
     try:
         cfg = LlamaConfig.tiny()
         cfg.group_size = group_size
-        r = DecodeRunner(cfg, BATCH, 0, steps + 2, torch.device("cuda:0"), seed=5, use_graph=graph, fused=1,
+        r = DecodeRunner(cfg, BATCH, 0, steps + 2, torch.device("cuda:0"), seed=5, use_graph=graph, fused=fused,
                          tp_rank=rank, tp_size=world, shard_full=True, tp_comm=tp_comm)
+        assert r.fused <= 1 or world == 1     # the level of the row-parallel projections drops to 1 under TP
         for _ in range(steps):
             r.step()
         torch.cuda.synchronize()
@@ -261,3 +262,22 @@ def test_tp2_peer_comm_matches_the_collective_path_bitwise(group_size, graph):
 
 def _run_rank_peer(rank, world, port, group_size, steps, graph, ret):
     _run_rank(rank, world, port, group_size, steps, ret, tp_comm="peer", graph=graph)
+
+
+def _run_rank_l2_attn(rank, world, port, group_size, steps, graph, ret):
+    os.environ["OMNI_QKV_SLABS"] = "1"       # (batch 4: "auto" would leave the slab form of the qkv projection off)
+    _run_rank(rank, world, port, group_size, steps, ret, tp_comm="peer", graph=graph, fused=True)
+
+
+@pytest.mark.parametrize("group_size,graph", [(-1, False), (128, True)])
+def test_tp2_attention_side_fusions_match_level_1_bitwise(group_size, graph):
+    """Under TP the level of the row-parallel projections is 1, but the attention-side fusions of level 2 stay (split merge
+    inside the quantiser, q / k / v read from the column-parallel qkv projection's slabs): hidden states and tokens
+    bit-identical to the plain level-1 TP run, on both ranks."""
+    steps = 3
+    ref = _spawn2(_run_rank, (group_size, steps))
+    got = _spawn2(_run_rank_l2_attn, (group_size, steps, graph))
+    for rk in range(2):
+        xr, tr = ref[(2, rk)]
+        xg, tg = got[(2, rk)]
+        assert np.array_equal(xr, xg) and np.array_equal(tr, tg), "rank %d: attention-side fusions differ" % rk

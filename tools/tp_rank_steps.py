@@ -10,7 +10,7 @@ from omniserve_amd.runtime import DecodeRunner, LlamaConfig  # noqa: E402
 
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 dev = torch.device("cuda:0")
-r = DecodeRunner(LlamaConfig.llama2_70b(-1), bs, 1024, 40, dev, seed=3, fused=1, tp_rank=0, tp_size=8)
+r = DecodeRunner(LlamaConfig.llama2_70b(-1), bs, 1024, 40, dev, seed=3, fused=int(os.environ.get("OMNI_FUSED", "3")), tp_rank=0, tp_size=8)
 for _ in range(4):
     r.step()
 torch.cuda.synchronize()
