@@ -200,6 +200,13 @@ class LServeDecodeRunner:
 
     # one decode step; `select` = this step refreshes the page selection (every `interval`-th step upstream)
     def _eager_step(self, hist: int, select: bool):
+        try:
+            self._eager_step_body(hist, select)
+        finally:
+            if self.qkv_slabs:      # a step that raised between arming and the attention launch must not leave the
+                fused_ext.decode_arm_qkv_slabs(None, 0, 0, 0, 0, 0, 0, None, None)   # one-shot descriptor armed
+
+    def _eager_step_body(self, hist: int, select: bool):
         """hist = upper bound of the history length of this step's page bucket (the kernels take the true lengths from
         `self.lengths`; `hist` only sizes RoPE tables, split plans and the selector's padded output)."""
         c, B = self.cfg, self.B

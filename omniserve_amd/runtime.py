@@ -355,6 +355,8 @@ class DecodeRunner:
             fused_ext.set_weight_policy(0)
             if self.prefetch_bytes > 0:
                 fused_ext.prefetch_disarm()     # a step that raised may leave a descriptor armed
+            if self.qkv_slabs:
+                fused_ext.decode_arm_qkv_slabs(None, 0, 0, 0, 0, 0, 0, None, None)     # ... and the q / k / v slab source
 
     def _eager_step_body(self):
         # one decoder layer at decode shape = llama_w4a8_unpad.py:406-438
