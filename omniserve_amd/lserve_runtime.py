@@ -72,9 +72,12 @@ class LServeDecodeRunner:
         level = 3 if fused is True else int(fused)
         # L2 weight prefetch riding on the row kernels (see omniserve_amd/runtime.py; a hint, results unaffected)
         import os
+        prefetch_default = prefetch_mb is None
         if prefetch_mb is None:
-            # off by default here: at batch 1 with W8A8 weights it measured 4-5 % SLOWER (profiles/r02_*)
-            prefetch_mb = float(os.environ.get("OMNI_LSERVE_PREFETCH_MB", "0")) if self.fused else 0.0
+            # round 2 (quantiser row kernels as carriers): 4-5 % SLOWER at batch 1 with W8A8 weights, so it was off; with the
+            # row-kernel-free layer (norms and the wide merge as the carriers) 24-64 MiB measure 1.5-2 % FASTER per step
+            # (3.11-3.13 -> 3.05-3.07 ms, tools/r03_call60/61.sh); 8-16 MiB are neutral
+            prefetch_mb = float(os.environ.get("OMNI_LSERVE_PREFETCH_MB", "32")) if self.fused else 0.0
         self.prefetch_bytes = int(float(prefetch_mb) * (1 << 20)) if self.fused else 0
         if kv_format not in ("kv8", "kv4"):
             raise ValueError("kv_format must be 'kv8' (per_tensor) or 'kv4' (fine_grained)")
@@ -175,6 +178,8 @@ class LServeDecodeRunner:
         # row-kernel-free decode layer (fused level 3): needs the deferred epilogue (slab consumers) and <= 16 rows
         self.rowfree = (self.defer and level >= 3 and B <= 16 and Hq % 4 == 0 and
                         os.environ.get("OMNI_LSERVE_ROWFREE", "1") != "0")
+        if prefetch_default and not self.rowfree and "OMNI_LSERVE_PREFETCH_MB" not in os.environ:
+            self.prefetch_bytes = 0     # (with the quantiser row kernels as carriers the prefetch measured slower)
         if self.rowfree:
             self.attn_f16 = torch.empty((B, Hq * d), dtype=f16, device=device)
             self.amax = torch.zeros((c.layers, 2, fused_ext.AMAX_WORDS), dtype=torch.int32, device=device)
@@ -296,6 +301,7 @@ class LServeDecodeRunner:
                 L["o"].forward(self.q_attn, sq, self.proj_buf)
             if not (rowfree and li < nl - 1):     # (the SiLU-epilogue form pairs gate / up rows: no prefetch descriptor)
                 self._arm(L["gate_up"])
+            # (letting that norm carry the head of down_proj's 58.7 MB instead measured slower: 3.09 -> 3.21 ms per step)
             if self.defer:
                 fused_ext.splitk_w8_add_rms_norm_general_fuse_sum(self.q_hidden, self.x, self.slab, sk,
                                                                   L["o"].dequant_scale, sq, L["ln2"], sm, sc, c.eps)

@@ -167,7 +167,11 @@ class DecodeRunner:
         if prefetch_mb is None:
             # measured (profiles/r02_*): +6-7 % at bs = 16 with 28-40 MiB per row kernel (the L2s hold 32 MiB; the
             # excess lands in MALL), nothing at bs = 128, -4 % at bs = 64 where the row kernels are no longer idle
-            prefetch_mb = float(os.environ.get("OMNI_PREFETCH_MB", "40" if batch <= 32 else "0")) if self.fused else 0.0
+            # (batch 33..64: 12 MiB per carrier measured best at configs[2] -- 3.50 -> 3.43 ms per step, 24 MiB and more lose.
+            #  A tensor-parallel shard's projections are small enough to be fetched whole: one Llama-2-70B TP = 8 rank at
+            #  bs = 128 7.22-7.26 -> 6.59-6.65 ms per step with 12 .. 48 MiB.  Other batches > 64: not measured, off)
+            dflt = "40" if batch <= 32 else ("12" if batch <= 64 else ("24" if self.tp_size > 1 else "0"))
+            prefetch_mb = float(os.environ.get("OMNI_PREFETCH_MB", dflt)) if self.fused else 0.0
         self.prefetch_bytes = int(float(prefetch_mb) * (1 << 20)) if self.fused else 0
         self.prefetch_blocks = int(os.environ.get("OMNI_PREFETCH_BLOCKS", prefetch_blocks))
         if weight_policy is None:
