@@ -79,6 +79,7 @@ class LServeDecodeRunner:
             # (3.11-3.13 -> 3.05-3.07 ms, tools/r03_call60/61.sh); 8-16 MiB are neutral
             prefetch_mb = float(os.environ.get("OMNI_LSERVE_PREFETCH_MB", "32")) if self.fused else 0.0
         self.prefetch_bytes = int(float(prefetch_mb) * (1 << 20)) if self.fused else 0
+        self.prefetch_blocks = int(os.environ.get("OMNI_PREFETCH_BLOCKS", "160"))
         if kv_format not in ("kv8", "kv4"):
             raise ValueError("kv_format must be 'kv8' (per_tensor) or 'kv4' (fine_grained)")
         self.kv8 = kv_format == "kv8"
@@ -201,7 +202,8 @@ class LServeDecodeRunner:
 
     def _arm(self, lin, deferred=False):
         if self.prefetch_bytes > 0:
-            fused_ext.prefetch_arm_gemm(lin.weight, self.B, lin.n, lin.k, 2, deferred, self.prefetch_bytes, 240)
+            fused_ext.prefetch_arm_gemm(lin.weight, self.B, lin.n, lin.k, 2, deferred, self.prefetch_bytes,
+                                        self.prefetch_blocks)
 
     # one decode step; `select` = this step refreshes the page selection (every `interval`-th step upstream)
     def _eager_step(self, hist: int, select: bool):

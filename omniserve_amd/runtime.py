@@ -120,7 +120,7 @@ class DecodeRunner:
 
     def __init__(self, cfg: LlamaConfig, batch: int, context: int, max_new: int, device, seed=0,
                  use_graph=True, fused=True, tp_rank=0, tp_size=1, tp_group=None, shard_full=False,
-                 prefetch_mb=None, prefetch_blocks=240, weight_policy=None, tp_comm=None):
+                 prefetch_mb=None, prefetch_blocks=160, weight_policy=None, tp_comm=None):
         """tp_size > 1: Megatron-style tensor parallelism (omniserve_amd/tp.py): qkv / gate_up column-parallel,
         o / down row-parallel, attention by kv head, one fp16 sum all-reduce of the [B, hidden] projection after
         o_proj and after down_proj.  shard_full=True builds the full layers from the seed and keeps this
@@ -173,6 +173,8 @@ class DecodeRunner:
             dflt = "40" if batch <= 32 else ("12" if batch <= 64 else ("24" if self.tp_size > 1 else "0"))
             prefetch_mb = float(os.environ.get("OMNI_PREFETCH_MB", dflt)) if self.fused else 0.0
         self.prefetch_bytes = int(float(prefetch_mb) * (1 << 20)) if self.fused else 0
+        # (fetching workgroups per carrier: 240 was round 2's optimum; with down_proj's 29.6 MB on the norm in front of gate_up
+        #  128-192 measure 1.7 % faster per step at bs = 16 -- 2.28 -> 2.24 ms --, 64-96 slower; bs = 64 / TP / LServe: flat)
         self.prefetch_blocks = int(os.environ.get("OMNI_PREFETCH_BLOCKS", prefetch_blocks))
         if weight_policy is None:
             weight_policy = int(os.environ.get("OMNI_WEIGHT_POLICY", "1"))
