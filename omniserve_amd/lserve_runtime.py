@@ -80,6 +80,8 @@ class LServeDecodeRunner:
             prefetch_mb = float(os.environ.get("OMNI_LSERVE_PREFETCH_MB", "32")) if self.fused else 0.0
         self.prefetch_bytes = int(float(prefetch_mb) * (1 << 20)) if self.fused else 0
         self.prefetch_blocks = int(os.environ.get("OMNI_PREFETCH_BLOCKS", "160"))
+        # (the wide merge as a carrier for o_proj's 16.8 MB costs it 2.8 us where o_proj gains 1.1: 3.07 -> 3.05 ms without)
+        self.arm_o = os.environ.get("OMNI_LSERVE_ARM_O", "0") != "0"
         if kv_format not in ("kv8", "kv4"):
             raise ValueError("kv_format must be 'kv8' (per_tensor) or 'kv4' (fine_grained)")
         self.kv8 = kv_format == "kv8"
@@ -272,7 +274,8 @@ class LServeDecodeRunner:
                       self.ns, hist + 1, d, c.rope_theta, 1.0, True, not self.kv8, not self.kv8, self.sub, self.nr * d,
                       2048)
             if rowfree:         # merge as a wide kernel (fp16 + row maxima); o_proj quantises on the fly
-                self._arm(L["o"], True)
+                if self.arm_o:
+                    self._arm(L["o"], True)
                 fused_ext.sparse_decode_attention_f16_amax(
                     self.attn_f16, self.amax[li, 0], q, k, v, self.retr_tables[li], self.strm_tables[li], self.flags,
                     self.rank, self.page_idx[li], self.lengths, self.tpb, size_r, size_s, self.sink, self.local,

@@ -271,6 +271,7 @@ class DecodeRunner:
         # faster (batch > 16); OMNI_QKV_SLABS=0 / 1 forces it off / on (A/B)
         qs = os.environ.get("OMNI_QKV_SLABS", "auto")
         self.qkv_slabs = (self.fused >= 2 or self.l2_attn) and (batch > 16 if qs == "auto" else qs != "0")
+        self.arm_o = os.environ.get("OMNI_ARM_O", "1") != "0"      # (A/B: o_proj's weights prefetched by the kernel behind the attention)
         self.last_l3 = (self.fused >= 3 and self.tp_size == 1 and self.comm is None and
                         os.environ.get("OMNI_L3_LAST", "1") != "0")
         self.normed = torch.empty((B, c.hidden), dtype=f16, device=device)
@@ -408,7 +409,8 @@ class DecodeRunner:
             q = self.qkv_buf[:, : hq * d].view(B, hq, d)
             k = self.qkv_buf[:, hq * d:(hq + hk) * d].view(B, hk, d)
             v = self.qkv_buf[:, (hq + hk) * d:].view(B, hk, d)
-            self._arm(L["o"], deferred=self.fused >= 2)      # rides on the quantiser after the attention
+            if self.arm_o:
+                self._arm(L["o"], deferred=self.fused >= 2)      # rides on the quantiser after the attention
             if self.fused >= 3:     # merge as a wide kernel (fp16 + row maxima); o_proj quantises on the fly
                 fused_ext.decode_attention_f16_amax(self.attn_f16, self.amax[li, 0], q, k, v, self.block_tables[li],
                                                     self.lengths, self.tpb, self.max_context, c.rope_theta)
