@@ -271,6 +271,7 @@ class DecodeRunner:
         # faster (batch > 16); OMNI_QKV_SLABS=0 / 1 forces it off / on (A/B)
         qs = os.environ.get("OMNI_QKV_SLABS", "auto")
         self.qkv_slabs = (self.fused >= 2 or self.l2_attn) and (batch > 16 if qs == "auto" else qs != "0")
+        self.arm_qkv = os.environ.get("OMNI_ARM_QKV", "1") != "0"
         self.arm_o = os.environ.get("OMNI_ARM_O", "1") != "0"      # (A/B: o_proj's weights prefetched by the kernel behind the attention)
         self.last_l3 = (self.fused >= 3 and self.tp_size == 1 and self.comm is None and
                         os.environ.get("OMNI_L3_LAST", "1") != "0")
@@ -386,7 +387,8 @@ class DecodeRunner:
         for li, L in enumerate(self.layers):
             qa_h, qa_i = self._q_hidden, self._q_inter
             l3 = self.fused >= 3 and (li < nl - 1 or self.last_l3)     # row-kernel-free MLP half in this layer
-            self._arm(L["qkv"], deferred=self.qkv_slabs)
+            if self.arm_qkv:
+                self._arm(L["qkv"], deferred=self.qkv_slabs)
             if pending is not None:     # residual += down_proj(prev layer) [deferred epilogue], norm + quant
                 sk, lin = pending
                 self._consume(qa_h, sk, lin, sA, mA, L["ln1"], mB, sB)
