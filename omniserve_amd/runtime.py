@@ -270,7 +270,15 @@ class DecodeRunner:
         # splits K (batch > 16: (96, 2) workgroups + a 4.9-us epilogue launch per layer).  "auto": on where it measured
         # faster (batch > 16); OMNI_QKV_SLABS=0 / 1 forces it off / on (A/B)
         qs = os.environ.get("OMNI_QKV_SLABS", "auto")
-        self.qkv_slabs = (self.fused >= 2 or self.l2_attn) and (batch > 16 if qs == "auto" else qs != "0")
+        if qs == "auto":      # on exactly where the plain qkv GEMV would split K and launch a slab epilogue
+            import ctypes
+            sk_q = ctypes.c_int(1)
+            _lib.lib().omni_gemm_get_plan(batch, qkv_n, c.hidden, 128 if c.group_size == 128 else 64, None, None,
+                                          ctypes.byref(sk_q))
+            want = sk_q.value > 1
+        else:
+            want = qs != "0"
+        self.qkv_slabs = (self.fused >= 2 or self.l2_attn) and want
         self.arm_qkv = os.environ.get("OMNI_ARM_QKV", "1") != "0"
         self.arm_o = os.environ.get("OMNI_ARM_O", "1") != "0"      # (A/B: o_proj's weights prefetched by the kernel behind the attention)
         self.last_l3 = (self.fused >= 3 and self.tp_size == 1 and self.comm is None and
