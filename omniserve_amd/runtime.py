@@ -263,12 +263,11 @@ class DecodeRunner:
         # prefetched lines) and down reads L2: 2.322-2.334 -> 2.294-2.314 ms per step on the same box (profiles/r03_g;
         # OMNI_L3_PF_DOWN=0: round 3's first arrangement, 2: gate_up with plain loads -- slower, 2.35)
         self.pf_down = int(os.environ.get("OMNI_L3_PF_DOWN", "1"))
-        # level 3 also in the LAST layer: its down projection's slabs are consumed by the model's final norm
-        # (fused_ext.splitk_add_rms_norm) instead of GEMV epilogue + residual add + rms_norm (OMNI_L3_LAST=0: off, A/B)
         # fused level >= 2: the qkv projection leaves int32 split-K slabs and the decode attention applies its epilogue in
-        # its first load trip (fused_ext.decode_arm_qkv_slabs): no slab epilogue launch between the two where the plan
-        # splits K (batch > 16: (96, 2) workgroups + a 4.9-us epilogue launch per layer).  "auto": on where it measured
-        # faster (batch > 16); OMNI_QKV_SLABS=0 / 1 forces it off / on (A/B)
+        # its first load trip (fused_ext.decode_arm_qkv_slabs): no slab epilogue launch between the two.  "auto": on exactly
+        # where the plain qkv GEMV's plan splits K (bs = 64: (96, 2) workgroups + a 4.9-us epilogue launch per layer; 3.51 ->
+        # 3.47 ms per step); at bs = 16 the plan has no split and the slab form measured 1.5 % slower.  OMNI_QKV_SLABS=0 / 1
+        # forces it off / on (A/B)
         qs = os.environ.get("OMNI_QKV_SLABS", "auto")
         if qs == "auto":      # on exactly where the plain qkv GEMV would split K and launch a slab epilogue
             import ctypes
@@ -279,8 +278,11 @@ class DecodeRunner:
         else:
             want = qs != "0"
         self.qkv_slabs = (self.fused >= 2 or self.l2_attn) and want
+        # (A/B knobs: qkv's / o_proj's weights prefetched by the norm in front of qkv / the kernel behind the attention)
         self.arm_qkv = os.environ.get("OMNI_ARM_QKV", "1") != "0"
-        self.arm_o = os.environ.get("OMNI_ARM_O", "1") != "0"      # (A/B: o_proj's weights prefetched by the kernel behind the attention)
+        self.arm_o = os.environ.get("OMNI_ARM_O", "1") != "0"
+        # level 3 also in the LAST layer: its down projection's slabs are consumed by the model's final norm
+        # (fused_ext.splitk_add_rms_norm) instead of GEMV epilogue + residual add + rms_norm (OMNI_L3_LAST=0: off, A/B)
         self.last_l3 = (self.fused >= 3 and self.tp_size == 1 and self.comm is None and
                         os.environ.get("OMNI_L3_LAST", "1") != "0")
         self.normed = torch.empty((B, c.hidden), dtype=f16, device=device)
