@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void select_topk_pages_kernel(const half_t* __
   extern __shared__ uint32_t keys[];
   __shared__ uint32_t hist[4 * 256];
   __shared__ uint32_t surv[TOPK_MAX_K];
-  __shared__ uint32_t s_prefix, s_remaining, s_count;
+  __shared__ uint32_t s_prefix, s_remaining, s_count, s_done;
   const int n = total_pages - 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const half_t* sc = scores + (size_t)blockIdx.x * head_stride;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void select_topk_pages_kernel(const half_t* __
       keys[p] = make_key(m, p);
     }
   }
-  if (tid == 0) { s_prefix = 0; s_remaining = (uint32_t)k; s_count = 0; }
+  if (tid == 0) { s_prefix = 0; s_remaining = (uint32_t)k; s_count = 0; s_done = 0; }
   __syncthreads();
   // radix select, most significant byte first: after pass b the k-th largest key starts with s_prefix (b+1 bytes).
   // One histogram per wave (less contention on the few exponent bins), scanned from the top by one wave.
@@ -255,9 +255,13 @@ __global__ __launch_bounds__(256) void select_topk_pages_kernel(const half_t* __
         }
         s_prefix = prefix | ((uint32_t)(255 - 4 * lane - j) << shift);
         s_remaining = rem - before;
+        // after the second pass the 16 score bits of the k-th key are known: when EVERY key with that score is taken (the
+        // usual case: scores differ) the page bits need no passes -- all keys >= (score << 16) are exactly the k wanted
+        if (pass == 1 && rem - before == c[j]) s_done = 1;
       }
     }
     __syncthreads();
+    if (s_done) break;      // (workgroup-uniform; s_prefix then has zero page bits)
   }
   const uint32_t kth = s_prefix;      // keys are unique: exactly k keys are >= kth
   for (int p0 = tid; p0 < n; p0 += 256 * 8) {
