@@ -98,3 +98,28 @@ def test_ops_fail_loudly_without_device_tensors():
     x = torch.zeros(2, 128, dtype=torch.float16)
     with pytest.raises(RuntimeError):
         fk.invoke_quant(torch.zeros(2, 128, dtype=torch.int8), x, torch.zeros(2, dtype=torch.float16))
+
+
+def test_gemm_plans_of_the_baseline_decode_shapes():
+    """Host-side planner (no GPU): the plans the decode drivers rely on.  The slab form of the qkv projection
+    (fused_ext.decode_arm_qkv_slabs) is taken exactly where the plain qkv GEMV's plan splits K -- not at bs = 16 (one kernel,
+    no epilogue launch), at bs = 64 and on a Llama-2-70B TP = 8 shard at bs = 128; and the workspace bound covers the
+    deferred (slab-only) plans of every projection."""
+    import ctypes
+    from omniserve_amd import _lib
+    lib = _lib.lib()
+
+    def plan(M, N, K, kalign):
+        mb, waves, sk = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        lib.omni_gemm_get_plan(M, N, K, kalign, ctypes.byref(mb), ctypes.byref(waves), ctypes.byref(sk))
+        return mb.value, waves.value, sk.value
+
+    assert plan(16, 6144, 4096, 64) == (1, 1, 1)            # Llama-3-8B qkv at bs = 16: 96 single-wave tiles, no split
+    assert plan(16, 28672, 4096, 64)[2] == 1                # gate_up: one kernel (the SiLU-epilogue form needs that)
+    mb, _, sk = plan(64, 6144, 4096, 128)                   # configs[2]: 64-row tiles, K split -> slab epilogue / slab form
+    assert mb == 4 and sk > 1
+    assert plan(128, 1280, 8192, 64)[2] > 1                 # 70B TP = 8 shard's qkv at bs = 128
+    assert plan(4096, 4096, 4096, 64) == (8, 4, 1)          # prefill regime: 128 x 256 tiles, no split
+    for (M, N, K) in ((16, 4096, 14336), (64, 4096, 14336), (128, 8192, 3584), (1, 6144, 4096), (16, 6144, 4096)):
+        assert lib.omni_gemm_workspace_bytes(M, N, K) >= M * N * 4
+    assert lib.omni_gemm_workspace_bytes(4096, 4096, 4096) == 0
