@@ -41,6 +41,11 @@ size_t omni_gemm_workspace_bytes(int M, int N, int K);
  * heuristic; query the plan the library would use. */
 void omni_gemm_set_plan_override(int waves, int sk);
 void omni_gemm_get_plan(int M, int N, int K, int kalign, int* mb, int* waves, int* sk);
+/* 1 when the row-kernel-free decode forms below (omni_*_gemm_silu for gate_up [2*inter, hidden], omni_*_gemm_partial_f16
+ * for o [hidden, attn_dim] and down [hidden, inter]) accept a layer of these dimensions at M rows, 0 otherwise: the plan
+ * conditions those entry points check at launch, for a driver that picks its fusion level up front.
+ * mode: 0 per-channel W4A8, 1 per-group W4A8, 2 W8A8.  (Nothing upstream: fused extension) */
+int omni_gemm_rowfree_ok(int M, int hidden, int attn_dim, int inter, int mode);
 
 /* Replaces omniserve_backend.qgemm_w4a8_per_chn.gemm_forward_cuda
  *   (kernels/csrc/qgemm/w4a8_per_chn/gemm_cuda.cu:601-657, kernel :308-599).

@@ -26,6 +26,7 @@ PROTOTYPES = {
     "omni_gemm_set_weight_policy": (None, [_i]),
     "omni_prefetch_arm_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i64, _i]),
     "omni_gemm_get_plan": (None, [_i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
+    "omni_gemm_rowfree_ok": (_i, [_i, _i, _i, _i, _i]),
     "omni_w4a8_per_chn_gemm": (_i, [_vp] * 7 + [_i, _i, _i, _i64, _vp, _sz, _vp]),
     "omni_w4a8_per_group_gemm": (_i, [_vp] * 7 + [_i, _i, _i, _i64, _vp, _sz, _vp]),
     "omni_w8a8_gemm": (_i, [_vp] * 5 + [_i, _i, _i, _i64, _vp, _sz, _vp]),

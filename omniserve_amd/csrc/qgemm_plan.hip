@@ -136,6 +136,29 @@ extern "C" void omni_gemm_get_plan(int M, int N, int K, int kalign, int* mb, int
   if (sk) *sk = pl.sk;
 }
 
+// Would the row-kernel-free decode forms (omni_*_gemm_silu for gate_up, omni_*_gemm_partial_f16 for o / down) accept a layer
+// with these dimensions?  The same plan conditions launch_gemm_silu / launch_gemm_partial_f16 check at launch (one place to
+// keep in step: qgemm_kernel.h), so that a driver can choose its fusion level BEFORE its first step instead of running into
+// EINVAL there (hidden > 4096: the gate_up plan splits K across workgroups; rows > N / 64: no rider per row).
+// mode: 0 per-channel W4A8 (row sums needed), 1 per-group W4A8, 2 W8A8.
+extern "C" int omni_gemm_rowfree_ok(int M, int hidden, int attn_dim, int inter, int mode) {
+  using namespace omni;
+  if (mode < 0 || mode > 2 || M < 1 || M > 16 || hidden < 64 || attn_dim < 64 || inter < 64) return 0;
+  const int kalign = mode == MODE_GRP ? 128 : 64;
+  const bool w8 = mode == MODE_W8;
+  if (hidden % 64 || attn_dim % kalign || inter % kalign || (2 * inter) % 128 || hidden % kalign) return 0;
+  const GemmPlan gu = plan_gemm(M, 2 * inter, hidden, kalign, false, w8);
+  if (gu.sk != 1 || gu.mb != 1) return 0;
+  const int ar = w8 ? GemvCfg<1, MODE_W8>::AR : GemvCfg<1, MODE_CHN>::AR;
+  for (const int K : {attn_dim, inter}) {
+    if (hidden / 64 < M) return 0;
+    const GemmPlan pl = plan_gemm(M, hidden, K, kalign, true, w8);
+    if (pl.mb != 1 || pl.kw < 2) return 0;
+    if (mode == MODE_CHN && (size_t)K * sizeof(float) > (size_t)pl.kw * 2 * 16 * ar * KSTEP) return 0;   // rider's LDS row
+  }
+  return 1;
+}
+
 extern "C" size_t omni_gemm_workspace_bytes(int M, int N, int K) {
   if (M < 1 || N < 64 || K < 64 || M > 128) return 0;   // M > 128: no split, no scratch
   // sized from the very plans the launches use: the maximum over the K alignments of the three GEMM flavours

@@ -26,6 +26,7 @@ from .backend import (activation_ops, fused_attention_ctx_pool, fused_attention_
                       prefill_attn, qgemm_w8a8)
 from .rope import rope_table
 from .runtime import LlamaConfig
+from . import _lib
 
 
 def head_rank_table(retrieval_head_flags):
@@ -179,8 +180,10 @@ class LServeDecodeRunner:
         # without a selector refresh: no slab epilogue launch behind the (96, 2)-workgroup qkv GEMV
         self.qkv_slabs = self.defer and os.environ.get("OMNI_QKV_SLABS", "1") != "0"
         # row-kernel-free decode layer (fused level 3): needs the deferred epilogue (slab consumers) and <= 16 rows
+        # (and plans its entry points accept: omni_gemm_rowfree_ok, W8A8 form)
         self.rowfree = (self.defer and level >= 3 and B <= 16 and Hq % 4 == 0 and
-                        os.environ.get("OMNI_LSERVE_ROWFREE", "1") != "0")
+                        os.environ.get("OMNI_LSERVE_ROWFREE", "1") != "0" and
+                        _lib.lib().omni_gemm_rowfree_ok(B, c.hidden, Hq * d, c.inter, 2) == 1)
         if prefetch_default and not self.rowfree and "OMNI_LSERVE_PREFETCH_MB" not in os.environ:
             self.prefetch_bytes = 0     # (with the quantiser row kernels as carriers the prefetch measured slower)
         if self.rowfree:

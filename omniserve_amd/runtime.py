@@ -156,9 +156,13 @@ class DecodeRunner:
             # tensor parallel: the all-reduce needs the fp16 projection; batch > 128: the projections run through the
             # prefill tile, which has no slab-only form -- no deferred epilogue in either case
             self.fused = 1
-        if self.fused >= 3 and not (batch <= 16 and max(cfg.heads * cfg.head_dim, cfg.inter) <= 16384 and
-                                    cfg.hidden // 64 >= batch and cfg.heads % 4 == 0 and
-                                    int(os.environ.get("OMNI_FUSED_MAX", "3")) >= 3):
+        # level 3 wants the plans its entry points accept (omni_gemm_rowfree_ok: the launchers' own conditions -- gate_up
+        # without a grid-level K split, i.e. hidden <= 4096; one rider workgroup per row in a grid row of hidden / 64; the
+        # rider's LDS copy of a row) and the wide attention merge's 4 heads per wave; otherwise level 2, which has no such
+        # limits (a hidden = 5120 layer used to pass the old size test here and fail in its first step)
+        if self.fused >= 3 and not (self.hl % 4 == 0 and int(os.environ.get("OMNI_FUSED_MAX", "3")) >= 3 and
+                                    _lib.lib().omni_gemm_rowfree_ok(batch, cfg.hidden, self.hl * cfg.head_dim, self.il,
+                                                                    0 if cfg.group_size == -1 else 1) == 1):
             self.fused = 2
         # L2 weight prefetch riding on the row kernels (fused extension; a hint, results are unaffected): MiB of the
         # next GEMV's weights each row kernel pulls into the L2s (0 = off), with how many extra workgroups, and

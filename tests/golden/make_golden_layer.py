@@ -33,10 +33,15 @@ HIDDEN, INTER, HQ, HK, D, TPB = 256, 512, 2, 1, 128, 64
 ROPE_BASE, EPS = 500000.0, 1e-5
 B, L, DEC_STEPS, PAGES = 2, 70, 2, 2
 OUT = os.path.join(HERE, "decoder_layer_w4a8kv4.npz")
+# "h4": four q heads on one kv head, hidden 512 -- the smallest layer the runner's fusion level 3 accepts (its wide attention
+# merge hands one wave 4 heads, and the row-kernel-free projections want hidden / 64 >= batch): the vectors the headline
+# fusion level is replayed against (tests/test_reference_layer_golden_gpu.py)
+VARIANTS = {"base": (256, 512, 2, 1), "h4": (512, 1024, 4, 1)}
 
 
-def out_path(group_size):
-    return OUT if group_size == -1 else os.path.join(HERE, "decoder_layer_w4a8kv4_g%d.npz" % group_size)
+def out_path(group_size, variant="base"):
+    tag = ("" if group_size == -1 else "_g%d" % group_size) + ("" if variant == "base" else "_" + variant)
+    return os.path.join(HERE, "decoder_layer_w4a8kv4%s.npz" % tag)
 
 
 def _sp_attn_config():
@@ -49,7 +54,17 @@ def _sp_attn_config():
     return ns
 
 
-def generate(group_size=-1):
+def generate(group_size=-1, variant="base"):
+    global HIDDEN, INTER, HQ, HK
+    keep = (HIDDEN, INTER, HQ, HK)
+    HIDDEN, INTER, HQ, HK = VARIANTS[variant]
+    try:
+        return _generate(group_size)
+    finally:
+        HIDDEN, INTER, HQ, HK = keep
+
+
+def _generate(group_size):
     from omniserve_amd import ckpt
     from oracle import kv4
     with refstack.reference_over_mirror():
@@ -148,7 +163,8 @@ def generate(group_size=-1):
 
 
 if __name__ == "__main__":
-    for gs in (-1, 128):
-        vec = generate(gs)
-        np.savez_compressed(out_path(gs), **vec)
-        print("wrote", out_path(gs), os.path.getsize(out_path(gs)), "bytes;", ", ".join(sorted(vec)))
+    for var in VARIANTS:
+        for gs in (-1, 128):
+            vec = generate(gs, var)
+            np.savez_compressed(out_path(gs, var), **vec)
+            print("wrote", out_path(gs, var), os.path.getsize(out_path(gs, var)), "bytes;", ", ".join(sorted(vec)))

@@ -123,3 +123,10 @@ def test_gemm_plans_of_the_baseline_decode_shapes():
     for (M, N, K) in ((16, 4096, 14336), (64, 4096, 14336), (128, 8192, 3584), (1, 6144, 4096), (16, 6144, 4096)):
         assert lib.omni_gemm_workspace_bytes(M, N, K) >= M * N * 4
     assert lib.omni_gemm_workspace_bytes(4096, 4096, 4096) == 0
+    # fusion level 3's gate (the runners ask before their first step; ADVICE r3: a hidden = 5120 layer passed the old size
+    # test and then failed in gemm_silu because its gate_up plan splits K across workgroups)
+    assert lib.omni_gemm_rowfree_ok(16, 4096, 4096, 14336, 0) == 1 and lib.omni_gemm_rowfree_ok(16, 4096, 4096, 14336, 1) == 1
+    assert lib.omni_gemm_rowfree_ok(1, 4096, 4096, 14336, 2) == 1          # the LServe driver's W8A8 layer at batch 1
+    assert lib.omni_gemm_rowfree_ok(16, 5120, 5120, 13824, 0) == 0         # Llama-2-13B-shaped: level 2
+    assert lib.omni_gemm_rowfree_ok(17, 4096, 4096, 14336, 0) == 0         # more than the 16-row tile
+    assert lib.omni_gemm_rowfree_ok(16, 512, 512, 1024, 0) == 0            # more rows than hidden / 64 rider workgroups

@@ -278,14 +278,7 @@ def test_decode_append_special_rows():
 # ---------------------------------------------------------------------------------------------------------------
 # a9 at the BASELINE shapes: B = 16 and 64, 32 q heads / 8 kv heads, T = 1024 and 1535
 # ---------------------------------------------------------------------------------------------------------------
-def attention_errors(got, ref):
-    """(max over (b, head) of ||got - ref||_2 / ||ref||_2,  max over elements of |got - ref| / max_d |ref[b, h, :]|)."""
-    got = np.asarray(got, np.float64)
-    ref = np.asarray(ref, np.float64)
-    num = np.sqrt(((got - ref) ** 2).sum(axis=-1))
-    den = np.sqrt((ref ** 2).sum(axis=-1)) + 1e-30
-    head_max = np.abs(ref).max(axis=-1, keepdims=True) + 1e-30
-    return float((num / den).max()), float((np.abs(got - ref) / head_max).max())
+from tests.util import attention_errors  # noqa: E402  (the per-head bar shared by every attention test)
 
 
 @pytest.mark.parametrize("B,T", [(16, 1024), (16, 1535), (64, 1024), (64, 1535)])

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import kv4
-from tests.util import GpuPagedKV, assert_f16_equal, dev, to_dev
+from tests.util import GpuPagedKV, assert_attention_close, assert_f16_equal, dev, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -141,10 +141,7 @@ class Case:
             torch.cuda.synchronize()
             got = out.cpu().numpy().astype(np.float32)
             ref = want.astype(np.float32)
-            tol = 1e-3 * np.abs(ref) + 1e-3 * np.abs(ref).max()
-            bad = np.abs(got - ref) > tol
-            assert not bad.any(), "step %d: decode attention off at %s by %g" % (
-                step, np.argwhere(bad)[:4].tolist(), np.abs(got - ref).max())
+            assert_attention_close(got, ref, "fine-grained decode attention, step %d" % step)
             self.check_pools("decode step %d" % step)
 
 

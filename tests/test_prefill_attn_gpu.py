@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import attention as oa
-from tests.util import dev, to_dev
+from tests.util import assert_attention_close, dev, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -47,8 +47,7 @@ def _case(seq_lens, Hq, Hk, seed, streaming=None, strided=True):
     torch.cuda.synchronize()
     got = out.cpu().numpy().astype(np.float32)
     ref = want.astype(np.float32)
-    tol = 1e-3 * np.abs(ref) + 1e-3 * np.abs(ref).max()
-    assert (np.abs(got - ref) <= tol).all(), "max err %g" % np.abs(got - ref).max()
+    assert_attention_close(got, ref, "prefill attention, lengths %s" % (list(seq_lens),))
 
 
 @pytest.mark.parametrize("seq_lens,Hq,Hk", [([1], 4, 1), ([5, 64, 65], 8, 2), ([200, 33], 32, 8), ([300], 8, 8), ([1000, 17], 4, 4)])
@@ -110,9 +109,7 @@ def _long_case(L, Hq, Hk, seed, streaming=None, rows=None, lens=None):
     got = out.cpu().numpy().astype(np.float32)[rows]
     assert torch.isfinite(out.float()).all().item()
     ref = oa.varlen_attention_rows(q, k, v, cu, cu, rows, True, hm, si).astype(np.float32)
-    tol = 1e-3 * np.abs(ref) + 1e-3 * np.abs(ref).max()
-    bad = np.abs(got - ref) > tol
-    assert not bad.any(), "max err %g at %s" % (np.abs(got - ref).max(), np.argwhere(bad)[:4].tolist())
+    assert_attention_close(got, ref, "prefill attention, %d tokens, %d rows checked" % (T, len(rows)))
 
 
 def test_long_lambda_heads_configs3_window():

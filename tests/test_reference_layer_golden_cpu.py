@@ -22,11 +22,12 @@ def test_fixture_is_complete(golden_dir):
 
 
 @pytest.mark.skipif(not refstack.reference_available(), reason="/root/reference is not on this machine")
+@pytest.mark.parametrize("variant", ["base", "h4"])
 @pytest.mark.parametrize("group_size", [-1, 128])
-def test_fixture_matches_the_reference_layer_today(golden_dir, group_size):
+def test_fixture_matches_the_reference_layer_today(golden_dir, group_size, variant):
     from tests.golden import make_golden_layer
-    fresh = make_golden_layer.generate(group_size)
-    z = np.load(make_golden_layer.out_path(group_size))
+    fresh = make_golden_layer.generate(group_size, variant)
+    z = np.load(make_golden_layer.out_path(group_size, variant))
     assert sorted(fresh) == sorted(z.files)
     for k in z.files:
         assert np.array_equal(np.asarray(fresh[k]).view(np.uint8), z[k].view(np.uint8)), k

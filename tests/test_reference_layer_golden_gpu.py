@@ -2,7 +2,7 @@
 (tests/golden/make_golden_layer.py: `llama_w4a8_unpad.py::LlamaDecoderLayer`, unmodified, over the oracle-backed C-ABI):
 same packed weights (the reference's packer), same inputs, one context-stage pass over two 70-token prompts and two
 generation-stage steps.  Pins the WIRING of omniserve_amd.runtime.DecodeRunner -- call order, buffers, residual handling,
-in-place RoPE, cache append, lengths, and the fused entry points of levels 1 / 2 -- to the reference's layer:
+in-place RoPE, cache append, lengths, and the fused entry points of levels 1 / 2 / 3 -- to the reference's layer:
   * the KV4 pages (codes, scales, zeros of every written token) must be byte-identical: everything up to and including the
     cache write is integer / bit-exact arithmetic (norm + quant -> W4A8 GEMM -> RoPE -> 4-bit quantiser);
   * the hidden states go through the attention softmax (HIP: fp32 online softmax, fp16 probabilities; oracle: f64), whose
@@ -21,9 +21,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _load(golden_dir, group_size):
-    name = "decoder_layer_w4a8kv4.npz" if group_size == -1 else "decoder_layer_w4a8kv4_g%d.npz" % group_size
-    z = np.load(os.path.join(golden_dir, name))
+def _load(golden_dir, group_size, variant="base"):
+    tag = ("" if group_size == -1 else "_g%d" % group_size) + ("" if variant == "base" else "_" + variant)
+    z = np.load(os.path.join(golden_dir, "decoder_layer_w4a8kv4%s.npz" % tag))
     return {k: z[k] for k in z.files}
 
 
@@ -45,11 +45,14 @@ def _close(got, want, what):
     return msg
 
 
-@pytest.mark.parametrize("fused", [0, 1, 2])
+# "h4" (four q heads, hidden 512): the smallest layer fusion level 3 -- the headline's level: no quantiser row kernels, SiLU in
+# the gate_up epilogue, o / down quantising on the fly -- accepts; the level the runner really ran is asserted below, so a
+# silent drop to a lower level cannot pass for it
+@pytest.mark.parametrize("variant,fused", [("base", 0), ("base", 1), ("base", 2), ("h4", 0), ("h4", 2), ("h4", 3)])
 @pytest.mark.parametrize("group_size", [-1, 128])      # per channel (configs[1]) and g128 (configs[2])
-def test_runner_layer_matches_reference_layer_vectors(golden_dir, group_size, fused):
+def test_runner_layer_matches_reference_layer_vectors(golden_dir, group_size, variant, fused):
     from omniserve_amd.runtime import DecodeRunner, LlamaConfig
-    v = _load(golden_dir, group_size)
+    v = _load(golden_dir, group_size, variant)
     assert int(v["group_size"][0]) == group_size
     hidden, inter, hq, hk, d, tpb, B, L, steps, pages = [int(t) for t in v["shape"]]
     base, eps = [float(t) for t in v["rope_base_eps"]]
@@ -59,6 +62,7 @@ def test_runner_layer_matches_reference_layer_vectors(golden_dir, group_size, fu
                       rope_theta=base, eps=eps, group_size=group_size)
     r = DecodeRunner(cfg, B, L, 8, dev, seed=1, use_graph=False, fused=fused)
     assert r.tpb == tpb
+    assert r.fused == fused, "the runner dropped fusion level %d to %d on this layer" % (fused, r.fused)
     Ly = r.layers[0]
     for name in ("qkv", "o", "gate_up", "down"):
         for buf in (("qweight", "s1_scales", "s1_szeros") if group_size == -1 else ("qweight", "s1_scales", "s2_scales", "s2_zeros")):

@@ -35,6 +35,25 @@ def test_fusion_levels_and_graph_agree_bitwise(group_size, batch):
             assert torch.equal(a, b)
 
 
+def test_hidden_5120_layer_takes_level_2_and_steps():
+    """A Llama-2-13B-shaped layer (hidden 5120: the gate_up GEMV's plan splits K across workgroups, which the SiLU-epilogue
+    form of level 3 does not take) asked for the default level: the runner must settle on level 2 up front and decode --
+    bit-identically to the reference call sequence -- instead of raising in its first step."""
+    from omniserve_amd.runtime import DecodeRunner, LlamaConfig
+    dev = torch.device("cuda:0")
+    cfg = LlamaConfig(hidden=5120, inter=13824, heads=40, kv_heads=40, layers=1, vocab=512)
+    out = []
+    for fused in (True, 0):
+        r = DecodeRunner(cfg, batch=16, context=70, max_new=8, device=dev, seed=5, use_graph=False, fused=fused)
+        assert r.fused == (2 if fused else 0)
+        for _ in range(2):
+            r.step()
+        torch.cuda.synchronize()
+        out.append((r.tokens.clone().cpu(), r.x.clone().cpu()))
+        del r
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1].view(torch.int16), out[1][1].view(torch.int16))
+
+
 def test_prefill_is_deterministic_and_decodable():
     """Two prefill calls on the same prompt write bit-identical KV pages and pick the same token; the pages are then
     readable by the decode path (finite activations, valid tokens)."""

@@ -36,6 +36,32 @@ def f16_ulp_diff(got, want):
     return int(np.abs(key(got) - key(want)).max(initial=0))
 
 
+def attention_errors(got, ref):
+    """(max over output vectors of ||got - ref||_2 / ||ref||_2,  max over elements of |got - ref| / max_d |ref[..., :]|):
+    north_star's 1e-3 RELATIVE bar taken per output vector (one (token / sequence, head) row of head_dim values) -- no
+    tensor-wide absolute term."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    num = np.sqrt(((got - ref) ** 2).sum(axis=-1))
+    den = np.sqrt((ref ** 2).sum(axis=-1)) + 1e-30
+    head_max = np.abs(ref).max(axis=-1, keepdims=True) + 1e-30
+    return float((num / den).max()), float((np.abs(got - ref) / head_max).max())
+
+
+def assert_attention_close(got, ref, what="attention", bar=1e-3):
+    """Per-head bar of tests/test_edge_cases_gpu.py::test_decode_attention_baseline_shapes, with the measured distances in
+    the message: for every output vector ||got - ref||_2 <= bar * ||ref||_2 and max |got - ref| <= bar * max |ref|."""
+    got = np.asarray(got, np.float32)
+    ref = np.asarray(ref, np.float32)
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), "%s: non-finite output" % what
+    l2, linf = attention_errors(got, ref)
+    msg = "%s: per-head rel L2 %.3g, max |d| / head max %.3g (bar %.1e)" % (what, l2, linf, bar)
+    print(msg)
+    assert l2 <= bar and linf <= bar, msg
+    return msg
+
+
 def quantize_act(x_f16):
     """Oracle-side per-token activation quantisation used to make GEMM inputs."""
     from oracle import elementwise as oe
