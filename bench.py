@@ -7,9 +7,13 @@
 One "step" = one decode step (one new token for each of the 16 sequences) of Llama-3-8B
 W4A8KV4 per-channel at bs=16, 1024 cached tokens per sequence (BASELINE.json configs[1]), with
 synthetic packed weights / KV pages already resident in HBM, all kernels going through the
-C ABI (libomniserve_hip.so), the step captured in one HIP graph.  With N > 1 every rank decodes
-its own 16 sequences (independent replicas of the TP=1 config: weak scaling, no data-path
-collective); value = tokens decoded by all ranks / max-over-ranks time.
+C ABI (libomniserve_hip.so), the step captured in one HIP graph.
+
+With N > 1 (`--gpus N`; bench.py starts the N ranks itself when no launcher set WORLD_SIZE) the workload is BASELINE.json
+configs[4]: ONE Llama-2-70B W4A8KV4 model at bs=128 sharded TP=N (column / row parallel projections, attention by kv head,
+one fp16 sum all-reduce over RCCL / xGMI after o_proj and after down_proj INSIDE the step): strong scaling, value = 128 x steps /
+max-over-ranks time, `tensor_parallel.all_reduce_us` reported.  Its N = 1 point is `llama2_70b_tp1` of the one-GPU line (or
+`bench.py --model llama2-70b`).  `--replicas` keeps the old N > 1 mode: N independent copies of configs[1], no collective.
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      dominant kernel = the gate_up W4A8 GEMV (N=28672, K=4096, M=16) in the form the step runs
@@ -444,6 +448,30 @@ def tp_rank_leg(device, tp=8, batch=128, context=1024, steps=16, warmup=4):
             "all_reduce_calls_per_step": 2 * cfg.layers, "all_reduce_payload_bytes_per_step": ar_bytes}
 
 
+def tp1_leg(device, batch=128, context=1024, steps=8, warmup=3):
+    """BASELINE.json configs[4]'s model UNSHARDED on one GPU (Llama-2-70B W4A8KV4, bs = 128: 35 GB of packed weights + 12 GB of
+    KV4 pages): the N = 1 point the TP = 2 / 4 / 8 lines of `bench.py --gpus N` (strong scaling) are to be read against."""
+    from omniserve_amd.runtime import DecodeRunner, LlamaConfig
+    cfg = LlamaConfig.llama2_70b(-1)
+    r = DecodeRunner(cfg, batch, context, steps + warmup + 4, device, seed=5)
+    for _ in range(warmup):
+        r.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    if not torch.isfinite(r.x.float()).all():
+        raise RuntimeError("non-finite activations in the 70B decode step")
+    out = {"config": "Llama-2-70B W4A8KV4 per-channel, TP=1, bs=%d, context=%d" % (batch, context),
+           "ms_per_step": round(dt * 1e3, 3), "tokens_per_s": round(batch / dt, 1), "fused_ext_level": r.fused,
+           "gemm_weight_bytes_per_step": r.gemm_weight_bytes_per_step(), "kv_bytes_per_step": r.kv_bytes_per_step(context)}
+    del r
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_gemm_4096():
     """BASELINE.json configs[0] / SURVEY.md 8(d): the oracle's restatement of ONE W4A8 per-channel GEMM at M = N = K = 4096
     on the host -- codes unpacked once (untimed), timed: torch._int_mm(A int8 [M,K], U^T int8 [K,N]) -> int32 plus the
@@ -514,12 +542,82 @@ def cpu_baseline(cfg, batch):
                           batch, M, cores, reps, dt * reps, cfg.layers)}
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _shard_shapes(cfg, world):
+    """Per-rank projection shapes [N, K] of the Megatron split (omniserve_amd/tp.py; pure arithmetic, no device)."""
+    d = cfg.head_dim
+    hl, kl, il = cfg.heads // world, cfg.kv_heads // world, cfg.inter // world
+    return {"qkv": [(hl + 2 * kl) * d, cfg.hidden], "o": [cfg.hidden, hl * d], "gate_up": [2 * il, cfg.hidden],
+            "down": [cfg.hidden, il]}
+
+
+def dry_run(args, cfg, world, rank):
+    """No GPU: the N-rank launch path on the gloo backend (tests/test_bench_spawn_cpu.py) -- rendezvous, the configs[4]
+    partitioning, and one sum all-reduce of a [B, hidden] projection over all ranks -- then the JSON line with n_gpus = N."""
+    import torch.distributed as dist
+    seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        buf = torch.full((args.batch, cfg.hidden), float(rank + 1), dtype=torch.float32)
+        dist.all_reduce(buf)
+        seen = int(round(float(buf[0, 0]) * 2 / (world + 1)))     # sum of 1..N = N (N + 1) / 2
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": _metric_name(args, world), "value": None, "unit": "tokens/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": "strong" if args.tp_mode else "weak", "vs_baseline": None, "dry_run": True,
+                          "config": {"workload": _workload_name(args, cfg, world), "batch": args.batch,
+                                     "parallelism": _parallelism(args, world),
+                                     "rank_shard_shapes_N_K": _shard_shapes(cfg, world if args.tp_mode else 1)},
+                          "tensor_parallel": {"ranks_in_all_reduce": seen, "backend": "gloo (dry run)"}}), flush=True)
+
+
+def _metric_name(args, world):
+    name = "Llama-2-70B" if args.model == "llama2-70b" else "Llama-3-8B"
+    if args.tp_mode:
+        return "decode tokens/sec (all %d GPUs, one model, TP=%d) %s W4A8KV4 bs=%d" % (world, world, name, args.batch)
+    if world == 1:
+        return "decode tokens/sec/GPU %s W4A8KV4 bs=%d" % (name, args.batch)
+    return "decode tokens/sec (all GPUs) %s W4A8KV4 bs=%d per GPU" % (name, args.batch)
+
+
+def _workload_name(args, cfg, world):
+    name = "Llama-2-70B" if args.model == "llama2-70b" else "Llama-3-8B"
+    gs = "per-channel" if args.group_size == -1 else "g%d" % args.group_size
+    if args.tp_mode:
+        return "%s W4A8KV4 %s decode, bs=%d, context=%d, TP=%d (BASELINE.json configs[4])" % (name, gs, args.batch, args.context, world)
+    tag = ("BASELINE.json configs[1]" if (args.model == "llama3-8b" and args.group_size == -1 and args.batch == 16) else
+           "configs[4] model on one GPU" if args.model == "llama2-70b" else "configs[2]-like")
+    return "%s W4A8KV4 %s decode, bs=%d, context=%d, TP=1 (%s)" % (name, gs, args.batch, args.context, tag)
+
+
+def _parallelism(args, world):
+    if world == 1:
+        return "single GPU"
+    return ("tp%d (fp16 sum all-reduce x2 per layer, %s)" % (world, "RCCL" if args.tp_comm == "rccl" else "peer-mapped")
+            if args.tp_mode else "replicas x%d (no collective)" % world)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1 without a launcher (WORLD_SIZE unset): bench.py starts the N ranks "
+                    "itself (python -m torch.distributed.run, rendezvous on 127.0.0.1)")
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=None, help="default: 16 (configs[1]) on one GPU, 128 (configs[4]) with N > 1")
+    ap.add_argument("--model", choices=["llama3-8b", "llama2-70b"], default=None,
+                    help="default: llama3-8b on one GPU (configs[1]); llama2-70b sharded TP=N with N > 1 (configs[4])")
+    ap.add_argument("--replicas", action="store_true", help="with N > 1: N independent replicas of the one-GPU workload (weak "
+                    "scaling, no collective) instead of the default tensor-parallel configs[4]")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the N-rank launch path on gloo and print the line")
     ap.add_argument("--context", type=int, default=1024)
     ap.add_argument("--group-size", type=int, default=-1)
     ap.add_argument("--no-graph", action="store_true")
@@ -531,13 +629,27 @@ def main():
                     help="with --tp: the two all-reduces per layer on torch.distributed / RCCL (default) or on the library's own "
                          "peer-mapped collective folded into the add + norm kernel (omniserve_amd/tp.py: PeerComm; validated with "
                          "two ranks on one GPU only -- no multi-GPU box was available to its author)")
-    ap.add_argument("--tp", action="store_true", help="with N > 1: shard ONE model over the N GPUs (Megatron TP, fp16 "
-                    "all-reduce over RCCL after o_proj / down_proj; strong scaling) instead of N replicas")
+    ap.add_argument("--tp", action="store_true", help="(default with N > 1; kept for older command lines) shard ONE model over "
+                    "the N GPUs: Megatron TP, fp16 sum all-reduce after o_proj / down_proj inside the step; strong scaling")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become one.  One process per GPU under torch.distributed.run, same arguments.
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.tp_mode = world > 1 and not args.replicas
+    if args.model is None:
+        args.model = "llama2-70b" if args.tp_mode else "llama3-8b"
+    if args.batch is None:
+        args.batch = 128 if args.model == "llama2-70b" else 16
+    from omniserve_amd.runtime import LlamaConfig
+    cfg = LlamaConfig.llama2_70b(args.group_size) if args.model == "llama2-70b" else LlamaConfig.llama3_8b(args.group_size)
+    if args.dry_run:
+        return dry_run(args, cfg, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback: the HIP path is the product)")
     torch.cuda.set_device(local_rank)
@@ -548,9 +660,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from omniserve_amd.runtime import DecodeRunner, LlamaConfig
-    cfg = LlamaConfig.llama3_8b(args.group_size)
-    tp = args.tp and world > 1
+    from omniserve_amd.runtime import DecodeRunner
+    tp = args.tp_mode
     runner = DecodeRunner(cfg, args.batch, args.context, args.steps + args.warmup + 4, device,
                           seed=1234 + (0 if tp else rank), use_graph=not args.no_graph,
                           fused=0 if args.no_fused else args.fused_level,
@@ -612,8 +723,7 @@ def main():
             runner.comm.check_error()
     total_tokens = args.batch * args.steps * (1 if tp else world)
     result = {
-        "metric": "decode tokens/sec/GPU Llama-3-8B W4A8KV4 bs=%d" % args.batch if world == 1 else
-                  "decode tokens/sec (all GPUs) Llama-3-8B W4A8KV4 bs=%d per GPU" % args.batch,
+        "metric": _metric_name(args, world),
         "value": round(total_tokens / elapsed, 1),
         "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -621,12 +731,10 @@ def main():
         "higher_is_better": True, "scaling": "strong" if tp else "weak", "vs_baseline": None,
         "dtype": "int8 (W4A8 int32-accumulate GEMM) + fp16 (KV4 attention, fp32 softmax)",
         "data": "synthetic (random packed int4 weights, random KV4 pages, random tokens)",
-        "config": {"workload": "Llama-3-8B W4A8KV4 %s decode, bs=%d, context=%d, TP=1 (%s)" % (
-                       "per-channel" if args.group_size == -1 else "g%d" % args.group_size, args.batch,
-                       args.context, "BASELINE.json configs[1]" if args.group_size == -1 else "configs[2]-like"),
-                   "batch_per_gpu": args.batch, "context": args.context, "layers": cfg.layers,
-                   "parallelism": ("tp%d (RCCL all-reduce x2 per layer)" % world if tp else
-                                   "replicas x%d (no collective)" % world) if world > 1 else "single GPU",
+        "config": {"workload": _workload_name(args, cfg, world),
+                   "batch_per_gpu": args.batch if not tp else None, "global_batch": args.batch * (1 if tp else world),
+                   "context": args.context, "layers": cfg.layers,
+                   "parallelism": _parallelism(args, world),
                    "hip_graph": bool(runner.use_graph), "fused_ext_level": runner.fused,
                    "gemm_weight_bytes_per_step": runner.gemm_weight_bytes_per_step(),
                    "kv_bytes_per_step": runner.kv_bytes_per_step(args.context)},
@@ -643,7 +751,7 @@ def main():
         except Exception as exc:   # noqa: BLE001
             result[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and not args.no_extras and (world == 1 or not tp):
         leg("roofline", lambda: roofline_gate_up(runner, elapsed / args.steps * 1e3))
         prefetch_mb = runner.prefetch_bytes / float(1 << 20)
         result["config"]["l2_prefetch_mib_per_row_kernel"] = prefetch_mb
@@ -653,12 +761,19 @@ def main():
             torch.cuda.empty_cache()
             leg("protocol", lambda: protocol_leg(cfg, args, device))
             leg("drop_in", lambda: drop_in_leg(cfg, args, device))
-            if args.group_size == -1 and args.batch == 16:
+            headline = args.model == "llama3-8b" and args.group_size == -1 and args.batch == 16
+            if headline:
                 leg("configs2_g128_bs64", lambda: configs2_leg(args, device))
-            if not args.no_lserve:
+                # the batch the reference's published A100 figure is quoted at (README.md:269,279; benchmark_a100.sh: bs 256)
+                leg("protocol_bs128", lambda: protocol_leg(cfg, args, device, batch=128))
+                leg("protocol_bs256", lambda: protocol_leg(cfg, args, device, batch=256))
+            if not args.no_lserve and headline:
                 leg("lserve_ctx256k", lambda: lserve_leg(device))
                 torch.cuda.empty_cache()
                 leg("llama2_70b_tp8_rank", lambda: tp_rank_leg(device))
+                torch.cuda.empty_cache()
+                # configs[4]'s model whole on this GPU (70B W4 = 35 GB): the N = 1 point of the strong-scaling curve
+                leg("llama2_70b_tp1", lambda: tp1_leg(device))
                 torch.cuda.empty_cache()
             leg("cpu_baseline", lambda: cpu_baseline(cfg, args.batch))
     if dist is not None:

@@ -484,11 +484,12 @@ int omni_tp_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, cons
  * omni_attn_merge_quant_fuse_sum or omni_attn_merge_f16_amax carries `blocks` extra workgroups that pull up to budget_bytes of that GEMM's packed
  * weights (the head of every wave's weight stream, laid out by the GEMM's own plan) into the XCD-private L2s.
  * weight == NULL, blocks <= 0 or budget_bytes <= 0 disarms.  A pure performance hint: results never depend on it.
- * omni_gemm_set_weight_policy(1) makes the decode-shape GEMMs load weights with plain instead of non-temporal
- * loads (process-wide; 0 restores the default).  Both are evaluated at enqueue time (HIP-graph capturable). */
+ * Load policy, per call (no process-wide switch): the decode-shape GEMM this thread enqueues next ON THAT WEIGHT TENSOR
+ * reads its weights with plain loads (they sit in L2); every other decode-shape GEMM streams its weights with non-temporal
+ * loads.  mode | 0x10: the gate_up form with the SiLU epilogue (omni_*_gemm_silu); mode | 0x20: that GEMM keeps its
+ * non-temporal loads.  Evaluated at enqueue time (HIP-graph capturable); state is per enqueueing thread. */
 int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, int mode, int deferred, int64_t budget_bytes,
                            int blocks);
-void omni_gemm_set_weight_policy(int policy);
 
 /* omni_kv4_decode_attention_fine_grained replaces
  *   omniserve_backend.fused_attention_fine_grained_dense.single_query_attention

@@ -321,7 +321,10 @@ def prefetch_arm_gemm(weight, M, N, K, mode=0, deferred=False, budget_bytes=24 <
     """Arm the one-shot L2 weight prefetch for the NEXT decode-shape GEMM (include/omniserve_hip.h:
     omni_prefetch_arm_gemm): the next decode-size quant / norm row kernel launched through this library carries
     `blocks` extra workgroups that pull up to `budget_bytes` of `weight` into the L2s.  mode: 0 W4A8 per-channel,
-    1 per-group, 2 W8A8; | 0x10: the GEMM will run as gemm_silu_* (gate / up tile rows paired per workgroup).  budget_bytes <= 0 disarms.  A performance hint only."""
+    1 per-group, 2 W8A8; | 0x10: the GEMM will run as gemm_silu_* (gate / up tile rows paired per workgroup); | 0x20: that
+    GEMM keeps non-temporal weight loads (default: the GEMM enqueued next on `weight` loads plain -- its lines sit in L2;
+    every other decode-shape GEMM streams non-temporally: the policy is per call, there is no process-wide switch).
+    budget_bytes <= 0 disarms.  A performance hint only."""
     _lib.require_cuda(weight)
     rc = _lib.lib().omni_prefetch_arm_gemm(weight.data_ptr(), int(M), int(N), int(K), int(mode), int(bool(deferred)),
                                            int(budget_bytes), int(blocks))
@@ -332,12 +335,6 @@ def prefetch_disarm():
     """Drop an armed (not yet consumed) prefetch descriptor of this thread."""
     rc = _lib.lib().omni_prefetch_arm_gemm(None, 0, 0, 0, 0, 0, 0, 0)
     _lib.check(rc, "fused_ext.prefetch_disarm")
-
-
-def set_weight_policy(policy):
-    """0: decode-shape GEMMs stream their weights with non-temporal loads (default); 1: plain loads (for weights a
-    preceding row kernel prefetched into L2).  Process-wide, evaluated at enqueue time."""
-    _lib.lib().omni_gemm_set_weight_policy(int(policy))
 
 
 def sparse_decode_attention_quant(out_i8, input_sum, scale, q, k, v, retrieval_kv_pointers, streaming_kv_pointers,

@@ -602,13 +602,13 @@ void prefill_attn32_kernel(PrefillArgs p) {
 
 using namespace omni;
 
-static int g_prefill_variant = OMNI_PREFILL_MFMA32;
+static thread_local int g_prefill_variant = OMNI_PREFILL_MFMA32;
 // Tuning / test hook: 0 = the 16-row form (default), 1 = the 32-row form.  Same results within the attention tolerance.
 extern "C" void omni_prefill_set_variant(int variant) { g_prefill_variant = variant == 1 ? 1 : 0; }
 #ifndef OMNI_PREFILL_XCD_SPLIT_MASKED
 #define OMNI_PREFILL_XCD_SPLIT_MASKED 8
 #endif
-static int g_prefill_xcd_split = 0;
+static thread_local int g_prefill_xcd_split = 0;
 // Tuning hook: XCDs that share one kv head's query tiles when streaming heads are present (0 = default, else 1 / 2 / 4 / 8).
 extern "C" void omni_prefill_set_xcd_split(int w) { g_prefill_xcd_split = (w == 1 || w == 2 || w == 4 || w == 8) ? w : 0; }
 

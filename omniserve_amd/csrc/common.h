@@ -18,6 +18,18 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 #define OMNI_ENOMEM (-12)
 #define OMNI_ELAUNCH (-5)
 
+// Environment-driven A/B knobs (planner thresholds, debug ablations) exist only in tuning builds
+// (tools/build_variant.sh NAME "-DOMNI_TUNING ..."): the release library never calls getenv and has no "wrong results" switch.
+#ifdef OMNI_TUNING
+#include <cstdlib>
+static inline int omni_knob(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+#else
+#define omni_knob(name, dflt) (dflt)
+#endif
+
 static inline int omni_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? OMNI_OK : OMNI_ELAUNCH;

@@ -379,7 +379,7 @@ struct SrcPeerAdd {
   }
   __device__ __forceinline__ void fetch(int i, Raw& r) const {
     r.a = *reinterpret_cast<const v8h*>(res + i);
-    r.s = tp_sum8(tp, (size_t)i);
+    r.s = tp_sum8(tp, (size_t)i, tp.epoch);
   }
   __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
     v8h o;
@@ -671,6 +671,7 @@ __global__ __launch_bounds__(RT) void tp_add_norm_v2_kernel(int8_t* __restrict__
   extern __shared__ __attribute__((aligned(16))) float xs[];
   __shared__ float red[96];
   const uint32_t e = tp_publish_and_wait(src0.tp);
+  src0.tp.epoch = e;        // 0 = a peer never arrived: the row is poisoned (NaN), the epoch stays
   general_norm_v2_body<RT, RV, FUSE_SUM, SrcPeerAdd>(out, src0, gamma, sum_out, scale_out, eps, hidden, nv, xs, red);
   tp_finish(src0.tp, e);
 }
@@ -763,7 +764,7 @@ static inline PrefetchArgs take_prefetch(int tokens) {
 // OMNI_DECODE_RT=256 (tuning knob) runs decode-size rows of sources that batch their loads on 256 threads instead of 512.
 static const bool v2_batched = true;     // shadowed by `false` at the launch sites of sources that fetch per vector
 static inline int decode_rt() {
-  static const int v = [] { const char* e = getenv("OMNI_DECODE_RT"); return e ? atoi(e) : 512; }();
+  static const int v = omni_knob("OMNI_DECODE_RT", 512);
   return v;
 }
 #define OMNI_V2_LAUNCH(KERNEL, tokens, hidden, elems, ...)                                                      \
@@ -1208,7 +1209,10 @@ extern "C" int omni_tp_add_rms_norm_general_fuse_sum(void* out_i8, void* residua
     src.tp.data[p] = (const half_t*)peer_data[q];
     src.tp.flags[p] = (uint32_t*)peer_flags[q];
   }
-  src.tp.rank = rank; src.tp.world = world; src.tp.slot_off = slot_offset_elems;
+  src.tp.rank = rank; src.tp.world = world; src.tp.slot_off = slot_offset_elems; src.tp.epoch = 1;
+  // this row kernel carries no L2-prefetch riders (its workgroups meet at a ticket and must all be resident): a descriptor
+  // armed for "the next row kernel" is dropped here instead of riding on an unrelated launch later
+  (void)take_armed_prefetch();
   const size_t lds = (size_t)hidden * sizeof(float);
   if (sum_f16)
     hipLaunchKernelGGL((tp_add_norm_v2_kernel<512, 4, true>), dim3(tokens), dim3(512), lds, (hipStream_t)stream, (int8_t*)out_i8,

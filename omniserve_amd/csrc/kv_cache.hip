@@ -923,7 +923,7 @@ struct DecodePlan {
   size_t lds_bytes;
 };
 
-static int g_override_nsplit = 0;   // tuning hook, see omni_kv4_decode_set_split_override
+static thread_local int g_override_nsplit = 0;   // tuning hook, see omni_kv4_decode_set_split_override
 
 static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int max_context, int tokens_per_block,
                               bool per_q_head = false) {

@@ -21,7 +21,6 @@
 #pragma once
 #include "common.h"
 #include "row_reduce.h"
-#include <cstdlib>
 
 namespace omni {
 
@@ -52,12 +51,22 @@ struct GemmArgs {
   uint32_t* amax;         // [AMAX_WORDS] row-maximum candidates (common.h): EPI = 1 raises them, A16 reads them
   half_t* sum_out;        // [M] A16 rider outputs: the reference-ordered fp16 row sum (NULL = not wanted) ...
   half_t* scale_out;      // [M] ... and h(amax / 127)
+#ifdef OMNI_TUNING
   int dbg;                // timing experiments (OMNI_GEMV_DBG; wrong results): 1 no rider work, 2 no conversion, 4 no row-maximum atomics
+#endif
 };
+// ablation switches of the fp16-input / SiLU-epilogue GEMVs: tuning builds only (the release kernels carry no such branch)
+#ifdef OMNI_TUNING
 static inline int gemv_dbg_flags() {
-  static const int v = [] { const char* e = getenv("OMNI_GEMV_DBG"); return e ? atoi(e) : 0; }();
+  static const int v = omni_knob("OMNI_GEMV_DBG", 0);
   return v;
 }
+#define OMNI_GEMV_DBG_BIT(p, bit) (((p).dbg & (bit)) != 0)
+#define OMNI_GEMV_SET_DBG(a) ((a).dbg = gemv_dbg_flags())
+#else
+#define OMNI_GEMV_DBG_BIT(p, bit) false
+#define OMNI_GEMV_SET_DBG(a) ((void)0)
+#endif
 
 
 // per-byte add mod 256 (CUDA __vadd4)
@@ -75,90 +84,24 @@ __device__ __forceinline__ uint32_t vadd4(uint32_t x, uint32_t y) {
 // by the very next VALU instruction (one wait state; hipcc pads its own code, not the inside of an asm statement) -- the first
 // version, four byte adds per word back to back, returned wrong bytes.  Interleaved, three instructions separate the writes
 // of one register; the statement's outputs are read by compiler code, which gets hipcc's boundary pad.
+// The statement is generated: byte j of word q + byte Z of the zero-point dword, q = 0..3 inside j = 0..3 (the first write
+// of a register pads the other bytes, the later ones preserve them).
+#define OMNI_VADD4_LINE(R, S, J, UNUSED, Z) \
+  "v_add_u32_sdwa %" #R ", %" #S ", %8 dst_sel:BYTE_" #J " dst_unused:" UNUSED " src0_sel:BYTE_" #J " src1_sel:BYTE_" #Z "\n\t"
+#define OMNI_VADD4_BYTE(J, UNUSED, Z) \
+  OMNI_VADD4_LINE(0, 4, J, UNUSED, Z) OMNI_VADD4_LINE(1, 5, J, UNUSED, Z) OMNI_VADD4_LINE(2, 6, J, UNUSED, Z) OMNI_VADD4_LINE(3, 7, J, UNUSED, Z)
+#define OMNI_VADD4_ASM(Z) \
+  OMNI_VADD4_BYTE(0, "UNUSED_PAD", Z) OMNI_VADD4_BYTE(1, "UNUSED_PRESERVE", Z) OMNI_VADD4_BYTE(2, "UNUSED_PRESERVE", Z) OMNI_VADD4_BYTE(3, "UNUSED_PRESERVE", Z)
+#define OMNI_VADD4_STMT(Z) \
+  asm(OMNI_VADD4_ASM(Z) : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(zw))
 template <int ZB>
 __device__ __forceinline__ void vadd4_zbyte_x4(uint32_t (&u)[4], uint32_t zw) {
 #if OMNI_GRP_SDWA
   uint32_t r0, r1, r2, r3;
-  if constexpr (ZB == 0) {
-    asm("v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_0\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_0"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(zw));
-  }
-  else if constexpr (ZB == 1) {
-    asm("v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_1"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(zw));
-  }
-  else if constexpr (ZB == 2) {
-    asm("v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_2\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_2"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(zw));
-  }
-  else {
-    asm("v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %0, %4, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %1, %5, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %2, %6, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
-        "v_add_u32_sdwa %3, %7, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(zw));
-  }
+  if constexpr (ZB == 0) OMNI_VADD4_STMT(0);
+  else if constexpr (ZB == 1) OMNI_VADD4_STMT(1);
+  else if constexpr (ZB == 2) OMNI_VADD4_STMT(2);
+  else OMNI_VADD4_STMT(3);
   u[0] = r0; u[1] = r1; u[2] = r2; u[3] = r3;
 #else
   const uint32_t zr = ((zw >> (8 * ZB)) & 0xFFu) * 0x01010101u;
@@ -672,7 +615,7 @@ struct GemvCfg {
 //     LDS at the end and wave w finishes the 4/KW row blocks it owns.  More waves in flight per CU
 //     without the slab round trip of a grid-level split.
 // NT: weight loads carry the non-temporal hint (weights streamed once from HBM, the default); false = plain loads,
-// for weights a preceding row kernel has prefetched into the L2s (omni_prefetch_arm_gemm, omni_gemm_set_weight_policy).
+// for weights a preceding row kernel has prefetched into the L2s (omni_prefetch_arm_gemm; take_prefetched_weight below).
 // MZ = 2 (M = 65..128): the workgroup carries BOTH 64-row tiles of its channel group -- waves (kw, half) -- so the two
 // reads of a weight byte are issued side by side by waves of one CU (the second is served by L1 / the in-flight line in
 // L2) instead of by two workgroups somewhere on the chip at different times.
@@ -711,7 +654,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
 
   if constexpr (A16) {
     if (blockIdx.y == 0) {      // rider workgroups (dispatched first): ordered row sum + scale of activation row blockIdx.x
-      if (!(p.dbg & 1)) a16_rider<64 * KW>(p, reinterpret_cast<float*>(&lds_all[0][0][0]), epi_red);
+      if (!OMNI_GEMV_DBG_BIT(p, 1)) a16_rider<64 * KW>(p, reinterpret_cast<float*>(&lds_all[0][0][0]), epi_red);
       return;
     }
   }
@@ -821,7 +764,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
       piece(j, m, kk);
       uint4 av;
       if constexpr (A16) {
-        if (p.dbg & 2) av = make_uint4(araw[j][0].x ^ araw[j][1].x, araw[j][0].y ^ araw[j][1].y, araw[j][0].z ^ araw[j][1].z, araw[j][0].w ^ araw[j][1].w);
+        if (OMNI_GEMV_DBG_BIT(p, 2)) av = make_uint4(araw[j][0].x ^ araw[j][1].x, araw[j][0].y ^ araw[j][1].y, araw[j][0].z ^ araw[j][1].z, araw[j][0].w ^ araw[j][1].w);
         else
         av = make_uint4(quant4_f16(araw[j][0].x, araw[j][0].y, qrow[j]), quant4_f16(araw[j][0].z, araw[j][0].w, qrow[j]),
                         quant4_f16(araw[j][1].x, araw[j][1].y, qrow[j]), quant4_f16(araw[j][1].z, araw[j][1].w, qrow[j]));
@@ -1126,7 +1069,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
 #pragma unroll
       for (int w = 1; w < KW; ++w) v = __builtin_fmaxf(v, smax[w][threadIdx.x]);
       const int m = m0 + threadIdx.x;
-      if (m < p.M && !(p.dbg & 4)) amax_raise(p.amax, m, blockIdx.x >> 3, v);
+      if (m < p.M && !OMNI_GEMV_DBG_BIT(p, 4)) amax_raise(p.amax, m, blockIdx.x >> 3, v);
     }
   }
 }
@@ -1195,9 +1138,12 @@ static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st
   b.tiles_n = b.tiles_m = 0;
 #endif
   // exact shapes (the models' projections at prefill): the straight-line kernel of qgemm_exact.h
-  static const int exact_mode = [] { const char* e = getenv("OMNI_GEMM_EXACT"); return e ? atoi(e) : 1; }();   // 0: off (A/B)
+  static const int exact_mode = omni_knob("OMNI_GEMM_EXACT", 1);   // 0: off (A/B, tuning builds)
+  // (the exact kernel decodes the 1-D XCD tile order and stores 16 B per lane: rows of the output must start 16-B aligned)
+  static_assert(OMNI_GEMM_XCD_ORDER == 1, "w4a8_gemm_exact_kernel reads tiles_m / tiles_n of the 1-D XCD-ordered grid");
+  const bool out16 = (a.out_stride % 8) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
   if (MB == 8 && WAVES == 4 && exact_mode != 0 && a.M % 128 == 0 && a.N % 256 == 0 && a.K % KCHUNK == 0 && b.kslice >= a.K &&
-      (size_t)a.M * a.K < ((size_t)1 << 32)) {
+      (size_t)a.M * a.K < ((size_t)1 << 32) && out16) {
     if (OMNI_GEMM_EXACT_DMA && exact_mode != 2)
       hipLaunchKernelGGL((w4a8_gemm_exact_kernel<MODE, true>), grid, dim3(256), 0, st, b);
     else
@@ -1207,7 +1153,10 @@ static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st
   hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, false>), grid, dim3(64 * WAVES), 0, st, b);
 }
 
-extern int g_weight_policy;   // qgemm_plan.hip (omni_gemm_set_weight_policy)
+// Load policy of a decode-shape GEMV's weight stream, decided PER CALL: plain loads when the call's weight tensor is the
+// one a preceding omni_prefetch_arm_gemm named (a row kernel pulled the head of its stream into the L2s -- one-shot entry,
+// consumed here), non-temporal loads otherwise (streamed once from HBM).  qgemm_plan.hip.
+bool take_prefetched_weight(const void* weight);
 
 template <int MODE, int MB, bool TO_SLAB, bool NT>
 static void launch_gemv_kernel_nt(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
@@ -1261,7 +1210,7 @@ static void launch_gemv_kernel_nt(const GemmArgs& a, const GemmPlan& pl, hipStre
 
 template <int MODE, int MB, bool TO_SLAB>
 static void launch_gemv_kernel(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
-  if (g_weight_policy == 1) launch_gemv_kernel_nt<MODE, MB, TO_SLAB, false>(a, pl, st);
+  if (take_prefetched_weight(a.W)) launch_gemv_kernel_nt<MODE, MB, TO_SLAB, false>(a, pl, st);
   else launch_gemv_kernel_nt<MODE, MB, TO_SLAB, true>(a, pl, st);
 }
 
@@ -1324,8 +1273,8 @@ static int launch_gemm_silu(GemmArgs a, hipStream_t st) {
   GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64, false, MODE == MODE_W8);
   if (pl.sk != 1 || pl.mb != 1) return OMNI_EINVAL;
   a.kslice = pl.kslice;
-  a.dbg = gemv_dbg_flags();
-  return g_weight_policy == 1 ? launch_gemv_silu_nt<MODE, false>(a, pl, st) : launch_gemv_silu_nt<MODE, true>(a, pl, st);
+  OMNI_GEMV_SET_DBG(a);
+  return take_prefetched_weight(a.W) ? launch_gemv_silu_nt<MODE, false>(a, pl, st) : launch_gemv_silu_nt<MODE, true>(a, pl, st);
 }
 
 template <int MODE, bool NT>
@@ -1356,8 +1305,8 @@ static int launch_gemm_partial_f16(GemmArgs a, void* slab, size_t slab_bytes, in
   a.slab = static_cast<int32_t*>(slab);
   a.kslice = pl.kslice;
   *sk_out = pl.sk;
-  a.dbg = gemv_dbg_flags();
-  return g_weight_policy == 1 ? launch_gemv_f16_nt<MODE, false>(a, pl, st) : launch_gemv_f16_nt<MODE, true>(a, pl, st);
+  OMNI_GEMV_SET_DBG(a);
+  return take_prefetched_weight(a.W) ? launch_gemv_f16_nt<MODE, false>(a, pl, st) : launch_gemv_f16_nt<MODE, true>(a, pl, st);
 }
 
 // Deferred-epilogue variant (fused extension): only the int32 split-K slabs are produced; the consumer

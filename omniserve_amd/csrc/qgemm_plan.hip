@@ -1,13 +1,29 @@
 // Host-side tiling / split-K planning for the W4A8 / W8A8 GEMMs (shared by the three GEMM TUs).
 #include "qgemm_kernel.h"
-#include <cstdlib>
 
 namespace omni {
 
-static int g_override_waves = 0;
-static int g_override_sk = 0;
-int g_weight_policy = 0;             // 0: non-temporal weight loads (streamed once), 1: plain loads (L2-prefetched weights)
+// (plan overrides: test / sweep hooks, per enqueueing thread like everything else here)
+static thread_local int g_override_waves = 0;
+static thread_local int g_override_sk = 0;
 static thread_local PrefetchArgs g_armed_prefetch = {};   // per enqueueing thread: armed and consumed by the same caller
+// weight tensors named by omni_prefetch_arm_gemm whose GEMV has not been enqueued yet (one-shot, per thread): that GEMV
+// reads its weights with plain loads (they sit in L2), every other one streams non-temporally.  A decode layer has at
+// most two such entries alive at a time (down_proj armed while gate_up runs); 4 slots, oldest replaced.
+static thread_local const void* g_prefetched_w[4] = {nullptr, nullptr, nullptr, nullptr};
+static thread_local unsigned g_prefetched_next = 0;
+
+bool take_prefetched_weight(const void* weight) {
+  if (!weight) return false;
+  for (auto& w : g_prefetched_w)
+    if (w == weight) { w = nullptr; return true; }
+  return false;
+}
+static void note_prefetched_weight(const void* weight) {
+  for (auto& w : g_prefetched_w)
+    if (w == weight) return;
+  g_prefetched_w[g_prefetched_next++ & 3] = weight;
+}
 
 PrefetchArgs take_armed_prefetch() {
   PrefetchArgs pf = g_armed_prefetch;
@@ -37,7 +53,7 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
   // chains per wave at the same two waves per SIMD (measured, profiles/r03_c_*: Llama-2-70B TP=8 shard at M = 128
   // gate_up 24.8 -> 21.6 us, down 18.4 -> 12.9, qkv 12.5 -> 10.0, o 7.6 -> 5.6; Llama-3-8B g128 at M = 64 down 20.4 ->
   // 18.6, qkv 12.8 -> 10.1, o 10.9 -> 9.9, but gate_up 23.0 -> 31.5: 896 workgroups, two rounds -- stays on 64 rows).
-  static const int narrow_mode = [] { const char* e = getenv("OMNI_GEMV_NARROW"); return e ? atoi(e) : 1; }();   // 0: never (A/B)
+  static const int narrow_mode = omni_knob("OMNI_GEMV_NARROW", 1);   // 0: never (A/B, tuning builds)
   // (g128 at M <= 64: faster launch by launch, but the Llama-3-8B bs = 64 decode step measured 1.2 % slower with it -- off)
   if (!w8 && M > 32 && !(kalign == 128 && M <= 64) && narrow_mode != 0 && g_override_waves == 0 && g_override_sk == 0) {
     const int mz = (M + 31) / 32;
@@ -65,11 +81,11 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
     auto part = [&](int s) { return K / (s * kw); };
     auto fits = [&](int s) { return ok(s) && ((K / s) % (kw * kalign)) == 0; };
     // W8A8 rows are twice the bytes per k: the deferred (slab-only) plan halves the k per wave (same bytes per wave)
-    static const int part_w4_deferred = [] { const char* e = getenv("OMNI_DEFERRED_PART"); return e ? atoi(e) : 512; }();   // (A/B knob)
+    static const int part_w4_deferred = omni_knob("OMNI_DEFERRED_PART", 512);   // (A/B knob, tuning builds)
     const int part_target = (deferred && w8) ? 256 : (deferred ? part_w4_deferred : 512);
     // W8A8 rows are twice the bytes per k: with few channel groups (qkv at batch 1: 96 workgroups streaming 256 KiB each)
     // a split to 512 k per wave + the slab epilogue launch beats the single kernel (OMNI_W8_SMALL_SPLIT=0: off, A/B)
-    static const int w8_small_split = [] { const char* e = getenv("OMNI_W8_SMALL_SPLIT"); return e ? atoi(e) : 1; }();
+    static const int w8_small_split = omni_knob("OMNI_W8_SMALL_SPLIT", 1);
     const bool w8_small = w8 && !deferred && w8_small_split && ngroups <= 128 && part(1) > 512;
     if (!deferred && part(1) <= 1024 && !w8_small) {
       sk = 1;
@@ -177,16 +193,21 @@ extern "C" size_t omni_gemm_workspace_bytes(int M, int N, int K) {
 }
 
 // ---- fused extension: L2 weight prefetch riding on the next row kernel (common.h: PrefetchArgs) -------------------
-extern "C" void omni_gemm_set_weight_policy(int policy) { omni::g_weight_policy = policy == 1 ? 1 : 0; }
-
 extern "C" int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, int mode, int deferred,
                                       int64_t budget_bytes, int blocks) {
   using namespace omni;
   g_armed_prefetch = PrefetchArgs{};
-  if (!weight || blocks <= 0 || budget_bytes <= 0) return OMNI_OK;          // disarm
+  if (!weight || blocks <= 0 || budget_bytes <= 0) {                        // disarm (and forget every pending load-policy entry)
+    if (!weight)
+      for (auto& w : g_prefetched_w) w = nullptr;
+    return OMNI_OK;
+  }
   // mode | 0x10: the gate_up form with the fused SiLU epilogue (omni_w4a8_per_*_gemm_silu): workgroup x streams tile row x
   // of the gate half and tile row N/64 + x of the up half
   const bool silu = (mode & 0x10) != 0;
+  // mode | 0x20: the consuming GEMV keeps its non-temporal weight loads (the prefetch then only warms the memory-side
+  // cache); default: that GEMV -- the next decode-shape GEMM enqueued by this thread on this weight tensor -- loads plain
+  const bool keep_nt = (mode & 0x20) != 0;
   mode &= 0xF;
   if (silu && (mode == MODE_W8 || deferred || (N / 64) % 8 != 0)) return mode == MODE_W8 ? OMNI_EINVAL : OMNI_OK;
   if (mode < 0 || mode > 2 || M < 1 || M > 128 || N % 64 != 0 || K % 64 != 0 || K < 64) return OMNI_EINVAL;
@@ -227,9 +248,10 @@ extern "C" int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, i
     pf.pf_bytes = (int)want;
   }
   pf.blocks = (blocks + 7) & ~7;
-  static const int delay = [] { const char* e = getenv("OMNI_PREFETCH_DELAY"); return e ? atoi(e) : 0; }();
+  static const int delay = omni_knob("OMNI_PREFETCH_DELAY", 0);
   pf.delay = delay;
   g_armed_prefetch = pf;
+  if (!keep_nt) note_prefetched_weight(weight);     // the GEMV on this weight tensor reads L2-resident lines: plain loads
   return OMNI_OK;
 }
 

@@ -33,15 +33,22 @@ struct TpPeers {
   uint32_t* flags[TP_MAX_WORLD];       // rank p's flag words
   int rank, world;
   long long slot_off;                  // element offset of the slot this call uses
+  uint32_t epoch;                      // filled in by the consumer kernel after tp_publish_and_wait (0 = timed out)
 };
 
 __device__ __forceinline__ uint32_t tp_load_sys(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Prologue of a consumer kernel: publish my slot, wait for every peer's.  Returns the epoch (0 = timed out).
+// Prologue of a consumer kernel: publish my slot, wait for every peer's.  Returns the epoch, or 0 when a wait timed out:
+// the caller then POISONS its output (tp_sum8 returns NaN for epoch 0 -- wrong tokens must not pass for results) and
+// tp_finish leaves the rank's epoch where it was; the error word stays set until the host clears it (PeerComm.check_error
+// raises on it; omniserve_amd/runtime.py reads it wherever it reads tokens back).
 __device__ __forceinline__ uint32_t tp_publish_and_wait(const TpPeers& tp) {
   __shared__ uint32_t s_epoch;
+  __shared__ uint32_t s_fail;
+  if (threadIdx.x == 0) s_fail = 0;
+  __syncthreads();
   uint32_t* mine = tp.flags[tp.rank];
   const uint32_t e = tp_load_sys(mine + TP_W_EPOCH) + 1;
   if (blockIdx.x == 0 && (int)threadIdx.x < tp.world) {
@@ -56,6 +63,7 @@ __device__ __forceinline__ uint32_t tp_publish_and_wait(const TpPeers& tp) {
       seen = tp_load_sys(mine + threadIdx.x);
       if (++spins > (1ll << 23)) {                    // ~ seconds: a peer is gone -- report, do not hang the queue
         __hip_atomic_store(mine + TP_W_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_fail = 1;
         break;
       }
     }
@@ -63,7 +71,7 @@ __device__ __forceinline__ uint32_t tp_publish_and_wait(const TpPeers& tp) {
   if (threadIdx.x == 0) s_epoch = e;
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system-scope acquire: the peers' slots are readable from here on
-  return s_epoch;
+  return s_fail ? 0u : s_epoch;
 }
 
 // Epilogue: the last workgroup of the kernel to get here advances this rank's epoch.
@@ -74,13 +82,20 @@ __device__ __forceinline__ void tp_finish(const TpPeers& tp, uint32_t e) {
     const uint32_t done = __hip_atomic_fetch_add(mine + TP_W_TICKET, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (done == gridDim.x - 1) {
       __hip_atomic_store(mine + TP_W_TICKET, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(mine + TP_W_EPOCH, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      // (a timed-out collective -- e == 0 in any of the kernel's workgroups shows as the error word -- does not count)
+      if (e != 0 && tp_load_sys(mine + TP_W_ERROR) == 0)
+        __hip_atomic_store(mine + TP_W_EPOCH, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
 
 // h( sum over ranks 0 .. world-1 of f32(data_p[i .. i+8)) ): the all-reduced fp16 vector, identical on every rank
-__device__ __forceinline__ v8h tp_sum8(const TpPeers& tp, size_t i) {
+// (epoch 0 = the wait timed out: NaN, so that nothing downstream mistakes the sum of half-written slots for a result)
+__device__ __forceinline__ v8h tp_sum8(const TpPeers& tp, size_t i, uint32_t epoch = 1) {
+  if (epoch == 0) {
+    const half_t qnan = __builtin_bit_cast(half_t, (uint16_t)0x7E00);
+    return (v8h){qnan, qnan, qnan, qnan, qnan, qnan, qnan, qnan};
+  }
   v8h t[TP_MAX_WORLD];
 #pragma unroll
   for (int p = 0; p < TP_MAX_WORLD; ++p)

@@ -9,7 +9,7 @@ __global__ __launch_bounds__(256) void tp_allreduce_f16_kernel(half_t* __restric
   const uint32_t e = tp_publish_and_wait(tp);
   const long long nvec = count / 8;
   for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256)
-    *reinterpret_cast<v8h*>(out + v * 8) = tp_sum8(tp, (size_t)v * 8);
+    *reinterpret_cast<v8h*>(out + v * 8) = tp_sum8(tp, (size_t)v * 8, e);
   tp_finish(tp, e);
 }
 
@@ -25,7 +25,7 @@ static int fill_peers(TpPeers& tp, const void* const* peer_data, void* const* pe
     tp.data[p] = static_cast<const half_t*>(peer_data[q]);
     tp.flags[p] = static_cast<uint32_t*>(peer_flags[q]);
   }
-  tp.rank = rank; tp.world = world; tp.slot_off = slot_off;
+  tp.rank = rank; tp.world = world; tp.slot_off = slot_off; tp.epoch = 1;
   return OMNI_OK;
 }
 

@@ -207,7 +207,8 @@ class LServeDecodeRunner:
 
     def _arm(self, lin, deferred=False):
         if self.prefetch_bytes > 0:
-            fused_ext.prefetch_arm_gemm(lin.weight, self.B, lin.n, lin.k, 2, deferred, self.prefetch_bytes,
+            # (| 0x20: the W8A8 GEMVs keep their non-temporal loads, the arrangement this driver was measured with)
+            fused_ext.prefetch_arm_gemm(lin.weight, self.B, lin.n, lin.k, 2 | 0x20, deferred, self.prefetch_bytes,
                                         self.prefetch_blocks)
 
     # one decode step; `select` = this step refreshes the page selection (every `interval`-th step upstream)

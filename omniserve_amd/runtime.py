@@ -166,7 +166,8 @@ class DecodeRunner:
             self.fused = 2
         # L2 weight prefetch riding on the row kernels (fused extension; a hint, results are unaffected): MiB of the
         # next GEMV's weights each row kernel pulls into the L2s (0 = off), with how many extra workgroups, and
-        # whether the GEMVs then use plain instead of non-temporal weight loads.  Defaults: on with the fused
+        # whether the GEMV on a prefetched tensor then uses plain instead of non-temporal weight loads (per call: the arm
+        # names the tensor, omni_prefetch_arm_gemm; un-armed projections always stream non-temporally).  Defaults: on with the fused
         # entry points (environment overrides for sweeps: OMNI_PREFETCH_MB, OMNI_PREFETCH_BLOCKS, OMNI_WEIGHT_POLICY).
         if prefetch_mb is None:
             # measured (profiles/r02_*): +6-7 % at bs = 16 with 28-40 MiB per row kernel (the L2s hold 32 MiB; the
@@ -259,9 +260,6 @@ class DecodeRunner:
         # row-maximum candidates of the level-3 path: [layer][0 = attention output, 1 = MLP activation][AMAX_WORDS], zeroed once
         # per step (the producers raise them with atomicMax)
         self.amax = torch.zeros((c.layers, 2, fused_ext.AMAX_WORDS), dtype=torch.int32, device=device)
-        # the down projection of the level-3 path has no row kernel in front of it to carry an L2 prefetch: its weights
-        # are streamed with non-temporal loads whatever the step's policy says
-        self.down_nt = int(os.environ.get("OMNI_DOWN_NT", "1"))
         # level 3: the norm in front of gate_up prefetches ALL of DOWN's weights (29.6 MB fit the 32 MB of L2s) instead of
         # the head of gate_up's 58.7 MB; gate_up then streams cold with non-temporal loads (they do not displace the
         # prefetched lines) and down reads L2: 2.322-2.334 -> 2.294-2.314 ms per step on the same box (profiles/r03_g;
@@ -331,6 +329,8 @@ class DecodeRunner:
                 torch.cuda.synchronize()
                 self.use_graph = False
                 self.graph_error = "%s: %s" % (type(exc).__name__, exc)
+                if self.comm is not None:
+                    self.comm.resync()      # the abandoned capture may have consumed an odd number of slots
                 self.lengths.copy_(saved[0])
                 self.tokens.copy_(saved[1])
                 self._eager_step()
@@ -338,6 +338,21 @@ class DecodeRunner:
                 return
         self.graph.replay()
         self.steps_done += 1
+
+    def read_tokens(self):
+        """The tokens of the last step on the host (synchronises).  Under tensor parallelism with the library's own
+        collective this is also where a timed-out peer wait surfaces: the affected collectives returned NaN, the epoch did
+        not advance, and this raises instead of handing back tokens computed from them."""
+        toks = self.tokens.cpu()
+        if self.comm is not None:
+            self.comm.check_error()
+        return toks
+
+    def close(self):
+        """Release the peer-mapped communication buffers (tensor parallel, tp_comm = "peer")."""
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
     def _partial(self, x_i8, lin):
         """o_proj / down_proj without its epilogue: int32 split-K slabs in self.slab, returns the slab count."""
@@ -365,16 +380,15 @@ class DecodeRunner:
     def _arm(self, lin, deferred=False, silu=False):
         """The next row kernel prefetches the head of `lin`'s weight stream into the L2s (no-op when disabled).
         silu: `lin` will run as fused_ext.gemm_silu_* (gate / up tile rows paired per workgroup)."""
-        if self.prefetch_bytes > 0:
-            fused_ext.prefetch_arm_gemm(lin.qweight, self.B, lin.n, lin.k, (0 if lin.group == -1 else 1) | (0x10 if silu else 0),
+        if self.prefetch_bytes > 0:      # (weight_policy 0: the consuming GEMV keeps its non-temporal loads -- A/B)
+            fused_ext.prefetch_arm_gemm(lin.qweight, self.B, lin.n, lin.k,
+                                        (0 if lin.group == -1 else 1) | (0x10 if silu else 0) | (0 if self.weight_policy else 0x20),
                                         deferred, self.prefetch_bytes, self.prefetch_blocks)
 
     def _eager_step(self):
-        fused_ext.set_weight_policy(self.weight_policy)
         try:
             self._eager_step_body()
         finally:
-            fused_ext.set_weight_policy(0)
             if self.prefetch_bytes > 0:
                 fused_ext.prefetch_disarm()     # a step that raised may leave a descriptor armed
             if self.qkv_slabs:
@@ -470,22 +484,14 @@ class DecodeRunner:
                         layernorm_ops.rms_norm_general(qa_h, self.x, L["ln2"], sB, c.eps, True)
             if l3:
                 # gate_up with silu_and_mul in its epilogue -> fp16 activation + row maxima; down_proj quantises on the fly
-                G = L["gate_up"]
-                if self.pf_down == 1 and self.weight_policy:
-                    fused_ext.set_weight_policy(0)
+                G = L["gate_up"]       # (pf_down: not the armed tensor -> streams cold, non-temporal; down_proj then reads L2)
                 if per_chn:
                     fused_ext.gemm_silu_per_chn(qa_h, G.qweight, G.s1_scales, sB, G.s1_szeros, mB, self.mlp_act,
                                                 self.amax[li, 1])
                 else:
                     fused_ext.gemm_silu_per_group(qa_h, G.qweight, G.s2_zeros, G.s2_scales, G.s1_scales, sB,
                                                   self.mlp_act, self.amax[li, 1])
-                if self.pf_down:
-                    fused_ext.set_weight_policy(self.weight_policy)
-                elif self.down_nt and self.weight_policy:
-                    fused_ext.set_weight_policy(0)
                 pending = (self._partial_f16(self.mlp_act, self.amax[li, 1], L["down"], mA, sA), L["down"])
-                if self.down_nt and self.weight_policy:
-                    fused_ext.set_weight_policy(self.weight_policy)
                 continue
             L["gate_up"].forward(qa_h, sB, mB, self.gate_up_buf)
             self._arm(L["down"], deferred=self.fused >= 2 and li < nl - 1)

@@ -168,17 +168,33 @@ class PeerComm:
             tokens, hidden, _lib.current_stream())
         _lib.check(rc, "omni_tp_add_rms_norm_general_fuse_sum")
 
-    def check_error(self):
+    def check_error(self, clear=False):
+        """Raises if a wait for a peer timed out since the last clear (device word TP_W_ERROR; reading it synchronises).
+        The collective that timed out produced NaN and did not advance the epoch (csrc/tp_comm.h)."""
         words = self._mine[self.data_bytes:].view(torch.int32)
         if int(words[18].item()) != 0:
-            raise RuntimeError("PeerComm: a wait for a peer timed out (rank %d)" % self.rank)
+            if clear:
+                words[18] = 0
+            raise RuntimeError("PeerComm: a wait for a peer timed out (rank %d); the affected collectives returned NaN" % self.rank)
+
+    def resync(self):
+        """Call after a step was abandoned half way (e.g. a failed graph capture): the slot parity is a host-side counter
+        baked into captured launches, and every rank must restart a step on the same (even) parity."""
+        if self._call & 1:
+            self._call += 1
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001  (interpreter shutdown: the library may already be gone)
+            pass
 
     def close(self):
         from . import _lib
         lib = _lib.lib()
-        for q in self._mapped:
+        for q in getattr(self, "_mapped", []):
             lib.omni_tp_ipc_close(q)
         self._mapped = []
-        if self._own:
+        if getattr(self, "_own", None):
             lib.omni_tp_free(self._own)
             self._own = None

@@ -130,3 +130,19 @@ def test_gemm_plans_of_the_baseline_decode_shapes():
     assert lib.omni_gemm_rowfree_ok(16, 5120, 5120, 13824, 0) == 0         # Llama-2-13B-shaped: level 2
     assert lib.omni_gemm_rowfree_ok(17, 4096, 4096, 14336, 0) == 0         # more than the 16-row tile
     assert lib.omni_gemm_rowfree_ok(16, 512, 512, 1024, 0) == 0            # more rows than hidden / 64 rider workgroups
+
+
+def test_release_library_reads_no_environment():
+    """Release hygiene: the planner / debug knobs (OMNI_GEMV_DBG, OMNI_GEMV_NARROW, ...) exist only in
+    -DOMNI_TUNING builds; the shipped library neither imports getenv nor carries their names."""
+    import shutil
+    import subprocess
+    from omniserve_amd import _lib
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    syms = subprocess.run([nm, "-D", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for knob in (b"OMNI_GEMV_DBG", b"OMNI_GEMV_NARROW", b"OMNI_DEFERRED_PART", b"OMNI_W8_SMALL_SPLIT", b"OMNI_GEMM_EXACT",
+                 b"OMNI_DECODE_RT", b"OMNI_PREFETCH_DELAY"):
+        assert knob not in blob, knob
+    assert not hasattr(_lib.lib(), "omni_gemm_set_weight_policy")      # the load policy is per call (omni_prefetch_arm_gemm)

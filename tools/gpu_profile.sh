@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-3 profile pass: per-kernel table of the decode step (level 3), PMC traffic of the gate_up kernel, bench constants
+# profile pass (tools/gpu_call.sh TAG profile): per-kernel table of the decode step (level 3), PMC traffic of the gate_up kernel, bench constants
 cd "$(dirname "$0")/.."
 R=$PWD
 TAG=${1:-r03_a}

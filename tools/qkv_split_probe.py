@@ -17,7 +17,6 @@ for (N, K) in [(6144, 4096), (4096, 4096)]:
     sw = torch.full((N,), 0.01, dtype=torch.float16, device=dev); sz = sw.clone()
     sa = torch.full((M,), 0.01, dtype=torch.float16, device=dev); asum = sa.clone()
     out = torch.empty((M, N), dtype=torch.float16, device=dev)
-    lib.omni_gemm_set_weight_policy(1)      # plain (not non-temporal) weight loads, as in the step when prefetched
     us = graph_time_us(lambda i: qgemm_w4a8_per_chn.gemm_forward_cuda(a, w, sw, sa, sz, asum, out), 32)
     print("N=%d K=%d one kernel (default plan)          : %6.2f us" % (N, K, us), flush=True)
     for kw in (4, 2, 1):
@@ -28,4 +27,3 @@ for (N, K) in [(6144, 4096), (4096, 4096)]:
             us1 = graph_time_us(lambda i: fused_ext.gemm_partial_per_chn(a, w, slab), 32)
             print("N=%d K=%d slab only kw=%d sk=%d (%4d workgroups): %6.2f us" % (N, K, kw, sk, N // 64 * sk, us1), flush=True)
     lib.omni_gemm_set_plan_override(0, 0)
-    lib.omni_gemm_set_weight_policy(0)
