@@ -14,6 +14,7 @@
 // fallback for row lengths the v2 geometry does not cover.)
 #include "common.h"
 #include "row_reduce.h"
+#include "row_kernels.h"
 #include "tp_comm.h"
 #include <cstdlib>
 
@@ -283,86 +284,7 @@ struct SrcAdd {  // residual += delta (fp16 add), in place
     *reinterpret_cast<v8h*>(res + i) = o;
   }
 };
-// ZP = true: the per-channel W4A8 epilogue ((acc*sw)*sa) - (sz*asum); ZP = false: the W8A8 / per-group one acc*(sw*sa)
-template <bool ZP>
-struct SrcSlabAddT {  // residual += h(GEMM epilogue(sum of split-K slabs)), in place
-  static constexpr bool BATCH = false;   // 76 registers per vector: fetched per valid vector (hidden <= 4096: one)
-  struct Raw { v4i s0, s1; v8h a, sw, sz; };
-  half_t* res;
-  const int32_t* slab;    // [sk][M][N]
-  size_t sstride;         // M*N
-  int sk, stride;         // stride = N = hidden
-  const half_t* wscales;  // [N]
-  const half_t* wsz;      // [N]
-  const half_t* ascales;  // [M] scales / sums of the GEMM's int8 input
-  const half_t* asum;
-  float sa, as;
-  __device__ __forceinline__ SrcSlabAddT at_row(int m) const {
-    SrcSlabAddT r = *this;
-    r.res = res + (size_t)m * stride;
-    r.slab = slab + (size_t)m * stride;
-    r.sa = (float)ascales[m];
-    if constexpr (ZP) r.as = (float)asum[m];
-    return r;
-  }
-  __device__ __forceinline__ void fetch(int i, Raw& r) const {
-    r.a = *reinterpret_cast<const v8h*>(res + i);
-    r.sw = *reinterpret_cast<const v8h*>(wscales + i);
-    if constexpr (ZP) r.sz = *reinterpret_cast<const v8h*>(wsz + i);
-    v4i s0 = (v4i){0, 0, 0, 0}, s1 = s0;
-    {  // up to 8 slabs: all loads in flight at once (slabs beyond sk re-read slab 0 and are dropped)
-      v4i t0[8], t1[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const size_t off = (size_t)(k < sk ? k : 0) * sstride + i;
-        t0[k] = *reinterpret_cast<const v4i*>(slab + off);
-        t1[k] = *reinterpret_cast<const v4i*>(slab + off + 4);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        s0 += k < sk ? t0[k] : (v4i){0, 0, 0, 0};
-        s1 += k < sk ? t1[k] : (v4i){0, 0, 0, 0};
-      }
-    }
-    // slabs beyond 8 (the W8A8 down projection of the LServe driver leaves 14): further batches of 8 -- a plain loop made
-    // every slab a dependent round trip for the one workgroup of a batch-1 row.  Integer sums: any order is exact.
-    for (int k0 = 8; k0 < sk; k0 += 8) {
-      v4i t0[8], t1[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const size_t off = (size_t)(k0 + k < sk ? k0 + k : 0) * sstride + i;
-        t0[k] = *reinterpret_cast<const v4i*>(slab + off);
-        t1[k] = *reinterpret_cast<const v4i*>(slab + off + 4);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        s0 += k0 + k < sk ? t0[k] : (v4i){0, 0, 0, 0};
-        s1 += k0 + k < sk ? t1[k] : (v4i){0, 0, 0, 0};
-      }
-    }
-    r.s0 = s0; r.s1 = s1;
-  }
-  __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
-    v8h o;
-#pragma unroll
-    for (int e = 0; e < VT; ++e) {
-      const int acc = e < 4 ? r.s0[e] : r.s1[e - 4];
-      half_t ep;                                               // = the GEMM's fp16 output (qgemm_kernel.h: epilogue<>)
-      if constexpr (ZP) {
-        float t = (float)acc * (float)r.sw[e];
-        t = t * sa;
-        const float c = (float)r.sz[e] * as;
-        ep = (half_t)(t - c);
-      } else {
-        const float sc = (float)r.sw[e] * sa;
-        ep = (half_t)((float)acc * sc);
-      }
-      o[e] = (half_t)((float)r.a[e] + (float)ep);
-      x[e] = (float)o[e];
-    }
-    *reinterpret_cast<v8h*>(res + i) = o;
-  }
-};
+// (SrcSlabAddT -- residual += h(GEMM epilogue(sum of split-K slabs)) -- lives in row_kernels.h: the fused MLP launch uses it too)
 // tensor parallel: residual += h( sum over ranks of the peers' fp16 partial projections ) -- the all-reduce of
 // llama_w4a8_unpad.py's row-parallel outputs folded into the consumer (tp_comm.h)
 struct SrcPeerAdd {
@@ -388,8 +310,6 @@ struct SrcPeerAdd {
     *reinterpret_cast<v8h*>(res + i) = o;
   }
 };
-typedef SrcSlabAddT<true> SrcSlabAddChn;
-typedef SrcSlabAddT<false> SrcSlabAddW8;
 struct SrcSilu {  // h(h(silu(gate)) * up) of a [2d] row
   static constexpr bool BATCH = true;
   struct Raw { v8h a, b; };
@@ -560,96 +480,7 @@ __global__ __launch_bounds__(RT) void quant_v2_kernel(int8_t* __restrict__ out, 
   OMNI_CLK(13);
 }
 
-// rms_norm_general[_fuse_sum] (+ fused residual sources): NV = roundup32(min(hidden,1024))
-template <int RT, int RV, bool FUSE_SUM, typename Src>
-__device__ __forceinline__ void general_norm_v2_body(int8_t* __restrict__ out, const Src& src0, const half_t* __restrict__ gamma,
-                                                     half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,
-                                                     float eps, int hidden, int nv, float* xs, float* red) {
-  const int p = threadIdx.x;
-  OMNI_CLK(0);
-  const Src src = src0.at_row(blockIdx.x);
-  float x[RV][VT];
-  typename Src::Raw raw[Src::BATCH ? RV : 1];
-  v8h g8[RV];   // gamma is requested with the inputs, not after the statistics
-#pragma unroll
-  for (int it = 0; it < RV; ++it) {
-    const int i = (p + it * RT) * VT;
-    const int ic = i < hidden ? i : 0;
-    if constexpr (Src::BATCH) src.fetch(ic, raw[it]);
-    g8[it] = *reinterpret_cast<const v8h*>(gamma + ic);
-  }
-#pragma unroll
-  for (int it = 0; it < RV; ++it) {
-    const int i = (p + it * RT) * VT;
-    const bool ok = i < hidden;
-    if (ok) {
-      if constexpr (Src::BATCH) {
-        src.finish(i, raw[it], x[it]);
-      } else {
-        src.fetch(i, raw[0]);
-        src.finish(i, raw[0], x[it]);
-      }
-      *reinterpret_cast<v4f*>(xs + i) = (v4f){x[it][0], x[it][1], x[it][2], x[it][3]};
-      *reinterpret_cast<v4f*>(xs + i + 4) = (v4f){x[it][4], x[it][5], x[it][6], x[it][7]};
-    }
-  }
-  OMNI_CLK(1);
-  __syncthreads();
-  float st[2][VT], tv[2];
-  ordered_partials<2>(xs, p, nv, hidden, st, [](float (&v)[2][VT], int e, float val) {
-    v[0][e] = v[0][e] + val;
-    v[1][e] = v[1][e] + val * val;
-  });
-  OMNI_CLK(2);
-  tree_sum8<2>(st, red, p, nv >> 5, tv);   // first barrier inside: everyone is done reading xs
-  OMNI_CLK(3);
-  const float mean = tv[0] / (float)hidden;
-  const float rstd = 1.0f / __builtin_sqrtf(tv[1] / (float)hidden + eps);
-  float amax_h = (float)(half_t)1e-6f;
-#pragma unroll
-  for (int it = 0; it < RV; ++it) {
-    const int i = (p + it * RT) * VT;
-    const bool ok = i < hidden;
-    if (ok) {
-      float yh[VT];
-#pragma unroll
-      for (int e = 0; e < VT; ++e) {
-        float y = (x[it][e] - mean) * rstd;
-        y = rounded_f32(y * (float)g8[it][e]);
-        x[it][e] = y;
-        yh[e] = (float)(half_t)y;
-        amax_h = __builtin_fmaxf(amax_h, __builtin_fabsf(yh[e]));
-      }
-      if constexpr (FUSE_SUM) {
-        *reinterpret_cast<v4f*>(xs + i) = (v4f){yh[0], yh[1], yh[2], yh[3]};
-        *reinterpret_cast<v4f*>(xs + i + 4) = (v4f){yh[4], yh[5], yh[6], yh[7]};
-      }
-    }
-  }
-  OMNI_CLK(4);
-  const float amax = block_max_rt<RT>(amax_h, red);   // barriers publish the fp16-rounded y in xs
-  OMNI_CLK(5);
-  // the codes only need the maximum: their stores go out first and drain while the fp16 sum is replayed
-  if (p == 0) scale_out[blockIdx.x] = (half_t)(amax / 127.0f);
-  const float q = 127.0f / amax;
-  int8_t* orow = out + (size_t)blockIdx.x * hidden;
-#pragma unroll
-  for (int it = 0; it < RV; ++it) {
-    const int i = (p + it * RT) * VT;
-    if (i < hidden) store8_i8(orow + i, x[it], q);
-  }
-  OMNI_CLK(6);
-  if constexpr (FUSE_SUM) {
-    float hs[1][VT], tot[1];
-    ordered_partials<1>(xs, p, nv, hidden, hs, [](float (&v)[1][VT], int e, float val) {
-      v[0][e] = (float)(half_t)(v[0][e] + val);   // the reference accumulates this sum in fp16
-    });
-    tree_sum8<1>(hs, red, p, nv >> 5, tot);
-    if (p == 0) sum_out[blockIdx.x] = (half_t)tot[0];
-  }
-  OMNI_CLK(7);
-}
-
+// (general_norm_v2_body -- rms_norm_general[_fuse_sum] with a pluggable source and sink -- lives in row_kernels.h)
 template <int RT, int RV, bool FUSE_SUM, typename Src>
 __global__ __launch_bounds__(RT) void general_norm_v2_kernel(int8_t* __restrict__ out, Src src0, const half_t* __restrict__ gamma,
                                                               half_t* __restrict__ sum_out, half_t* __restrict__ scale_out,

@@ -44,14 +44,18 @@ __device__ __forceinline__ void tree_sum8(float (&v)[NQ][VT], float* red, int p,
   }
 }
 
-__device__ __forceinline__ void store8_i8(int8_t* dst, const float (&x)[VT], float q) {
+// the eight int8 codes rni_sat_s8(x[e] * q), packed little-endian
+__device__ __forceinline__ uint2 pack8_i8(const float (&x)[VT], float q) {
   uint32_t lo = 0, hi = 0;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     lo |= (uint32_t)(uint8_t)rni_sat_s8(x[e] * q) << (8 * e);
     hi |= (uint32_t)(uint8_t)rni_sat_s8(x[4 + e] * q) << (8 * e);
   }
-  *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+  return make_uint2(lo, hi);
+}
+__device__ __forceinline__ void store8_i8(int8_t* dst, const float (&x)[VT], float q) {
+  *reinterpret_cast<uint2*>(dst) = pack8_i8(x, q);
 }
 
 template <int RT>
