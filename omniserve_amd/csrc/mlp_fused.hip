@@ -34,8 +34,9 @@
 namespace omni {
 
 constexpr int MLP_WGS = 256;           // one workgroup per CU; all must be resident (they wait on each other)
-constexpr int MLP_THREADS = 256;
-constexpr int MLP_RING = 16;           // k-steps of packed weights in flight per wave
+constexpr int MLP_THREADS = 512;
+constexpr int MLP_WAVES = MLP_THREADS / 64;
+constexpr int MLP_RING = 8;            // k-steps of packed weights in flight per wave
 constexpr int MLP_SERVICE = 16;        // workgroups 0..15 run the norm row / rider of activation row blockIdx.x
 constexpr int MLP_SHARDS = 8;          // arrival counters / row-maximum words of hand-off 2
 // counter words (uint32, zeroed once per decode step): one 64-B line each
@@ -99,17 +100,26 @@ struct SinkLds {
   __device__ __forceinline__ void sum(half_t s) const { pair_lds[1] = __builtin_bit_cast(uint16_t, s); }
 };
 
-__global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpArgs a) {
+#ifndef MLP_ACQUIRE_FENCE
+#define MLP_ACQUIRE_FENCE 0      // 1: an agent-scope acquire (buffer_inv sc1, ~1.3 us) behind each hand-off's poll.  Not needed here:
+#endif                           // every hand-off buffer is first touched by its consumer AFTER the hand-off (no line of it can sit in
+                                 // the CU's L1 from earlier in the launch), its producers store write-through, polls bypass the L1
+
+// 512 threads = 8 waves = two per SIMD (each other's LDS / MFMA latencies overlap; one wave per SIMD measured 4.5-5 us per
+// 16-step round, profiles/r04_a): wave w owns the K eighth [512 w, 512 w + 512) of a gate_up unit (8 k-steps = its ring) and
+// the K eighth [256 w, +256) of each down unit (4 + 4 k-steps).  256 registers per wave: ring 64, B operands 32.
+__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // [0, 16 KiB): K-part partial sums (4 waves x 4 row blocks x 64 lanes x 16 B)   -- GEMV epilogues
-  // [16 KiB, ...): f32 copy of a row (norm: H floats; rider: I floats), then 4 KiB of int8 codes, then `red`
+  // [0, 32 KiB)   K-part partial sums of a GEMV epilogue (8 waves x 4 row blocks x 64 lanes x 16 B)
+  // [32 KiB, ...) f32 copy of a row (norm service: H floats + H bytes of codes; rider: I floats), then `red`, the {scale, sum}
+  //               pair and the row maxima of the waves
   v4i* part = reinterpret_cast<v4i*>(smem);
-  float* xs = reinterpret_cast<float*>(smem + 16384);
-  const int xs_floats = a.I > a.H ? a.I : a.H;
-  uint8_t* codes_lds = reinterpret_cast<uint8_t*>(xs + xs_floats);
-  float* red = reinterpret_cast<float*>(codes_lds + a.H);
+  float* xs = reinterpret_cast<float*>(smem + 32768);
+  const int xs_floats = a.I > a.H + a.H / 4 ? a.I : a.H + a.H / 4;
+  uint8_t* codes_lds = reinterpret_cast<uint8_t*>(xs + a.H);
+  float* red = xs + xs_floats;
   uint32_t* pair_lds = reinterpret_cast<uint32_t*>(red + 96);
-  float* smax = reinterpret_cast<float*>(pair_lds + 4);      // [4 waves][16 rows]
+  float* smax = reinterpret_cast<float*>(pair_lds + 4);      // [8 waves][16 rows]
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave = K part
@@ -123,14 +133,14 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpArgs a) {
   // ---- weight addressing (qgemm_kernel.h: lane -> tile row lx, chunk (n3 = lc, k6 = le)) -------------------------------
   const int lx = (lane >> 3) & 1, lc = lane & 7, le = lane >> 4;
   const size_t chunk = (size_t)(lc * 4 + le) * 16;
-  auto gu_base = [&](int u) -> const uint8_t* {      // this wave's 1024-k quarter of gate tile row u / up tile row U + u
+  auto gu_base = [&](int u) -> const uint8_t* {      // this wave's 512-k eighth of gate tile row u / up tile row U + u
     const size_t trow = lx ? (size_t)U + u : (size_t)u;
-    return a.Wgu + trow * (size_t)(a.H / 32) * 512 + (size_t)(w * (a.H / 4) / 32) * 512 + chunk;
+    return a.Wgu + trow * (size_t)(a.H / 32) * 512 + (size_t)(w * (a.H / MLP_WAVES) / 32) * 512 + chunk;
   };
-  auto dn_base = [&](int v) -> const uint8_t* {      // this wave's 512-k quarter of K part v / 64 of channel group v % 64
+  auto dn_base = [&](int v) -> const uint8_t* {      // this wave's 256-k eighth of K part v / 64 of channel group v % 64
     const int g = v & 63, pt = v >> 6;
     const size_t trow = (size_t)(2 * g + lx);
-    return a.Wdn + trow * (size_t)(a.I / 32) * 512 + (size_t)((pt * 2048 + w * 512) / 32) * 512 + chunk;
+    return a.Wdn + trow * (size_t)(a.I / 32) * 512 + (size_t)((pt * 2048 + w * (2048 / MLP_WAVES)) / 32) * 512 + chunk;
   };
   auto load_w = [&](const uint8_t* p) -> uint4 {
     const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
@@ -139,13 +149,16 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpArgs a) {
   const int uA = b, uB = G + (G - 1 - b);            // gate_up units of this workgroup (uB: heavy only)
   const int vA = b, vB = G + (G - 1 - b);            // down units
 
+  // the weight ring: 8 k-steps x 2 KiB per wave in registers (128 KiB per CU).  It is filled once here; from then on every
+  // round refills a step's registers for the NEXT round right after unpacking them -- gate_up unit A -> unit B -> the down
+  // units -- so the stream runs through both hand-offs.
+  constexpr int HR = MLP_RING / 2;
   uint4 wq[MLP_RING][2];
-  auto fill_ring = [&](const uint8_t* p0, const uint8_t* p1) {      // steps 0..7 from p0, 8..15 from p1 (contiguous: p1 = p0 + 8 KiB)
+  auto fill_ring = [&](const uint8_t* p0) {
 #pragma unroll
     for (int s = 0; s < MLP_RING; ++s) {
-      const uint8_t* p = s < 8 ? p0 + (size_t)s * 1024 : p1 + (size_t)(s - 8) * 1024;
-      wq[s][0] = load_w(p);
-      wq[s][1] = load_w(p + 512);
+      wq[s][0] = load_w(p0 + (size_t)s * 1024);
+      wq[s][1] = load_w(p0 + (size_t)s * 1024 + 512);
     }
   };
   auto unpack = [&](const uint4 (&wv)[2], v4i (&wa)[4]) {
@@ -162,23 +175,24 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpArgs a) {
       }
   };
 
-  // epilogue operands of the gate_up units (row block ab = w of each unit): requested now, used after the rounds
+  // epilogue operands of the gate_up units (waves 0..3 finish row block ab = w of each unit): requested now
   const int i0 = (lane >> 4) * 4;
-  auto gu_chan = [&](int u) -> int { return (i0 >> 3) * a.I + u * 32 + w * 8 + (i0 & 7); };       // gate | up channel
+  const int fab = w & 3;
+  auto gu_chan = [&](int u) -> int { return (i0 >> 3) * a.I + u * 32 + fab * 8 + (i0 & 7); };       // gate | up channel
   uint2 swA = *reinterpret_cast<const uint2*>(a.gu_ws + gu_chan(uA)), szA = *reinterpret_cast<const uint2*>(a.gu_wsz + gu_chan(uA));
   uint2 swB = swA, szB = szA;
   if (heavy) { swB = *reinterpret_cast<const uint2*>(a.gu_ws + gu_chan(uB)); szB = *reinterpret_cast<const uint2*>(a.gu_wsz + gu_chan(uB)); }
 
   // ---- P1: norm rows (service workgroups first, THEN their weight ring: their row loads must not queue behind 128 KiB of
   //      weights); everybody else starts streaming at once ---------------------------------------------------------------
-  if (!service) fill_ring(gu_base(uA), gu_base(uA) + 8 * 1024);
+  if (!service) fill_ring(gu_base(uA));
   if (service) {
     const int r = b;
     if (r < a.M) {
       SrcSlabAddChn src{a.res, a.o_slab, (size_t)a.M * a.H, a.sk_o, a.H, a.o_ws, a.o_wsz, a.o_as, a.o_asum, 0.f, 0.f};
       const SrcSlabAddChn row = src.at_row(r);
       SinkLds sink{codes_lds, pair_lds};
-      general_norm_v2_row<MLP_THREADS, 2, true, SrcSlabAddChn, SinkLds>(row, a.gamma, sink, a.eps, a.H, 1024, xs, red);
+      general_norm_v2_row<MLP_THREADS, 4, true, SrcSlabAddChn, SinkLds>(row, a.gamma, sink, a.eps, a.H, 1024, xs, red);
     } else {
       for (int i = tid; i < a.H / 4; i += MLP_THREADS) reinterpret_cast<uint32_t*>(codes_lds)[i] = 0u;
       if (tid == 0) { pair_lds[0] = 0u; pair_lds[1] = 0u; }
@@ -199,92 +213,106 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpArgs a) {
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(a.cnt + MLP_W_CNT1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     MLP_CLK(1);
-    fill_ring(gu_base(uA), gu_base(uA) + 8 * 1024);
+    fill_ring(gu_base(uA));
   }
 
   // ---- hand-off 1: all 16 rows published ----------------------------------------------------------------------------
   if (tid == 0) wait_ge(a.cnt + MLP_W_CNT1, MLP_SERVICE * epoch, a.cnt + MLP_W_ERR);
+#if MLP_ACQUIRE_FENCE
   if (w == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
   __syncthreads();
   MLP_CLK(2);
-  v4i breg[MLP_RING];                               // B operands of this wave's K quarter (both gate_up units)
+  v4i breg[MLP_RING];                               // B operands of this wave's K eighth (both gate_up units)
 #pragma unroll
   for (int s = 0; s < MLP_RING; ++s)
     breg[s] = *reinterpret_cast<const v4i*>(a.xq + ((size_t)(w * MLP_RING + s) * 64 + lane) * 16);
-  const uint32_t sbw = a.sbmb[lane & 15];
+  uint32_t sbw = a.sbmb[lane & 15];
+  // Everything the epilogues read from memory must be IN REGISTERS before the rounds start: hipcc otherwise sinks these
+  // small loads to their first use, i.e. behind a round's refills -- and a wait for them is then a wait for the whole ring
+  // (loads return in order): measured, every round ended on a 5-us drain of its own prefetch (profiles/r04_a).
+  asm volatile("" : "+v"(sbw), "+v"(swA.x), "+v"(swA.y), "+v"(szA.x), "+v"(szA.y), "+v"(swB.x), "+v"(swB.y), "+v"(szB.x), "+v"(szB.y));
   const float sa = (float)__builtin_bit_cast(half_t, (uint16_t)(sbw & 0xFFFFu));
   const float as = (float)__builtin_bit_cast(half_t, (uint16_t)(sbw >> 16));
+#pragma unroll
+  for (int s = 0; s < MLP_RING; ++s) asm volatile("" : "+v"(breg[s]));
 
   // ---- P2: gate_up units ---------------------------------------------------------------------------------------------
   float rowmax = 0.0f;                              // max |act| of row (lane & 15) over the channels this lane finished
-  auto gu_round = [&](auto refill_tag, const uint8_t* nbase, v4i (&acc)[4]) {
-    constexpr bool REFILL = decltype(refill_tag)::value;
+  // one round = the 8 ring steps of one gate_up unit; the ring is refilled with the next round's weights: steps 0..3 from
+  // n0, 4..7 from n1 (gate_up unit: n1 = n0 + 4 KiB; down units: the two units' bases)
+  auto gu_round = [&](const uint8_t* n0, const uint8_t* n1, v4i (&acc)[4]) {
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) acc[ab] = (v4i){0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < MLP_RING; ++s) {
       v4i wa[4];
       unpack(wq[s], wa);
-      if constexpr (REFILL) {
-        wq[s][0] = load_w(nbase + (size_t)s * 1024);
-        wq[s][1] = load_w(nbase + (size_t)s * 1024 + 512);
-      }
+      const uint8_t* np = s < HR ? n0 + (size_t)s * 1024 : n1 + (size_t)(s - HR) * 1024;
+      wq[s][0] = load_w(np);
+      wq[s][1] = load_w(np + 512);
+      // keep the refill HERE, a whole round ahead of its use (left alone hipcc sinks every refill behind the round's last MFMA)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ab = 0; ab < 4; ++ab) acc[ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], breg[s], acc[ab], 0, 0, 0);
     }
   };
-  // K parts meet in LDS; wave w finishes row block ab = w: epilogue, silu_and_mul, fp16 activation in operand order
+  // K parts meet in LDS; waves 0..3 finish row block ab = w: epilogue, silu_and_mul, fp16 activation in operand order
   auto gu_finish = [&](const v4i (&acc)[4], int u, uint2 swv, uint2 szv) {
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) part[(w * 4 + ab) * 64 + lane] = acc[ab];
     __syncthreads();
-    v4i a4 = (v4i){0, 0, 0, 0};
+    if (w < 4) {
+      v4i a4 = (v4i){0, 0, 0, 0};
 #pragma unroll
-    for (int ww = 0; ww < 4; ++ww) a4 += part[(ww * 4 + w) * 64 + lane];
+      for (int ww = 0; ww < MLP_WAVES; ++ww) a4 += part[(ww * 4 + w) * 64 + lane];
+      typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
+      const v4h_t sw4 = __builtin_bit_cast(v4h_t, swv), sz4 = __builtin_bit_cast(v4h_t, szv);
+      half_t o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = epilogue<MODE_CHN>(a4[r], (float)sw4[r], sa, (float)sz4[r], as);
+      // lanes < 32 hold the fp16 gate outputs, lanes >= 32 the up outputs of the same (row, 4 channels)
+      const uint2 mine = *reinterpret_cast<const uint2*>(o);
+      const uint2 other = make_uint2((uint32_t)__shfl_xor((int)mine.x, 32, 64), (uint32_t)__shfl_xor((int)mine.y, 32, 64));
+      const uint2 g2 = lane < 32 ? mine : other, u2 = lane < 32 ? other : mine;
+      const v4h_t g4 = __builtin_bit_cast(v4h_t, g2), u4 = __builtin_bit_cast(v4h_t, u2);
+      half_t act[4];
+      float mx = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        act[r] = silu_mul_h(g4[r], u4[r]);
+        mx = __builtin_fmaxf(mx, __builtin_fabsf((float)act[r]));
+      }
+      rowmax = __builtin_fmaxf(rowmax, mx);
+      if (lane < 32) {
+        // activation channels n .. n + 3 of row m: k-step n / 64 of down_proj, piece j = (n % 64) / 16, slot e = (n % 16) / 4
+        const int n = u * 32 + w * 8 + (i0 & 7), m = lane & 15;
+        const int s = n >> 6, j = (n >> 4) & 3, e = (n >> 2) & 3;
+        st_agent64(a.act + ((size_t)s * 64 + (m + 16 * e)) * 16 + 4 * j, *reinterpret_cast<const uint64_t*>(act));
+      }
+    }
     __syncthreads();                                // (the next unit's partials may overwrite)
-    typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
-    const v4h_t sw4 = __builtin_bit_cast(v4h_t, swv), sz4 = __builtin_bit_cast(v4h_t, szv);
-    half_t o[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = epilogue<MODE_CHN>(a4[r], (float)sw4[r], sa, (float)sz4[r], as);
-    // lanes < 32 hold the fp16 gate outputs, lanes >= 32 the up outputs of the same (row, 4 channels)
-    const uint2 mine = *reinterpret_cast<const uint2*>(o);
-    const uint2 other = make_uint2((uint32_t)__shfl_xor((int)mine.x, 32, 64), (uint32_t)__shfl_xor((int)mine.y, 32, 64));
-    const uint2 g2 = lane < 32 ? mine : other, u2 = lane < 32 ? other : mine;
-    const v4h_t g4 = __builtin_bit_cast(v4h_t, g2), u4 = __builtin_bit_cast(v4h_t, u2);
-    half_t act[4];
-    float mx = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      act[r] = silu_mul_h(g4[r], u4[r]);
-      mx = __builtin_fmaxf(mx, __builtin_fabsf((float)act[r]));
-    }
-    rowmax = __builtin_fmaxf(rowmax, mx);
-    if (lane < 32) {
-      // activation channels n .. n + 3 of row m: k-step n / 64 of down_proj, piece j = (n % 64) / 16, slot e = (n % 16) / 4
-      const int n = u * 32 + w * 8 + (i0 & 7), m = lane & 15;
-      const int s = n >> 6, j = (n >> 4) & 3, e = (n >> 2) & 3;
-      st_agent64(a.act + ((size_t)s * 64 + (m + 16 * e)) * 16 + 4 * j, *reinterpret_cast<const uint64_t*>(act));
-    }
   };
+  const uint8_t* dnA = dn_base(vA);
+  const uint8_t* dnB = dn_base(heavy ? vB : vA);    // (light: the second half of the ring re-reads unit A, unused)
   {
     v4i acc[4];
     if (heavy) {
-      gu_round(BoolTag<true>{}, gu_base(uB), acc);
+      gu_round(gu_base(uB), gu_base(uB) + HR * 1024, acc);
       gu_finish(acc, uA, swA, szA);
       MLP_CLK(3);
-      gu_round(BoolTag<false>{}, nullptr, acc);
+      gu_round(dnA, dnB, acc);
       gu_finish(acc, uB, swB, szB);
     } else {
-      gu_round(BoolTag<false>{}, nullptr, acc);
+      gu_round(dnA, dnB, acc);
       gu_finish(acc, uA, swA, szA);
       MLP_CLK(3);
     }
   }
-  // ---- hand-off 2: arrive (row maxima raised, activation written through), re-arm the ring with the down units, wait ----
+  // ---- hand-off 2: arrive (row maxima raised, activation written through), wait -----------------------------------------
   {
     const float v = rows4_max(rowmax);
-    if (lane < 16) smax[w * 16 + lane] = v;
+    if (lane < 16) smax[w * 16 + lane] = v;         // (waves 4..7 never finished a channel: zeros)
     __syncthreads();
     if (tid < 16) {
       float mxr = smax[tid];
@@ -293,15 +321,16 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpArgs a) {
       __hip_atomic_fetch_max(a.amax + (b & (MLP_SHARDS - 1)) * 16 + tid, __builtin_bit_cast(uint32_t, mxr), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
     }
-    drain_vmem();
+    drain_vmem();                                   // (also the last refills of the ring: issued during the round)
     __syncthreads();
     if (tid == 0)
       __hip_atomic_fetch_add(a.cnt + MLP_W_CNT2 + 16 * (b & (MLP_SHARDS - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   MLP_CLK(4);
-  fill_ring(dn_base(vA), dn_base(heavy ? vB : vA));
   if (tid < MLP_SHARDS) wait_ge(a.cnt + MLP_W_CNT2 + 16 * tid, (uint32_t)(G / MLP_SHARDS) * epoch, a.cnt + MLP_W_ERR);
+#if MLP_ACQUIRE_FENCE
   if (w == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
   __syncthreads();
   MLP_CLK(5);
   // row maxima -> 127 / amax of row (lane & 15)
@@ -315,41 +344,50 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpArgs a) {
   const float qlane = quant_multiplier(amax_row);
 
   // ---- P3: down units (fp16 activation slice quantised on the fly -> int32 split-K slab of K part v / 64) ---------------
-  auto dn_unit = [&](int v, auto half_tag) {
-    constexpr int S0 = decltype(half_tag)::value ? 8 : 0;        // ring steps S0 .. S0 + 7
-    const int g = v & 63, pt = v >> 6;
-    const int ks0 = (pt * 2048 + w * 512) / 64;                  // first k-step of this wave's quarter
-    uint4 raw[8][2];
+  // B operands: both units' slices of this wave (4 + 4 k-steps) requested together, quantised into 32 registers
+  v4i bq[MLP_RING];
+  {
+    uint4 raw[MLP_RING][2];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const half_t* src = a.act + ((size_t)(ks0 + s) * 64 + lane) * 16;
+    for (int s = 0; s < MLP_RING; ++s) {
+      const int v = (s < HR || !heavy) ? vA : vB;
+      const int ks = ((v >> 6) * 2048 + w * (2048 / MLP_WAVES)) / 64 + (s & (HR - 1));
+      const half_t* src = a.act + ((size_t)ks * 64 + lane) * 16;
       raw[s][0] = *reinterpret_cast<const uint4*>(src);
       raw[s][1] = *reinterpret_cast<const uint4*>(src + 8);
     }
+#pragma unroll
+    for (int s = 0; s < MLP_RING; ++s)
+      bq[s] = (v4i){(int)quant4_f16(raw[s][0].x, raw[s][0].y, qlane), (int)quant4_f16(raw[s][0].z, raw[s][0].w, qlane),
+                    (int)quant4_f16(raw[s][1].x, raw[s][1].y, qlane), (int)quant4_f16(raw[s][1].z, raw[s][1].w, qlane)};
+  }
+  auto dn_unit = [&](int v, auto half_tag) {
+    constexpr int S0 = decltype(half_tag)::value ? HR : 0;       // ring steps S0 .. S0 + 3
+    const int g = v & 63, pt = v >> 6;
     v4i acc[4];
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) acc[ab] = (v4i){0, 0, 0, 0};
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const v4i bq = (v4i){(int)quant4_f16(raw[s][0].x, raw[s][0].y, qlane), (int)quant4_f16(raw[s][0].z, raw[s][0].w, qlane),
-                           (int)quant4_f16(raw[s][1].x, raw[s][1].y, qlane), (int)quant4_f16(raw[s][1].z, raw[s][1].w, qlane)};
+    for (int s = 0; s < HR; ++s) {
       v4i wa[4];
       unpack(wq[S0 + s], wa);
 #pragma unroll
-      for (int ab = 0; ab < 4; ++ab) acc[ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bq, acc[ab], 0, 0, 0);
+      for (int ab = 0; ab < 4; ++ab) acc[ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bq[S0 + s], acc[ab], 0, 0, 0);
     }
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) part[(w * 4 + ab) * 64 + lane] = acc[ab];
     __syncthreads();
-    v4i a4 = (v4i){0, 0, 0, 0};
+    if (w < 4) {
+      v4i a4 = (v4i){0, 0, 0, 0};
 #pragma unroll
-    for (int ww = 0; ww < 4; ++ww) a4 += part[(ww * 4 + w) * 64 + lane];
-    __syncthreads();
-    const int m = lane & 15;
-    if (m < a.M) {
-      const int n = g * 64 + (i0 >> 3) * 32 + w * 8 + (i0 & 7);
-      *reinterpret_cast<v4i*>(a.dn_slab + ((size_t)pt * a.M + m) * a.H + n) = a4;
+      for (int ww = 0; ww < MLP_WAVES; ++ww) a4 += part[(ww * 4 + w) * 64 + lane];
+      const int m = lane & 15;
+      if (m < a.M) {
+        const int n = g * 64 + (i0 >> 3) * 32 + w * 8 + (i0 & 7);
+        *reinterpret_cast<v4i*>(a.dn_slab + ((size_t)pt * a.M + m) * a.H + n) = a4;
+      }
     }
+    __syncthreads();
   };
   dn_unit(vA, BoolTag<false>{});
   if (heavy) dn_unit(vB, BoolTag<true>{});
@@ -398,6 +436,7 @@ extern "C" size_t omni_mlp_fused_scratch_bytes(int hidden, int inter) {
 // and a device whose 256 CUs can hold the 256 workgroups together.
 extern "C" int omni_mlp_fused_ok(int M, int hidden, int inter) {
   if (M < 1 || M > 16 || hidden != 4096 || inter % 2048 != 0 || inter / 32 < MLP_WGS || inter / 32 > 2 * MLP_WGS) return 0;
+  if ((size_t)inter * 4 > 120 * 1024) return 0;                                  // a row as f32 in LDS
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
@@ -438,8 +477,10 @@ extern "C" int omni_w4a8_per_chn_mlp_fused(void* residual_f16, const void* o_sla
   a.M = M; a.H = hidden; a.I = inter; a.phase = phase;
   *sk_out = sk;
   // > 80 KiB of LDS per workgroup: one workgroup per CU whatever the register allocation (they wait on each other)
-  const size_t xs_floats = (size_t)(inter > hidden ? inter : hidden);
-  size_t lds = 16384 + xs_floats * 4 + hidden + 96 * 4 + 16 + 64 * 4;
+  // 32 KiB of partial sums + a row as f32 + reduction scratch, asked for as at least 96 KiB: more than half a CU's LDS, i.e.
+  // one workgroup per CU whatever the register allocation (they wait on each other)
+  const size_t xs_floats = (size_t)(inter > hidden + hidden / 4 ? inter : hidden + hidden / 4);
+  size_t lds = 32768 + xs_floats * 4 + 96 * 4 + 16 + 8 * 16 * 4;
   if (lds < 96 * 1024) lds = 96 * 1024;
   static bool attr_set = false;
   if (!attr_set) {

@@ -8,9 +8,11 @@
 namespace omni {
 
 // ZP = true: the per-channel W4A8 epilogue ((acc*sw)*sa) - (sz*asum); ZP = false: the W8A8 / per-group one acc*(sw*sa)
-template <bool ZP>
+// BATCH_: all of a thread's vectors fetched back to back before any arithmetic (76 registers per vector: the stand-alone row
+// kernels run one vector per thread and leave it off; the fused MLP launch's 256-thread service rows hold two)
+template <bool ZP, bool BATCH_ = false>
 struct SrcSlabAddT {  // residual += h(GEMM epilogue(sum of split-K slabs)), in place
-  static constexpr bool BATCH = false;   // 76 registers per vector: fetched per valid vector (hidden <= 4096: one)
+  static constexpr bool BATCH = BATCH_;
   struct Raw { v4i s0, s1; v8h a, sw, sz; };
   half_t* res;
   const int32_t* slab;    // [sk][M][N]

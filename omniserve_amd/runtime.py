@@ -148,10 +148,14 @@ class DecodeRunner:
         # applies silu_and_mul in its epilogue and leaves the row maxima, the attention merge is a wide kernel that
         # leaves fp16 + row maxima, and o_proj / down_proj quantise their input on the fly (fused_ext.gemm_silu_*,
         # decode_attention_f16_amax, gemm_partial_f16_*): 7 kernels per layer instead of 9, same bits.
-        # 4 (default where it applies: per-channel weights, batch <= 16, hidden 4096, one GPU with 256 CUs) = level 3 with
-        # the MLP half of every layer -- add + norm + quant, gate_up + SiLU, down -- as ONE persistent launch with in-kernel
-        # hand-offs (fused_ext.mlp_fused_per_chn, csrc/mlp_fused.hip): 5 launches per layer, same bits.
-        self.fused = 4 if fused is True else int(fused)
+        # 3 is the default (fused=True) where it applies: batch <= 16, one GPU.
+        # 4 (opt-in; per-channel weights, batch <= 16, hidden 4096, one GPU with 256 CUs) = level 3 with the MLP half of every
+        # layer -- add + norm + quant, gate_up + SiLU, down -- as ONE persistent launch with in-kernel hand-offs
+        # (fused_ext.mlp_fused_per_chn, csrc/mlp_fused.hip): 5 launches per layer, same bits.  Measured SLOWER than level 3
+        # in the step (2.37 vs 2.17 ms, profiles/r04_a_*: the launch is bound by the per-CU miss rate x what 128 KiB of
+        # registers per CU can hold ahead of a hand-off, which is what the L2 prefetch of the launch-per-kernel path already
+        # buys), so it is not the default.
+        self.fused = 3 if fused is True else int(fused)
         # the attention-side fusions of level 2 (split merge inside the quantiser, q / k / v from the qkv projection's slabs)
         # involve no row-parallel projection, so they also apply under tensor parallelism, where the level drops to 1
         self.l2_attn = self.fused >= 2 and batch <= 128 and os.environ.get("OMNI_TP_L2_ATTN", "1") != "0"

@@ -2,7 +2,7 @@
 # One parametrised runner for a gpurun call (replaces the per-call scripts of rounds 1-3, kept under tools/archive/ because
 # profiles/*.md cite them by name).  Usage, from the repo root on the GPU box:
 #     tools/gpu_call.sh TAG RECIPE [RECIPE ...]
-# Recipes (each writes gpurun_out/TAG/<recipe>.log and prints its tail):
+# Recipes (recipe number i writes gpurun_out/TAG/<i>_<recipe>.log and prints its tail):
 #     suite            python -m pytest tests -m gpu -x -q
 #     suite:EXPR       ... -k EXPR
 #     smoke            __graft_entry__.smoke()
@@ -16,9 +16,11 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
+i=0
 for r in "$@"; do
+  i=$((i + 1))
   name=${r%%:*}; arg=""; [[ "$r" == *:* ]] && arg=${r#*:}
-  log=$O/$(echo "$name" | tr -c 'A-Za-z0-9_\n' '_').log
+  log=$O/${i}_$(echo "$name" | tr -c 'A-Za-z0-9_\n' '_').log
   case $name in
     suite)   if [ -n "$arg" ]; then (time timeout 1500 python -m pytest tests -m gpu -x -q -k "$arg" 2>&1 | tail -15) > $log 2>&1
              else (time timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15) > $log 2>&1; fi ;;
