@@ -106,18 +106,27 @@ struct SinkLds {
                                  // the CU's L1 from earlier in the launch), its producers store write-through, polls bypass the L1
 
 // 512 threads = 8 waves = two per SIMD (each other's LDS / MFMA latencies overlap; one wave per SIMD measured 4.5-5 us per
-// 16-step round, profiles/r04_a): wave w owns the K eighth [512 w, 512 w + 512) of a gate_up unit (8 k-steps = its ring) and
-// the K eighth [256 w, +256) of each down unit (4 + 4 k-steps).  256 registers per wave: ring 64, B operands 32.
+// 16-step round, profiles/r04_a): wave w owns the K eighth [512 w, 512 w + 512) of a gate_up unit (8 k-steps) and the K eighth
+// [256 w, +256) of each down unit (4 + 4 k-steps).
+// Two buffer levels per wave, 16 KiB each (256 KiB per CU, 64 MiB on the chip -- a round that REFILLS from memory is paced by
+// the CU's miss path, 5 us per 128 KiB, so every byte that can be on the chip before a hand-off resolves is time saved):
+//   * a LANDING SLOT in LDS, filled by LDS-DMA (global_load_lds: no registers, hidden from hipcc -- the wave counts its own
+//     vmcnt: the DMAs are waited for with vmcnt(0) at points where everything older has to be complete anyway);
+//   * the register ring (64 VGPRs) the MFMAs are fed from, refilled from the landing slot (ds_read) step by step.
+// Stream of a heavy wave: unit A -> slot -> registers at once; unit B -> slot (lands during the norm / hand-off 1); round A
+// consumes the registers and pulls B out of the slot, re-arming the slot with the down units' steps; round B consumes B;
+// the down units are consumed straight from the slot after hand-off 2.
 __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // [0, 32 KiB)   K-part partial sums of a GEMV epilogue (8 waves x 4 row blocks x 64 lanes x 16 B)
-  // [32 KiB, ...) f32 copy of a row (norm service: H floats + H bytes of codes; rider: I floats), then `red`, the {scale, sum}
-  //               pair and the row maxima of the waves
+  // [0, 16 KiB)        partial sums of a GEMV epilogue, combined in two stages (waves 4..7 -> waves 0..3 -> row-block owners)
+  // [16 KiB, +128 KiB) the 8 landing slots; before the first DMA (service workgroups) the norm row's f32 copy + int8 codes live
+  //                    here, after the last down unit the rider's f32 copy of an activation row
+  // then `red`, the {scale, sum} pair and the row maxima of the waves
   v4i* part = reinterpret_cast<v4i*>(smem);
-  float* xs = reinterpret_cast<float*>(smem + 32768);
-  const int xs_floats = a.I > a.H + a.H / 4 ? a.I : a.H + a.H / 4;
+  uint8_t* slots = smem + 16384;
+  float* xs = reinterpret_cast<float*>(slots);
   uint8_t* codes_lds = reinterpret_cast<uint8_t*>(xs + a.H);
-  float* red = xs + xs_floats;
+  float* red = reinterpret_cast<float*>(slots + 131072);
   uint32_t* pair_lds = reinterpret_cast<uint32_t*>(red + 96);
   float* smax = reinterpret_cast<float*>(pair_lds + 4);      // [8 waves][16 rows]
 
@@ -142,25 +151,29 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
     const size_t trow = (size_t)(2 * g + lx);
     return a.Wdn + trow * (size_t)(a.I / 32) * 512 + (size_t)((pt * 2048 + w * (2048 / MLP_WAVES)) / 32) * 512 + chunk;
   };
-  auto load_w = [&](const uint8_t* p) -> uint4 {
-    const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
-    return make_uint4((uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
-  };
   const int uA = b, uB = G + (G - 1 - b);            // gate_up units of this workgroup (uB: heavy only)
   const int vA = b, vB = G + (G - 1 - b);            // down units
+  const uint8_t* dnA = dn_base(vA);
+  const uint8_t* dnB = dn_base(heavy ? vB : vA);     // (light: the second half of the slot re-reads unit A, unused)
 
-  // the weight ring: 8 k-steps x 2 KiB per wave in registers (128 KiB per CU).  It is filled once here; from then on every
-  // round refills a step's registers for the NEXT round right after unpacking them -- gate_up unit A -> unit B -> the down
-  // units -- so the stream runs through both hand-offs.
   constexpr int HR = MLP_RING / 2;
-  uint4 wq[MLP_RING][2];
-  auto fill_ring = [&](const uint8_t* p0) {
+  uint8_t* slot = slots + (size_t)w * 16384;         // this wave's landing slot: [k-step][tile 0 | 1][64 lanes x 16 B]
+  const uint8_t* slot_l = slot + (size_t)lane * 16;
+  // steps [s0, s1) of the slot <- 2 KiB per step from p0 (steps 0..3) / p1 (steps 4..7), nobody but this wave reads the slot
+  auto dma_steps = [&](const uint8_t* p0, const uint8_t* p1, int s0, int s1) {
 #pragma unroll
     for (int s = 0; s < MLP_RING; ++s) {
-      wq[s][0] = load_w(p0 + (size_t)s * 1024);
-      wq[s][1] = load_w(p0 + (size_t)s * 1024 + 512);
+      if (s < s0 || s >= s1) continue;
+      const uint8_t* p = s < HR ? p0 + (size_t)s * 1024 : p1 + (size_t)(s - HR) * 1024;
+      lds_dma16_untracked(p, slot + (size_t)(2 * s) * 1024);
+      lds_dma16_untracked(p + 512, slot + (size_t)(2 * s + 1) * 1024);
     }
   };
+  auto slot_step = [&](int s, uint4 (&wv)[2]) {
+    wv[0] = *reinterpret_cast<const uint4*>(slot_l + (size_t)(2 * s) * 1024);
+    wv[1] = *reinterpret_cast<const uint4*>(slot_l + (size_t)(2 * s + 1) * 1024);
+  };
+  uint4 wq[MLP_RING][2];
   auto unpack = [&](const uint4 (&wv)[2], v4i (&wa)[4]) {
     const uint4 t0 = wv[0], t1 = wv[1];
     const uint32_t d[2][4] = {{t0.x, t0.z, t1.x, t1.z}, {t0.y, t0.w, t1.y, t1.w}};
@@ -174,6 +187,16 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
         wa[x * 2 + y] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
       }
   };
+  // unit A -> slot -> registers; then the slot is re-armed with the next unit (heavy: gate_up unit B; light: the down units)
+  auto start_stream = [&]() {
+    dma_steps(gu_base(uA), gu_base(uA) + HR * 1024, 0, MLP_RING);
+    drain_vmem();
+#pragma unroll
+    for (int s = 0; s < MLP_RING; ++s) slot_step(s, wq[s]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the slot has been read: the DMAs below may overwrite it)
+    if (heavy) dma_steps(gu_base(uB), gu_base(uB) + HR * 1024, 0, MLP_RING);
+    else dma_steps(dnA, dnB, 0, MLP_RING);
+  };
 
   // epilogue operands of the gate_up units (waves 0..3 finish row block ab = w of each unit): requested now
   const int i0 = (lane >> 4) * 4;
@@ -183,9 +206,9 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
   uint2 swB = swA, szB = szA;
   if (heavy) { swB = *reinterpret_cast<const uint2*>(a.gu_ws + gu_chan(uB)); szB = *reinterpret_cast<const uint2*>(a.gu_wsz + gu_chan(uB)); }
 
-  // ---- P1: norm rows (service workgroups first, THEN their weight ring: their row loads must not queue behind 128 KiB of
-  //      weights); everybody else starts streaming at once ---------------------------------------------------------------
-  if (!service) fill_ring(gu_base(uA));
+  // ---- P1: norm rows (service workgroups first, THEN their stream: their row loads must not queue behind the weights, and
+  //      the row lives where the slots are); everybody else starts streaming at once ------------------------------------------
+  if (!service) start_stream();
   if (service) {
     const int r = b;
     if (r < a.M) {
@@ -210,10 +233,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
     if (tid == 0)
       __hip_atomic_store(a.sbmb + r, pair_lds[0] | (pair_lds[1] << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     drain_vmem();                                   // every storing wave: its write-through stores have landed
-    __syncthreads();
+    __syncthreads();                                // (and every wave is done with the row in LDS: the slots may be written)
     if (tid == 0) __hip_atomic_fetch_add(a.cnt + MLP_W_CNT1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     MLP_CLK(1);
-    fill_ring(gu_base(uA));
+    start_stream();
   }
 
   // ---- hand-off 1: all 16 rows published ----------------------------------------------------------------------------
@@ -229,43 +252,68 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
     breg[s] = *reinterpret_cast<const v4i*>(a.xq + ((size_t)(w * MLP_RING + s) * 64 + lane) * 16);
   uint32_t sbw = a.sbmb[lane & 15];
   // Everything the epilogues read from memory must be IN REGISTERS before the rounds start: hipcc otherwise sinks these
-  // small loads to their first use, i.e. behind a round's refills -- and a wait for them is then a wait for the whole ring
-  // (loads return in order): measured, every round ended on a 5-us drain of its own prefetch (profiles/r04_a).
+  // small loads to their first use, and a wait for them is then a wait for everything issued before (loads return in
+  // order): measured, every round ended on a 5-us drain of its own prefetch (profiles/r04_a).
   asm volatile("" : "+v"(sbw), "+v"(swA.x), "+v"(swA.y), "+v"(szA.x), "+v"(szA.y), "+v"(swB.x), "+v"(swB.y), "+v"(szB.x), "+v"(szB.y));
   const float sa = (float)__builtin_bit_cast(half_t, (uint16_t)(sbw & 0xFFFFu));
   const float as = (float)__builtin_bit_cast(half_t, (uint16_t)(sbw >> 16));
 #pragma unroll
   for (int s = 0; s < MLP_RING; ++s) asm volatile("" : "+v"(breg[s]));
+  drain_vmem();                                     // (everything issued so far has landed -- the slot's DMAs included)
 
   // ---- P2: gate_up units ---------------------------------------------------------------------------------------------
   float rowmax = 0.0f;                              // max |act| of row (lane & 15) over the channels this lane finished
-  // one round = the 8 ring steps of one gate_up unit; the ring is refilled with the next round's weights: steps 0..3 from
-  // n0, 4..7 from n1 (gate_up unit: n1 = n0 + 4 KiB; down units: the two units' bases)
-  auto gu_round = [&](const uint8_t* n0, const uint8_t* n1, v4i (&acc)[4]) {
+  // one round = the 8 ring steps of one gate_up unit.  PULL: the registers of a step are refilled from the landing slot
+  // (gate_up unit B) right after they were unpacked, and each half of the slot is re-armed with the down units' steps once it
+  // has been read.
+  auto gu_round = [&](auto pull_tag, v4i (&acc)[4]) {
+    constexpr bool PULL = decltype(pull_tag)::value;
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) acc[ab] = (v4i){0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < MLP_RING; ++s) {
       v4i wa[4];
       unpack(wq[s], wa);
-      const uint8_t* np = s < HR ? n0 + (size_t)s * 1024 : n1 + (size_t)(s - HR) * 1024;
-      wq[s][0] = load_w(np);
-      wq[s][1] = load_w(np + 512);
-      // keep the refill HERE, a whole round ahead of its use (left alone hipcc sinks every refill behind the round's last MFMA)
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PULL) slot_step(s, wq[s]);
 #pragma unroll
       for (int ab = 0; ab < 4; ++ab) acc[ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], breg[s], acc[ab], 0, 0, 0);
+      if constexpr (PULL) {
+        if (s == HR - 1 || s == MLP_RING - 1) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this half of the slot is in registers
+          dma_steps(dnA, dnB, s == HR - 1 ? 0 : HR, s == HR - 1 ? HR : MLP_RING);
+        }
+      }
     }
   };
-  // K parts meet in LDS; waves 0..3 finish row block ab = w: epilogue, silu_and_mul, fp16 activation in operand order
-  auto gu_finish = [&](const v4i (&acc)[4], int u, uint2 swv, uint2 szv) {
+  // K parts meet in LDS in two stages (16 KiB): waves 4..7 -> waves 0..3, then waves 0..3 -> the owner of each row block
+  // (wave ab); the owners run the epilogue, silu_and_mul, and store the fp16 activation in operand order
+  auto combine = [&](v4i (&acc)[4]) -> v4i {
+    if (w >= 4) {
 #pragma unroll
-    for (int ab = 0; ab < 4; ++ab) part[(w * 4 + ab) * 64 + lane] = acc[ab];
+      for (int ab = 0; ab < 4; ++ab) part[((w - 4) * 4 + ab) * 64 + lane] = acc[ab];
+    }
     __syncthreads();
     if (w < 4) {
-      v4i a4 = (v4i){0, 0, 0, 0};
 #pragma unroll
-      for (int ww = 0; ww < MLP_WAVES; ++ww) a4 += part[(ww * 4 + w) * 64 + lane];
+      for (int ab = 0; ab < 4; ++ab) acc[ab] += part[(w * 4 + ab) * 64 + lane];
+    }
+    __syncthreads();
+    if (w < 4) {
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab) part[(w * 4 + ab) * 64 + lane] = acc[ab];
+    }
+    __syncthreads();
+    v4i a4 = (v4i){0, 0, 0, 0};
+    if (w < 4) {
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) a4 += part[(ww * 4 + w) * 64 + lane];
+    }
+    __syncthreads();                                // (the next unit's partials may overwrite)
+    return a4;
+  };
+  auto gu_finish = [&](v4i (&acc)[4], int u, uint2 swv, uint2 szv) {
+    const v4i a4 = combine(acc);
+    if (w < 4) {
       typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
       const v4h_t sw4 = __builtin_bit_cast(v4h_t, swv), sz4 = __builtin_bit_cast(v4h_t, szv);
       half_t o[4];
@@ -291,20 +339,17 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
         st_agent64(a.act + ((size_t)s * 64 + (m + 16 * e)) * 16 + 4 * j, *reinterpret_cast<const uint64_t*>(act));
       }
     }
-    __syncthreads();                                // (the next unit's partials may overwrite)
   };
-  const uint8_t* dnA = dn_base(vA);
-  const uint8_t* dnB = dn_base(heavy ? vB : vA);    // (light: the second half of the ring re-reads unit A, unused)
   {
     v4i acc[4];
     if (heavy) {
-      gu_round(gu_base(uB), gu_base(uB) + HR * 1024, acc);
+      gu_round(BoolTag<true>{}, acc);
       gu_finish(acc, uA, swA, szA);
       MLP_CLK(3);
-      gu_round(dnA, dnB, acc);
+      gu_round(BoolTag<false>{}, acc);
       gu_finish(acc, uB, swB, szB);
     } else {
-      gu_round(dnA, dnB, acc);
+      gu_round(BoolTag<false>{}, acc);
       gu_finish(acc, uA, swA, szA);
       MLP_CLK(3);
     }
@@ -321,7 +366,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
       __hip_atomic_fetch_max(a.amax + (b & (MLP_SHARDS - 1)) * 16 + tid, __builtin_bit_cast(uint32_t, mxr), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
     }
-    drain_vmem();                                   // (also the last refills of the ring: issued during the round)
+    drain_vmem();                                   // (the activation stores -- and the down units' DMAs, issued a round ago)
     __syncthreads();
     if (tid == 0)
       __hip_atomic_fetch_add(a.cnt + MLP_W_CNT2 + 16 * (b & (MLP_SHARDS - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -344,7 +389,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
   const float qlane = quant_multiplier(amax_row);
 
   // ---- P3: down units (fp16 activation slice quantised on the fly -> int32 split-K slab of K part v / 64) ---------------
-  // B operands: both units' slices of this wave (4 + 4 k-steps) requested together, quantised into 32 registers
+  // B operands: both units' slices of this wave (4 + 4 k-steps) requested together, quantised into 32 registers; the packed
+  // weights are consumed straight from the landing slot
   v4i bq[MLP_RING];
   {
     uint4 raw[MLP_RING][2];
@@ -362,32 +408,28 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
                     (int)quant4_f16(raw[s][1].x, raw[s][1].y, qlane), (int)quant4_f16(raw[s][1].z, raw[s][1].w, qlane)};
   }
   auto dn_unit = [&](int v, auto half_tag) {
-    constexpr int S0 = decltype(half_tag)::value ? HR : 0;       // ring steps S0 .. S0 + 3
+    constexpr int S0 = decltype(half_tag)::value ? HR : 0;       // slot steps S0 .. S0 + 3
     const int g = v & 63, pt = v >> 6;
     v4i acc[4];
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) acc[ab] = (v4i){0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < HR; ++s) {
+      uint4 wv[2];
+      slot_step(S0 + s, wv);
       v4i wa[4];
-      unpack(wq[S0 + s], wa);
+      unpack(wv, wa);
 #pragma unroll
       for (int ab = 0; ab < 4; ++ab) acc[ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bq[S0 + s], acc[ab], 0, 0, 0);
     }
-#pragma unroll
-    for (int ab = 0; ab < 4; ++ab) part[(w * 4 + ab) * 64 + lane] = acc[ab];
-    __syncthreads();
+    const v4i a4 = combine(acc);
     if (w < 4) {
-      v4i a4 = (v4i){0, 0, 0, 0};
-#pragma unroll
-      for (int ww = 0; ww < MLP_WAVES; ++ww) a4 += part[(ww * 4 + w) * 64 + lane];
       const int m = lane & 15;
       if (m < a.M) {
         const int n = g * 64 + (i0 >> 3) * 32 + w * 8 + (i0 & 7);
         *reinterpret_cast<v4i*>(a.dn_slab + ((size_t)pt * a.M + m) * a.H + n) = a4;
       }
     }
-    __syncthreads();
   };
   dn_unit(vA, BoolTag<false>{});
   if (heavy) dn_unit(vB, BoolTag<true>{});
@@ -397,6 +439,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
   if (service && b < a.M) {
     const int r = b;
     const float rmax = __shfl(amax_row, r, 64);
+    __syncthreads();                                 // (every wave is done with its slot: the row goes where the slots are)
     for (int i = tid * VT; i < a.I; i += MLP_THREADS * VT) {
       // 8 consecutive channels i .. i + 7 = pieces (s, j, e) and (s, j, e + 1) of the operand-order activation
       const int s = i >> 6, j = (i >> 4) & 3, e = (i >> 2) & 3;
@@ -436,7 +479,7 @@ extern "C" size_t omni_mlp_fused_scratch_bytes(int hidden, int inter) {
 // and a device whose 256 CUs can hold the 256 workgroups together.
 extern "C" int omni_mlp_fused_ok(int M, int hidden, int inter) {
   if (M < 1 || M > 16 || hidden != 4096 || inter % 2048 != 0 || inter / 32 < MLP_WGS || inter / 32 > 2 * MLP_WGS) return 0;
-  if ((size_t)inter * 4 > 120 * 1024) return 0;                                  // a row as f32 in LDS
+  if ((size_t)inter * 4 > 131072) return 0;                                      // a row as f32 in the landing slots' LDS
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
@@ -477,11 +520,9 @@ extern "C" int omni_w4a8_per_chn_mlp_fused(void* residual_f16, const void* o_sla
   a.M = M; a.H = hidden; a.I = inter; a.phase = phase;
   *sk_out = sk;
   // > 80 KiB of LDS per workgroup: one workgroup per CU whatever the register allocation (they wait on each other)
-  // 32 KiB of partial sums + a row as f32 + reduction scratch, asked for as at least 96 KiB: more than half a CU's LDS, i.e.
-  // one workgroup per CU whatever the register allocation (they wait on each other)
-  const size_t xs_floats = (size_t)(inter > hidden + hidden / 4 ? inter : hidden + hidden / 4);
-  size_t lds = 32768 + xs_floats * 4 + 96 * 4 + 16 + 8 * 16 * 4;
-  if (lds < 96 * 1024) lds = 96 * 1024;
+  // 16 KiB of partial sums + eight 16-KiB landing slots (a row as f32 lives there before / after the stream) + reduction
+  // scratch: one workgroup per CU (they wait on each other)
+  const size_t lds = 16384 + 131072 + 96 * 4 + 16 + 8 * 16 * 4;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)mlp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
