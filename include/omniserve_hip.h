@@ -187,7 +187,8 @@ int omni_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const v
                                        const void* weight_f16, void* sum_f16, void* scale_f16,
                                        float eps, int tokens, int hidden, void* stream);
 
-/* Deferred split-K epilogue for decode shapes (M <= 128): omni_w4a8_per_chn_gemm_partial writes only the
+/* Deferred split-K epilogue for decode shapes (M <= 512; above 128 rows on the 128 x 256 tile with K slices over grid.y):
+ * omni_w4a8_per_chn_gemm_partial writes only the
  * int32 partial sums slab[sk][M][N] (*sk_out = number of slabs, host int), and
  * omni_splitk_add_rms_norm_general_fuse_sum consumes them:
  *   residual += fp16( epilogue( sum_k slab[k] ) )   -- exactly omni_w4a8_per_chn_gemm's output, then

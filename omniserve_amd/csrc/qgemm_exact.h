@@ -62,7 +62,9 @@ __device__ __forceinline__ void lds_dma16_x8(const void* sbase0, const void* sba
       : "memory", "scc");
 }
 
-template <int MODE, bool ADMA>
+// TO_SLAB (decode batches of 256 / 384 / 512 rows: few tiles): the workgroup takes K slice blockIdx.y of p.kslice (a whole
+// number of chunks) and stores its int32 accumulators to slab[blockIdx.y][M][N] for splitk_epilogue_kernel / a slab consumer.
+template <int MODE, bool ADMA, bool TO_SLAB = false>
 __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
   constexpr int MB = 8, MT = 128, WAVES = 4, NTHREADS = 256, A_LOADS = 8;
   static_assert(KCHUNK == 256 && STEPS == 4, "tile maps assume 256-k chunks of four 64-k steps");
@@ -86,6 +88,14 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
   int tile_m, tile_n;
   {
     const int wid = blockIdx.x;
+    if (p.tile_linear) {
+      // few row tiles (decode batches of 129 .. 1023 rows): the super-block order would put every existing tile of a block
+      // on ONE XCD (only the first rows of each 8 x 8 block exist: 32 tiles of Llama-3-8B's down_proj at bs = 256 ran on 2 of
+      // the 8 XCDs, profiles/r04_b); consecutive workgroups -- consecutive XCDs -- take consecutive tiles instead
+      tile_m = wid % p.tiles_m;
+      tile_n = wid / p.tiles_m;
+      if (tile_n >= p.tiles_n) return;
+    } else {
     const int per_xcd = gridDim.x >> 3;
     const int t = (wid & 7) * per_xcd + (wid >> 3);
     const int sbn = (p.tiles_n + 7) >> 3;
@@ -93,10 +103,12 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
     tile_m = (sb / sbn) * 8 + (in >> 3);
     tile_n = (sb % sbn) * 8 + (in & 7);
     if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
+    }
   }
   const int ng = tile_n * WAVES + wave;  // 64-channel group of this wave
   const int m0 = tile_m * MT;
-  const int nchunks = p.K / KCHUNK;
+  const int k0 = TO_SLAB ? (int)blockIdx.y * p.kslice : 0;      // first k of this workgroup's K slice
+  const int nchunks = (TO_SLAB ? p.kslice : p.K) / KCHUNK;
   // (Two workgroups share a CU, one wave of each per SIMD, and the arbiter strictly favours the OLDER wave: per-workgroup
   // clocks show the first-dispatched workgroup of every CU running its K loop in 30 us and the second in 46, the last 16
   // alone at 2/3 of the paired rate.  s_setprio flips or time-slices that at will -- and the pair finishes at the same
@@ -105,12 +117,12 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
   // ---- weights: HBM / L2 -> VGPR ring (as w4a8_gemm_kernel) ---------------------------------------------
   const int lx = (lane >> 3) & 1, lc = lane & 7, le = lane >> 4;
   const uint8_t* wbase;
-  if constexpr (W8C) wbase = p.W + (size_t)(ng * 64 + (lane >> 2)) * p.K + (lane & 3) * 16;
-  else if constexpr (MODE == MODE_W8) wbase = p.W + (size_t)(ng * 64 + (lane & 15)) * p.K + (lane >> 4) * 16;
-  else wbase = p.W + ((size_t)(2 * ng + lx) * (p.K / 32)) * 512 + (lc * 4 + le) * 16;
+  if constexpr (W8C) wbase = p.W + (size_t)(ng * 64 + (lane >> 2)) * p.K + (lane & 3) * 16 + k0;
+  else if constexpr (MODE == MODE_W8) wbase = p.W + (size_t)(ng * 64 + (lane & 15)) * p.K + (lane >> 4) * 16 + k0;
+  else wbase = p.W + ((size_t)(2 * ng + lx) * (p.K / 32) + k0 / 32) * 512 + (lc * 4 + le) * 16;
   uint8_t* const wtr_w = wtr + (W8C ? wave * 1024 + ((lane & 3) * 16 + ((lane >> 2) ^ (5 * (lane & 3)))) * 16 : 0);
   const uint8_t* const wtr_r = wtr + (W8C ? wave * 1024 + ((lane & 48) + ((lane & 15) ^ (5 * (lane >> 4)))) * 16 : 0);
-  auto load_w = [&](int k, int j) -> uint4 {
+  auto load_w = [&](int k, int j) -> uint4 {      // k: relative to the K slice
     const uint8_t* ptr;
     if constexpr (MODE == MODE_W8) ptr = wbase + (size_t)j * 16 * p.K + k;
     else ptr = wbase + (size_t)(k / 32 + j) * 512;
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
       for (int j = 0; j < A_LOADS; ++j) {
         int m, kk;
         piece(j, m, kk);
-        areg[j] = *reinterpret_cast<const uint4*>(p.A + (size_t)(m0 + m) * p.K + chunk * KCHUNK + kk * 16);
+        areg[j] = *reinterpret_cast<const uint4*>(p.A + (size_t)(m0 + m) * p.K + k0 + chunk * KCHUNK + kk * 16);
       }
     }
   };
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)smem;
   auto dma_chunk = [&](int chunk, int buf) {
     if constexpr (ADMA) {
-      const uint8_t* s0 = reinterpret_cast<const uint8_t*>(p.A) + (size_t)(m0 + wave * 32) * p.K + (size_t)chunk * KCHUNK;
+      const uint8_t* s0 = reinterpret_cast<const uint8_t*>(p.A) + (size_t)(m0 + wave * 32) * p.K + (size_t)k0 + (size_t)chunk * KCHUNK;
       const uint8_t* s1 = s0 + (size_t)16 * p.K;
       lds_dma16_x8(s0, s1, dvo[0], dvo[1], dvo[2], dvo[3],
                    __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)buf * (MT * KCHUNK) + (uint32_t)wave * 32 * 256));
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < WL; ++j) wq[s][j] = load_w(s * KSTEP, j);
   load_a(0);
-  {   // epilogue operands -> LDS (published by the first chunk's barrier)
+  if constexpr (!TO_SLAB) {   // epilogue operands -> LDS (published by the first chunk's barrier); the slab form has none
     const int n = tile_n * 64 * WAVES + tid;
     const uint32_t sw = __builtin_bit_cast(uint16_t, p.wscales[n]);
     uint32_t sz = 0;
@@ -225,8 +237,8 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
   if constexpr (MODE == MODE_GRP) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      gs[h] = *reinterpret_cast<const uint32_t*>(p.s2s + (size_t)h * p.N + gcol);
-      gz[h] = *reinterpret_cast<const uint32_t*>(p.s2z + (size_t)h * p.N + gcol);
+      gs[h] = *reinterpret_cast<const uint32_t*>(p.s2s + (size_t)(k0 / 128 + h) * p.N + gcol);
+      gz[h] = *reinterpret_cast<const uint32_t*>(p.s2z + (size_t)(k0 / 128 + h) * p.N + gcol);
     }
   }
 #ifdef OMNI_DEBUG_CLOCKS
@@ -245,8 +257,8 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
     if constexpr (MODE == MODE_GRP && NEXT) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        gsn[h] = *reinterpret_cast<const uint32_t*>(p.s2s + (size_t)((kc + KCHUNK) / 128 + h) * p.N + gcol);
-        gzn[h] = *reinterpret_cast<const uint32_t*>(p.s2z + (size_t)((kc + KCHUNK) / 128 + h) * p.N + gcol);
+        gsn[h] = *reinterpret_cast<const uint32_t*>(p.s2s + (size_t)((k0 + kc + KCHUNK) / 128 + h) * p.N + gcol);
+        gzn[h] = *reinterpret_cast<const uint32_t*>(p.s2z + (size_t)((k0 + kc + KCHUNK) / 128 + h) * p.N + gcol);
       }
     }
     if constexpr (ADMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_AFTER_DMA) : "memory");   // my pieces of chunk c landed
@@ -377,6 +389,20 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
   // W4: i = x * 8 + c, channel = ng * 64 + x * 32 + ab * 8 + c (4 consecutive channels per lane); W8: ng * 64 + ab * 16 + i.
   const int mcol = lane & 15;
   const int i0 = (lane >> 4) * 4;
+  if constexpr (TO_SLAB) {      // int32 accumulators of this K slice -> slab[blockIdx.y] (4 consecutive channels per lane: 16-B stores)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      int32_t* row = p.slab + ((size_t)blockIdx.y * p.M + (m0 + mb * 16 + mcol)) * p.N;
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab) {
+        int n;
+        if constexpr (MODE == MODE_W8) n = ng * 64 + ab * 16 + i0;
+        else n = ng * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
+        *reinterpret_cast<v4i*>(row + n) = acc[mb][ab];
+      }
+    }
+    return;
+  }
   // The lane's 16 channels are the same for every row block: their scales are converted once (32 registers the K loop
   // no longer needs); the arithmetic runs on float pairs (v_pk_mul_f32 / v_pk_add_f32: the reference's three products and one
   // difference, each rounded to f32 -- -ffp-contract=off) and the pair is made opaque before the fp16 conversion: hipcc

@@ -46,6 +46,7 @@ struct GemmArgs {
   int64_t out_stride;
   int kslice;             // k per split (multiple of 64)
   int tiles_m, tiles_n;   // > 0: 1-D grid with the XCD-aware tile order of w4a8_gemm_kernel
+  int tile_linear;        // 1 (with tiles_n > 0): workgroup w = tile (w % tiles_m, w / tiles_m) -- few row tiles
   // ---- row-kernel-free decode forms (fused extension; see w4a8_gemv_kernel EPI / A16) ----
   const half_t* A16;      // [M,K] fp16 activations quantised on the fly (A16 kernels; `A` unused)
   uint32_t* amax;         // [AMAX_WORDS] row-maximum candidates (common.h): EPI = 1 raises them, A16 reads them
@@ -185,6 +186,14 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
     // the ~64 workgroups an XCD runs at a time share 8 activation row-tiles and 8 weight column-tiles
     // (every L2 line is fetched once from the fabric and reused 8x) instead of striding over all of M.
     const int wid = blockIdx.x;
+    if (p.tile_linear) {
+      // few row tiles (decode batches of 129 .. 1023 rows): the super-block order would put every existing tile of a block
+      // on ONE XCD (only the first rows of each 8 x 8 block exist: 32 tiles of Llama-3-8B's down_proj at bs = 256 ran on 2 of
+      // the 8 XCDs, profiles/r04_b); consecutive workgroups -- consecutive XCDs -- take consecutive tiles instead
+      tile_m = wid % p.tiles_m;
+      tile_n = wid / p.tiles_m;
+      if (tile_n >= p.tiles_n) return;
+    } else {
     const int per_xcd = gridDim.x >> 3;
     const int t = (wid & 7) * per_xcd + (wid >> 3);
     const int sbn = (p.tiles_n + 7) >> 3;
@@ -192,6 +201,7 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
     tile_m = (sb / sbn) * 8 + (in >> 3);
     tile_n = (sb % sbn) * 8 + (in & 7);
     if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
+    }
   }
   const int ng = tile_n * WAVES + wave;  // 64-channel group
   const bool wave_active = (ng * 64) < p.N;
@@ -1133,6 +1143,10 @@ static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st
 #if OMNI_GEMM_XCD_ORDER
   const int sbs = ((b.tiles_m + 7) / 8) * ((b.tiles_n + 7) / 8);
   dim3 grid(sbs * 64, 1, 1);
+  if (b.tiles_m < 8) {      // (the super-block order needs whole blocks of 8 row tiles to spread over the XCDs)
+    b.tile_linear = 1;
+    grid.x = b.tiles_m * b.tiles_n;
+  }
 #else
   dim3 grid(b.tiles_n, 1, b.tiles_m);
   b.tiles_n = b.tiles_m = 0;
@@ -1148,6 +1162,17 @@ static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st
       hipLaunchKernelGGL((w4a8_gemm_exact_kernel<MODE, true>), grid, dim3(256), 0, st, b);
     else
       hipLaunchKernelGGL((w4a8_gemm_exact_kernel<MODE, false>), grid, dim3(256), 0, st, b);
+    return;
+  }
+  if (pl.sk > 1) {      // few tiles (decode at batch 129..512): K slices over grid.y -> int32 slabs -> the slab epilogue
+    grid.y = pl.sk;
+    if (MB == 8 && WAVES == 4 && exact_mode != 0 && OMNI_GEMM_EXACT_DMA && a.M % 128 == 0 && a.N % 256 == 0 && b.kslice % KCHUNK == 0 &&
+        (size_t)a.M * a.K < ((size_t)1 << 32))
+      hipLaunchKernelGGL((w4a8_gemm_exact_kernel<MODE, true, true>), grid, dim3(256), 0, st, b);
+    else
+      hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, true, false>), grid, dim3(64 * WAVES), 0, st, b);
+    const size_t total = (size_t)a.M * (a.N / 4);
+    hipLaunchKernelGGL((splitk_epilogue_kernel<MODE>), dim3((total + 63) / 64), dim3(64), 0, st, a, pl.sk);
     return;
   }
   hipLaunchKernelGGL((w4a8_gemm_kernel<MB, MODE, WAVES, false, false>), grid, dim3(64 * WAVES), 0, st, b);
@@ -1313,12 +1338,24 @@ static int launch_gemm_partial_f16(GemmArgs a, void* slab, size_t slab_bytes, in
 // kernel (omni_splitk_add_rms_norm_general_fuse_sum) reduces them and applies the epilogue.
 template <int MODE>
 static int launch_gemm_partial(GemmArgs a, void* slab, size_t slab_bytes, int* sk_out, hipStream_t st) {
-  if (a.M < 1 || a.M > 128 || a.N % 64 != 0 || a.K % 64 != 0 || a.K < 64 || !slab || !sk_out) return OMNI_EINVAL;
+  if (a.M < 1 || a.M > 512 || a.N % 64 != 0 || a.K % 64 != 0 || a.K < 64 || !slab || !sk_out) return OMNI_EINVAL;
   if (MODE == MODE_GRP && a.K % 128 != 0) return OMNI_EINVAL;
   GemmPlan pl = plan_gemm(a.M, a.N, a.K, MODE == MODE_GRP ? 128 : 64, true, MODE == MODE_W8);
   if (slab_bytes < (size_t)pl.sk * a.M * a.N * sizeof(int32_t)) return OMNI_ENOMEM;
   a.slab = static_cast<int32_t*>(slab);
   a.kslice = pl.kslice;
+  if (a.M > 128) {      // decode batches of 129 .. 512 rows: the 128 x 256 tile with K slices over grid.y, slabs only
+    GemmArgs b = a;
+    b.tiles_n = (a.N / 64 + 3) / 4;
+    b.tiles_m = (a.M + 127) / 128;
+    b.tile_linear = 1;
+    if (OMNI_GEMM_EXACT_DMA && a.M % 128 == 0 && a.N % 256 == 0 && b.kslice % KCHUNK == 0 && (size_t)a.M * a.K < ((size_t)1 << 32))
+      hipLaunchKernelGGL((w4a8_gemm_exact_kernel<MODE, true, true>), dim3(b.tiles_m * b.tiles_n, pl.sk, 1), dim3(256), 0, st, b);
+    else
+      hipLaunchKernelGGL((w4a8_gemm_kernel<8, MODE, 4, true, false>), dim3(b.tiles_m * b.tiles_n, pl.sk, 1), dim3(256), 0, st, b);
+    *sk_out = pl.sk;
+    return omni_launch_status();
+  }
   switch (pl.mb) {
     case 1: launch_gemv_kernel<MODE, 1, true>(a, pl, st); break;
     case 2: launch_gemv_kernel<MODE, 2, true>(a, pl, st); break;

@@ -36,8 +36,24 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
   pl.kw = 1;
   pl.mz = 1;
   pl.narrow = 0;
-  if (M > 128) {  // MFMA-bound regime: 128 x 256 tile per workgroup, no split
+  if (M > 128) {  // MFMA-bound regime: 128 x 256 tile per workgroup
     pl.mb = 8; pl.waves = 4; pl.sk = 1; pl.kslice = K;
+    // Few tiles (decode at batch 129..512: the published A100 figure is quoted at bs = 256): Llama-3-8B's down_proj is
+    // 2 x 16 = 32 tiles of 56 K chunks on 256 CUs (80 us per layer at bs = 256, profiles/r04_b), o_proj 32, qkv 48.  Split K over
+    // grid.y into int32 slabs (+ the slab epilogue launch) until about one workgroup per CU streams: the smallest split with
+    // >= 256 workgroups, whole 256-k chunks and >= 1024 k per workgroup.  A grid that already covers half the chip stays whole.
+    const long long tiles = (long long)((M + 127) / 128) * ((N + 255) / 256);
+    if (M <= 512 && tiles <= 128 && g_override_waves == 0) {
+      int best = 1;
+      for (int s2 = 2; s2 <= 8; s2 *= 2) {
+        if (K % (s2 * KCHUNK) != 0 || K / s2 < 1024 || tiles * s2 > 512) break;
+        best = s2;
+        if (tiles * s2 >= 256) break;
+      }
+      if (g_override_sk > 0 && K % (g_override_sk * KCHUNK) == 0) best = g_override_sk;
+      pl.sk = best;
+      pl.kslice = K / best;
+    }
     return pl;
   }
   // bandwidth-bound regime (decode): every CU must stream weights.  One wave owns 64 channels
@@ -176,7 +192,11 @@ extern "C" int omni_gemm_rowfree_ok(int M, int hidden, int attn_dim, int inter, 
 }
 
 extern "C" size_t omni_gemm_workspace_bytes(int M, int N, int K) {
-  if (M < 1 || N < 64 || K < 64 || M > 128) return 0;   // M > 128: no split, no scratch
+  if (M < 1 || N < 64 || K < 64) return 0;
+  if (M > 128) {                                          // prefill tile: split K only where few tiles would leave the chip idle
+    const omni::GemmPlan pl = omni::plan_gemm(M, N, K, K % 128 == 0 ? 128 : 64, false, false);
+    return pl.sk > 1 ? (size_t)pl.sk * M * N * sizeof(int32_t) : 0;
+  }
   // sized from the very plans the launches use: the maximum over the K alignments of the three GEMM flavours
   // (64; 128 for per-group) and over the plain / deferred (slab-only) variants
   int sk = 1;

@@ -159,9 +159,10 @@ class DecodeRunner:
         # the attention-side fusions of level 2 (split merge inside the quantiser, q / k / v from the qkv projection's slabs)
         # involve no row-parallel projection, so they also apply under tensor parallelism, where the level drops to 1
         self.l2_attn = self.fused >= 2 and batch <= 128 and os.environ.get("OMNI_TP_L2_ATTN", "1") != "0"
-        if (self.tp_size > 1 or batch > 128) and self.fused > 1:
-            # tensor parallel: the all-reduce needs the fp16 projection; batch > 128: the projections run through the
-            # prefill tile, which has no slab-only form -- no deferred epilogue in either case
+        if (self.tp_size > 1 or batch > 512) and self.fused > 1:
+            # tensor parallel: the all-reduce needs the fp16 projection; batch > 512: the prefill tile's slab-only form
+            # (omni_*_gemm_partial) stops there -- no deferred epilogue in either case.  (batch 129 .. 512: o_proj / down_proj
+            # run on the 128 x 256 tile with K slices over grid.y and leave slabs for the norm, as at smaller batches)
             self.fused = 1
         # level 3 wants the plans its entry points accept (omni_gemm_rowfree_ok: the launchers' own conditions -- gate_up
         # without a grid-level K split, i.e. hidden <= 4096; one rider workgroup per row in a grid row of hidden / 64; the

@@ -46,6 +46,47 @@ def test_per_chn_prefill_shapes(M, N, K):
     _run_chn(M, N, K, seed=M)
 
 
+# Decode at batch 129 .. 512 (the reference's published A100 figure is quoted at bs = 256): few 128 x 256 tiles, so the plan
+# splits K over grid.y into int32 slabs + the slab epilogue (qgemm_plan.hip: down_proj 8 ways, o_proj / qkv 4 ways at
+# bs = 256; gate_up has 224 tiles and stays whole).  Ragged M (row tiles partly filled), all three flavours.
+FEW_TILE_SHAPES = [(256, 4096, 14336), (256, 6144, 4096), (256, 4096, 4096), (129, 4096, 14336), (300, 512, 2048), (512, 4096, 4096)]
+
+
+@pytest.mark.parametrize("M,N,K", FEW_TILE_SHAPES)
+def test_per_chn_few_tiles_split_k(M, N, K):
+    import ctypes
+    from omniserve_amd import _lib
+    sk = ctypes.c_int(0)
+    _lib.lib().omni_gemm_get_plan(M, N, K, 64, None, None, ctypes.byref(sk))
+    assert sk.value > 1 and _lib.lib().omni_gemm_workspace_bytes(M, N, K) >= sk.value * M * N * 4
+    _run_chn(M, N, K, seed=M + N)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 4096, 14336), (256, 4096, 4096), (384, 512, 2048), (300, 512, 2048)])
+def test_per_chn_partial_few_tiles(M, N, K):
+    """The slab-only form (fused_ext.gemm_partial_per_chn: o_proj / down_proj of the decode drivers at batch 129 .. 512): the
+    sum of the int32 slabs is the exact accumulator."""
+    from omniserve_amd.backend import fused_ext
+    u, z, s1 = w4a8.synth_per_channel(N, K, M)
+    qw, _, _ = w4a8.pack_per_channel(u, z, s1)
+    a, _, _ = _acts(M, K, M + 1)
+    slab = torch.zeros((8, M, N), dtype=torch.int32, device=dev())
+    sk = fused_ext.gemm_partial_per_chn(to_dev(a), to_dev(qw), slab)
+    torch.cuda.synchronize()
+    assert sk > 1 and not slab[sk:].any()
+    assert np.array_equal(slab[:sk].sum(dim=0).cpu().numpy(), w4a8.gemm_per_chn_acc(a, qw))
+
+
+@pytest.mark.parametrize("M,N,K", FEW_TILE_SHAPES[:3] + FEW_TILE_SHAPES[4:5])
+def test_per_group_few_tiles_split_k(M, N, K):
+    _run_grp(M, N, K, False)
+
+
+@pytest.mark.parametrize("M,N,K", FEW_TILE_SHAPES[1:3] + FEW_TILE_SHAPES[4:5])
+def test_w8a8_few_tiles_split_k(M, N, K):
+    _run_w8(M, N, K)
+
+
 @pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)])
 def test_per_chn_llama3_8b_decode_bs16(N, K):
     _run_chn(16, N, K, seed=1)

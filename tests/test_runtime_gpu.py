@@ -22,10 +22,11 @@ def _run(fused, graph, steps=3, group_size=-1, batch=5):
     return torch.stack(toks).cpu(), r.x.clone().cpu(), [p.clone().cpu() for p in r.pools[0]]
 
 
-@pytest.mark.parametrize("group_size,batch", [(-1, 5), (128, 5), (128, 40)])
+@pytest.mark.parametrize("group_size,batch", [(-1, 5), (128, 5), (128, 40), (-1, 160), (128, 130)])
 def test_fusion_levels_and_graph_agree_bitwise(group_size, batch):
     """(g128 at level 2 = the per-group partial GEMM + the slab-consuming norm; batch 40 = the 64-row GEMV tile; level 3 =
-    no quantiser row kernels: SiLU in the gate_up epilogue, o / down quantising on the fly -- it falls back to 2 at batch 40)"""
+    no quantiser row kernels: SiLU in the gate_up epilogue, o / down quantising on the fly -- it falls back to 2 at batch 40;
+    batch 130 / 160 = the 128 x 256 tile with K slices over grid.y: slab-only form for o / down, split + slab epilogue elsewhere)"""
     ref_t, ref_x, ref_p = _run(0, False, group_size=group_size, batch=batch)
     for fused, graph in [(1, False), (2, False), (2, True), (3, False), (3, True)]:
         t, x, pools = _run(fused, graph, group_size=group_size, batch=batch)
