@@ -492,6 +492,19 @@ int omni_tp_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, cons
 int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, int mode, int deferred, int64_t budget_bytes,
                            int blocks);
 
+/* Fused extension (round 4): omni_kv4_decode_attention_partial + omni_attn_merge_f16_amax as ONE launch.  Every split
+ * workgroup writes its partial through, takes a ticket of its (sequence, head group), and the last arriver merges the splits
+ * (the merge kernels' arithmetic), stores the fp16 [B, Hq * 128] output and raises the row maxima; an armed L2 prefetch rides
+ * on extra z slices of the grid.  tickets_u32: >= batch * num_heads / 4 words, zero on entry and zero again when the launch has
+ * finished (keep one buffer per stream).  batch <= 16, num_heads % 4 == 0.  With a single-split plan (short contexts) the two
+ * launches run instead.  Bit-identical to the two-launch form. */
+int omni_kv4_decode_attention_f16_amax(void* out_f16, void* amax_slots_u32, const void* q_f16, const void* k_f16,
+                                       const void* v_f16, int64_t q_stride, int64_t kv_stride, const void* kv_pointers_i64,
+                                       const void* lengths_i32, int batch, int max_blocks, int num_heads, int num_kv_heads,
+                                       int head_dim, int tokens_per_block, int max_context, const void* rope_cos_sin_f32,
+                                       int rope_max_pos, void* workspace, size_t workspace_bytes, void* tickets_u32,
+                                       size_t tickets_words, void* stream);
+
 /* ---- fused extension (nothing upstream): the MLP half of the per-channel W4A8 decode layer as
  * ONE persistent launch (csrc/mlp_fused.hip) -- llama_w4a8_unpad.py:425-436 at decode shape:
  *     residual += h(o_proj epilogue(sum of sk_o int32 split-K slabs))        [omni_splitk_add_rms_norm_general_fuse_sum]

@@ -60,6 +60,8 @@ PROTOTYPES = {
     "omni_mlp_fused_error": (_i, [_vp, _vp]),
     "omni_w4a8_per_chn_mlp_fused": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_i),
                                          _vp, _vp, _vp, _i, _i, _vp, _sz, _i, _i, _i, _i, _vp]),
+    "omni_kv4_decode_attention_f16_amax": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp,
+                                                _sz, _vp, _sz, _vp]),
     "omni_attn_merge_f16_amax": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "omni_splitk_add_rms_norm": (_i, [_vp, _vp, _vp, _i] + [_vp] * 5 + [_f, _i, _i, _vp]),
     "omni_decode_arm_qkv_slabs": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -343,10 +343,24 @@ def gemm_partial_f16_w8a8(act, amax, weight, slab, scale_out):
     return sk.value
 
 
-def decode_attention_f16_amax(out_f16, amax, q, k, v, kv_pointers, lengths, tokens_per_block, timestep, rotary_base):
-    """single_query_attention (KV4 + zeros, neox RoPE): the split partials, then the merge as a wide kernel writing the
-    fp16 [B, Hq*Dh] output (the values single_query_attention returns) into out_f16 and raising the row maxima of |out|
-    in `amax` -- the input pair of gemm_partial_f16_*."""
+_TICKETS = {}
+
+
+def _tickets(device):
+    """Ticket words of the single-launch decode attention: zero between launches (the last arriver resets its word)."""
+    t = _TICKETS.get(device)
+    if t is None:
+        t = _TICKETS[device] = torch.zeros((4096,), dtype=torch.int32, device=device)
+    return t
+
+
+def decode_attention_f16_amax(out_f16, amax, q, k, v, kv_pointers, lengths, tokens_per_block, timestep, rotary_base,
+                              single_launch=True):
+    """single_query_attention (KV4 + zeros, neox RoPE) writing the fp16 [B, Hq*Dh] output (the values
+    single_query_attention returns) into out_f16 and raising the row maxima of |out| in `amax` -- the input pair of
+    gemm_partial_f16_*.  single_launch: the last-arriving split workgroup of every (sequence, head group) merges the splits
+    inside the attention launch (omni_kv4_decode_attention_f16_amax); False: split partials + the wide merge kernel (two
+    launches).  Same bits either way."""
     import ctypes
     from ..rope import rope_table
     _lib.require_cuda(out_f16, amax, q, k, v, kv_pointers, lengths)
@@ -356,6 +370,14 @@ def decode_attention_f16_amax(out_f16, amax, q, k, v, kv_pointers, lengths, toke
     table = rope_table(max_ctx + 1, D, float(rotary_base), 1.0, q.device)
     need = _lib.lib().omni_kv4_decode_workspace_bytes(B, Hq, D, max_ctx)
     ws = _lib.workspace(need, q.device, "attn")
+    if single_launch:
+        tk = _tickets(q.device)
+        rc = _lib.lib().omni_kv4_decode_attention_f16_amax(
+            out_f16.data_ptr(), amax.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0),
+            kv_pointers.data_ptr(), lengths.data_ptr(), B, kv_pointers.shape[-1], Hq, Hkv, D, int(tokens_per_block), max_ctx,
+            table.data_ptr(), table.shape[0], ws.data_ptr(), ws.numel(), tk.data_ptr(), tk.numel(), _lib.current_stream())
+        _lib.check(rc, "fused_ext.decode_attention_f16_amax (single launch)")
+        return
     ns = ctypes.c_int(0)
     rc = _lib.lib().omni_kv4_decode_attention_partial(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), kv_pointers.data_ptr(),

@@ -323,8 +323,8 @@ struct PrefetchArgs {
 // (row, part) segment of a GEMV workgroup's bytes and walks its KiB pieces with a running pointer; with fewer
 // segments than waves the waves of a segment interleave its pieces.  All waves advance together, so the first KiB of
 // every part (what the GEMV's waves ask for first) still arrives first.
-__device__ __forceinline__ void prefetch_weights_to_l2(const PrefetchArgs& pf, void* lds_scratch) {
-  const int b = blockIdx.x;
+// `b`: the fetching workgroup's position in dispatch order (blockIdx.x of a 1-D grid; the linear id of a 3-D one)
+__device__ __forceinline__ void prefetch_weights_to_l2(const PrefetchArgs& pf, void* lds_scratch, int b) {
   const int xcd = b & 7;
   const int b0 = pf.first_block + ((xcd - pf.first_block) & 7);        // first fetching workgroup on this XCD
   const int slot = (b - b0) >> 3;
@@ -354,6 +354,10 @@ __device__ __forceinline__ void prefetch_weights_to_l2(const PrefetchArgs& pf, v
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void prefetch_weights_to_l2(const PrefetchArgs& pf, void* lds_scratch) {
+  prefetch_weights_to_l2(pf, lds_scratch, (int)blockIdx.x);
 }
 
 // Phase clocks for latency debugging (tools/phase_clocks.py; build with OMNI_HIPCC_EXTRA=-DOMNI_DEBUG_CLOCKS).

@@ -326,81 +326,8 @@ struct SrcSilu {  // h(h(silu(gate)) * up) of a [2d] row
   }
 };
 
-struct SrcAttnMerge {  // merged decode-attention output (flash-decoding partials) of one token: [Hq*128] fp16
-  static constexpr bool BATCH = false;
-  static constexpr int NS = 8;   // splits whose loads are issued together (further ones: plain loop)
-  struct Raw { float m[NS], l[NS]; v4f a[NS], b[NS]; };
-  const float* part_ml;   // [B,Hq,S,2]
-  const float* part_o;    // [B,Hq,S,128]
-  int nsplit, num_heads, token;
-  __device__ __forceinline__ SrcAttnMerge at_row(int m) const { SrcAttnMerge r = *this; r.token = m; return r; }
-  __device__ __forceinline__ void fetch(int i, Raw& r) const {
-    const size_t bh = (size_t)token * num_heads + (i >> 7);
-    const int d = i & 127;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {   // branch-free: splits >= nsplit re-read split 0 and get weight 0
-      const size_t pi = bh * nsplit + (s < nsplit ? s : 0);
-      const float2 ml = *reinterpret_cast<const float2*>(part_ml + pi * 2);
-      r.m[s] = s < nsplit ? ml.x : -1e30f;
-      r.l[s] = ml.y;
-      r.a[s] = *reinterpret_cast<const v4f*>(part_o + pi * 128 + d);
-      r.b[s] = *reinterpret_cast<const v4f*>(part_o + pi * 128 + d + 4);
-    }
-  }
-  __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
-    const size_t bh = (size_t)token * num_heads + (i >> 7);
-    const int d = i & 127;
-    // same operation order as kv4_decode_merge_kernel: max over s, then s ascending accumulation
-    float M = -1e30f;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) M = __builtin_fmaxf(M, r.m[s]);
-    // (splits beyond the first NS: batches of NS whose loads are issued together -- a plain loop made every split a
-    //  dependent memory round trip: 16 splits of the LServe sparse attention cost the merge 7.1 us instead of 4.7)
-    for (int s0 = NS; s0 < nsplit; s0 += NS) {
-      float mm[NS];
-#pragma unroll
-      for (int u = 0; u < NS; ++u) mm[u] = part_ml[(bh * nsplit + (s0 + u < nsplit ? s0 + u : 0)) * 2];
-#pragma unroll
-      for (int u = 0; u < NS; ++u) M = __builtin_fmaxf(M, s0 + u < nsplit ? mm[u] : -1e30f);
-    }
-    float l = 0.0f;
-    float o[VT];
-#pragma unroll
-    for (int e = 0; e < VT; ++e) o[e] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (s < nsplit) {
-        const float w = __expf(r.m[s] - M);
-        l += w * r.l[s];
-#pragma unroll
-        for (int e = 0; e < VT; ++e) o[e] += w * (e < 4 ? r.a[s][e] : r.b[s][e - 4]);
-      }
-    }
-    for (int s0 = NS; s0 < nsplit; s0 += NS) {
-      float2 ml[NS];
-      v4f a[NS], b[NS];
-#pragma unroll
-      for (int u = 0; u < NS; ++u) {   // branch-free: splits >= nsplit re-read split 0 and are skipped below
-        const size_t pi = bh * nsplit + (s0 + u < nsplit ? s0 + u : 0);
-        ml[u] = *reinterpret_cast<const float2*>(part_ml + pi * 2);
-        a[u] = *reinterpret_cast<const v4f*>(part_o + pi * 128 + d);
-        b[u] = *reinterpret_cast<const v4f*>(part_o + pi * 128 + d + 4);
-      }
-#pragma unroll
-      for (int u = 0; u < NS; ++u) {
-        if (s0 + u < nsplit) {
-          const float w = __expf(ml[u].x - M);
-          l += w * ml[u].y;
-#pragma unroll
-          for (int e = 0; e < VT; ++e) o[e] += w * (e < 4 ? a[u][e] : b[u][e - 4]);
-        }
-      }
-    }
-    const float inv = 1.0f / (l + 1e-6f);
-#pragma unroll
-    for (int e = 0; e < VT; ++e) x[e] = (float)(half_t)rounded_f32(o[e] * inv);   // = kv4_decode_merge_kernel's fp16 output
-  }
-};
+// (SrcAttnMerge -- the flash-decoding merge of one token's split partials -- lives in row_kernels.h: the decode attention
+// kernel's last-arriver merge uses the same code)
 
 // Row kernels, final form: RT threads compute the element values in parallel (8 consecutive elements
 // = one 16-B access per thread and iteration) and park them as f32 in LDS; the first NV/8 threads then

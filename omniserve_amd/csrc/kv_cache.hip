@@ -16,6 +16,7 @@
 //   * dequant is the reference's fp16 fma(u4, scale, -scale*zero); dot products and P.V
 //     accumulate in fp32.
 #include "common.h"
+#include "row_kernels.h"
 
 namespace omni {
 
@@ -306,6 +307,11 @@ struct DecodeArgs {
   const float* kv_qo;      // KV8 instantiations: device fp32 [2] kv_scale_quant_orig (K, V) ...
   const float* kv_oq;      // ... and kv_scale_orig_quant
   QkvSlabSrc qs;           // q / k / v from the projection's slabs (slab != nullptr)
+  // single-launch form (LASTM instantiation, fused extension): the workgroup that arrives LAST at its (sequence, head group)
+  // ticket merges the splits' partials, writes the fp16 output and raises the row maxima -- no merge launch
+  uint32_t* tickets;       // [B * gridDim.y] zero between launches (the last arriver resets its word)
+  uint32_t* amax;          // row-maximum slots (common.h: amax_raise) of the fp16 output
+  PrefetchArgs pf;         // armed L2 prefetch riding on extra z slices of the grid (pf.first_block = their first linear id)
 };
 
 constexpr int DEC_MAX_SPLITS = 1024;   // KV splits per (sequence, head group): contexts up to 1024 x 2048 tokens
@@ -358,9 +364,19 @@ constexpr int FVTILE = 32 * FVROW;
 #endif
 // KV8: per-tensor int8 pages (fused_attention_per_tensor): rows of Dh bytes, dequant h(kv_qo * f32(int8)) with the static
 // scales kv_qo[0] (K) / kv_qo[1] (V), natural element order (q is not reordered), append with kv_oq, no tail write.
-template <int G, bool DIRECT, bool FG = false, bool KV8 = false>
+// LASTM (dense KV4, splits > 1): partials are written through, every split workgroup takes a ticket of its (sequence, head
+// group), and the LAST arriver merges the splits (row_kernels.h: SrcAttnMerge, the merge kernels' own arithmetic), stores
+// the fp16 output and raises its row maxima: the attention is ONE launch (it also carries the armed L2 prefetch on extra
+// z slices of its grid, as the merge kernel did).
+template <int G, bool DIRECT, bool FG = false, bool KV8 = false, bool LASTM = false>
 __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode_flash_kernel(DecodeArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if constexpr (LASTM) {
+    if ((int)blockIdx.z >= p.batch) {       // rider workgroups: L2 prefetch of the next projection's weights
+      prefetch_weights_to_l2(p.pf, smem, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)));
+      return;
+    }
+  }
   half_t* q_lds = reinterpret_cast<half_t*>(smem);            // [G][128] dequant order
   half_t* kcur = q_lds + G * DH;                              // [128] natural order (post RoPE)
   half_t* kcur_p = kcur + DH;                                 // [128] dequant order
@@ -810,10 +826,52 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       p.out[((size_t)b * p.num_heads + hq0 + g) * DH + d] = (half_t)rounded_f32(acc * (1.0f / (L + 1e-6f)));   // (two roundings: see kv4_decode_merge_kernel)
     } else {
       const size_t pi = ((size_t)b * p.num_heads + hq0 + g) * p.nsplit + split;
-      p.part_o[pi * DH + d] = acc;
-      if (qpos == 0) {
-        p.part_ml[pi * 2 + 0] = M;
-        p.part_ml[pi * 2 + 1] = L;
+      if constexpr (LASTM) {      // written through: another CU's workgroup reads them inside this launch
+        __hip_atomic_store(p.part_o + pi * DH + d, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (qpos == 0) {
+          __hip_atomic_store(p.part_ml + pi * 2 + 0, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p.part_ml + pi * 2 + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+        p.part_o[pi * DH + d] = acc;
+        if (qpos == 0) {
+          p.part_ml[pi * 2 + 0] = M;
+          p.part_ml[pi * 2 + 1] = L;
+        }
+      }
+    }
+  }
+  if constexpr (LASTM) {
+    // ticket of (sequence b, head group blockIdx.y): the last of the nsplit workgroups merges.  Every storing wave drains
+    // its write-through stores first; the partials are first touched by the merging wave after the ticket (no stale line).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t* tk = p.tickets + (size_t)b * gridDim.y + blockIdx.y;
+    if (tid == 0) {
+      const uint32_t t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = t == (uint32_t)p.nsplit - 1u;
+      if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+      red[0] = last ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (red[0] != 0.0f && wave == DEC_WAVES - 1) {      // (the last wave: waves 0 / 1 go on to append the current token)
+      const int i = hq0 * DH + lane * VT;                // 8 outputs per lane: G * 128 = up to 512 per workgroup
+      if (lane * VT < G * DH) {
+        SrcAttnMerge src{p.part_ml, p.part_o, p.nsplit, p.num_heads, b};
+        SrcAttnMerge::Raw raw;
+        float x[VT];
+        src.fetch(i, raw);
+        src.finish(i, raw, x);
+        v8h o;
+        float mx = 0.0f;
+#pragma unroll
+        for (int e = 0; e < VT; ++e) {
+          o[e] = (half_t)x[e];                           // x[e] is already an fp16 value
+          mx = __builtin_fmaxf(mx, __builtin_fabsf(x[e]));
+        }
+        *reinterpret_cast<v8h*>(p.out + (size_t)b * p.num_heads * DH + i) = o;
+        mx = wave_max64(mx);
+        if (lane == 0) amax_raise(p.amax, b, hq0 >> 2, mx);
       }
     }
   }
@@ -1206,6 +1264,76 @@ static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, co
   }
 #undef OMNI_LAUNCH_DEC
   if (nsplit_out) *nsplit_out = pl.nsplit;
+  return omni_launch_status();
+}
+
+// Fused extension: omni_kv4_decode_attention_partial + omni_attn_merge_f16_amax as ONE launch (the last-arriving split
+// workgroup of every (sequence, head group) merges: LASTM above).  `tickets`: batch * num_kv_heads * (group / G) uint32 words,
+// zero on entry, zero again on exit.  Falls back to the two launches when the plan has a single split.  *launches_out: 1 or 2.
+namespace omni { PrefetchArgs take_armed_prefetch(); }      // qgemm_plan.hip
+extern "C" int omni_attn_merge_f16_amax(void* out_f16, const void* part_ml_f32, const void* part_o_f32, int nsplit,
+                                        void* amax_slots_u32, int batch, int num_heads, void* stream);
+extern "C" int omni_kv4_decode_attention_f16_amax(void* out_f16, void* amax_slots_u32, const void* q_f16, const void* k_f16,
+                                                  const void* v_f16, int64_t q_stride, int64_t kv_stride,
+                                                  const void* kv_pointers_i64, const void* lengths_i32, int batch,
+                                                  int max_blocks, int num_heads, int num_kv_heads, int head_dim,
+                                                  int tokens_per_block, int max_context, const void* rope_cos_sin_f32,
+                                                  int rope_max_pos, void* workspace, size_t workspace_bytes, void* tickets_u32,
+                                                  size_t tickets_words, void* stream) {
+  if (!out_f16 || !amax_slots_u32 || !tickets_u32) return OMNI_EINVAL;
+  if (num_heads < 1 || num_kv_heads < 1 || num_heads % num_kv_heads != 0 || num_heads % 4 != 0 || batch < 1 || batch > AMAX_ROWS)
+    return OMNI_EINVAL;
+  const int group = num_heads / num_kv_heads;
+  const DecodePlan pl = plan_decode(batch, num_heads, num_kv_heads, max_context < 1 ? 1 : max_context,
+                                    tokens_per_block < 16 ? 16 : tokens_per_block);
+  if (pl.nsplit < 2 || pl.g != 4 || group % 4 != 0) {      // one split (or an odd head group): the two-launch form
+    int ns = 0;
+    const int rc = decode_common(nullptr, q_f16, k_f16, v_f16, q_stride, kv_stride, kv_pointers_i64, lengths_i32, batch, max_blocks,
+                                 num_heads, num_kv_heads, head_dim, tokens_per_block, max_context, rope_cos_sin_f32,
+                                 rope_max_pos, workspace, workspace_bytes, stream, true, &ns);
+    if (rc != OMNI_OK) return rc;
+    const size_t ml = (size_t)batch * num_heads * ns * 2 * sizeof(float);
+    return omni_attn_merge_f16_amax(out_f16, workspace, (const uint8_t*)workspace + ml, ns, amax_slots_u32, batch, num_heads, stream);
+  }
+  const QkvSlabSrc armed_qs = take_armed_qkv_slabs();
+  if (!q_f16 || !k_f16 || !v_f16 || !kv_pointers_i64 || !lengths_i32 || !rope_cos_sin_f32 || !workspace) return OMNI_EINVAL;
+  if (head_dim != DH || tokens_per_block < 16 || (tokens_per_block & (tokens_per_block - 1)) != 0 || max_context < 1 ||
+      rope_max_pos < 1)
+    return OMNI_EINVAL;
+  if ((long long)pl.nsplit * pl.split_tokens < max_context) return OMNI_EINVAL;
+  const size_t need = (size_t)batch * num_heads * pl.nsplit * (DH + 2) * sizeof(float);
+  if (workspace_bytes < need) return OMNI_ENOMEM;
+  const int gy = num_kv_heads * (group / pl.g);
+  if (tickets_words < (size_t)batch * gy) return OMNI_ENOMEM;
+  DecodeArgs a;
+  a.out = (half_t*)out_f16; a.q = (const half_t*)q_f16; a.k = (const half_t*)k_f16; a.v = (const half_t*)v_f16;
+  a.q_stride = q_stride; a.kv_stride = kv_stride;
+  a.kv_pointers = (const int64_t*)kv_pointers_i64; a.lengths = (const int*)lengths_i32;
+  a.batch = batch; a.max_blocks = max_blocks; a.num_heads = num_heads; a.num_kv_heads = num_kv_heads;
+  a.lay = make_layout(tokens_per_block, num_kv_heads);
+  a.nsplit = pl.nsplit; a.split_tokens = pl.split_tokens;
+  a.rope = (const float*)rope_cos_sin_f32; a.rope_max_pos = rope_max_pos;
+  a.part_ml = (float*)workspace;
+  a.part_o = a.part_ml + (size_t)batch * num_heads * pl.nsplit * 2;
+  a.fg = FgArgs{};
+  a.kv_qo = nullptr; a.kv_oq = nullptr;
+  a.qs = armed_qs;
+  if (a.qs.slab && (a.qs.sstride != (long long)batch * a.qs.n || a.qs.col_q + num_heads * DH > a.qs.n ||
+                    a.qs.col_k + num_kv_heads * DH > a.qs.n || a.qs.col_v + num_kv_heads * DH > a.qs.n))
+    return OMNI_EINVAL;
+  a.tickets = (uint32_t*)tickets_u32; a.amax = (uint32_t*)amax_slots_u32;
+  a.pf = take_armed_prefetch();
+  const int per_slice = pl.nsplit * gy;
+  int rider_slices = 0;
+  if (a.pf.blocks > 0) {
+    rider_slices = (a.pf.blocks + per_slice - 1) / per_slice;
+    a.pf.blocks = rider_slices * per_slice;               // whole z slices
+    a.pf.first_block = per_slice * batch;
+  }
+  if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;
+  dim3 grid(pl.nsplit, gy, batch + rider_slices);
+  hipLaunchKernelGGL((kv4_decode_flash_kernel<4, false, false, false, true>), grid, dim3(DEC_THREADS), pl.lds_bytes,
+                     (hipStream_t)stream, a);
   return omni_launch_status();
 }
 

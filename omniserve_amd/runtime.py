@@ -304,6 +304,9 @@ class DecodeRunner:
             want = qs != "0"
         self.qkv_slabs = (self.fused >= 2 or self.l2_attn) and want
         # (A/B knobs: qkv's / o_proj's weights prefetched by the norm in front of qkv / the kernel behind the attention)
+        # level 3: the attention's split merge inside the attention launch (last-arriving workgroup; OMNI_ATTN_SINGLE=0: the
+        # two-launch form, A/B)
+        self.attn_single = os.environ.get("OMNI_ATTN_SINGLE", "1") != "0"
         self.arm_qkv = os.environ.get("OMNI_ARM_QKV", "1") != "0"
         self.arm_o = os.environ.get("OMNI_ARM_O", "1") != "0"
         # level 3 also in the LAST layer: its down projection's slabs are consumed by the model's final norm
@@ -473,7 +476,8 @@ class DecodeRunner:
                 self._arm(L["o"], deferred=self.fused >= 2)      # rides on the quantiser after the attention
             if self.fused >= 3:     # merge as a wide kernel (fp16 + row maxima); o_proj quantises on the fly
                 fused_ext.decode_attention_f16_amax(self.attn_f16, self.amax[li, 0], q, k, v, self.block_tables[li],
-                                                    self.lengths, self.tpb, self.max_context, c.rope_theta)
+                                                    self.lengths, self.tpb, self.max_context, c.rope_theta,
+                                                    single_launch=self.attn_single)
             elif self.fused >= 2 or self.l2_attn:   # attention with its split merge fused into the activation quant
                 fused_ext.decode_attention_quant_fuse_sum(self._q_attn, q, k, v, self.block_tables[li], self.lengths,
                                                           self.tpb, self.max_context, c.rope_theta, mA, sA)

@@ -174,8 +174,11 @@ def test_gemm_partial_f16_per_group(M, N, K):
 
 @pytest.mark.parametrize("hist,Hq,Hk", [([200, 17, 130, 1], 32, 8), ([1500, 1030], 32, 8), ([63, 64, 65], 8, 2),
                                          ([90, 33], 4, 1)])
-def test_decode_attention_f16_amax(hist, Hq, Hk):
-    """fp16 output == single_query_attention's, KV pages byte-identical, row maxima == max |out| per sequence."""
+@pytest.mark.parametrize("single_launch", [True, False])
+def test_decode_attention_f16_amax(hist, Hq, Hk, single_launch):
+    """fp16 output == single_query_attention's, KV pages byte-identical, row maxima == max |out| per sequence.
+    single_launch: the splits are merged by the last-arriving workgroup inside the attention launch (round 4) -- run three
+    times in a row on the same ticket words (they must come back to zero), with an armed L2 prefetch riding along."""
     import omniserve_backend.fused_attention_pure_dense as fa
     from omniserve_amd.backend import fused_ext
     from oracle import kv4
@@ -203,12 +206,23 @@ def test_decode_attention_f16_amax(hist, Hq, Hk):
     want = fa.single_query_attention(q, k, v, g1.table, lens, None, 65536, 64, Hk * D // 2, T, D, BASE, True, True, True)
     out = torch.empty((B, Hq * D), dtype=torch.float16, device=dev())
     amax = fused_ext.new_amax_slots(B, dev())
-    fused_ext.decode_attention_f16_amax(out, amax, q, k, v, g2.table, lens, 64, T, BASE)
+    fused_ext.decode_attention_f16_amax(out, amax, q, k, v, g2.table, lens, 64, T, BASE, single_launch=single_launch)
     torch.cuda.synchronize()
     assert torch.equal(out.view(torch.int16), want.reshape(B, Hq * D).view(torch.int16))
     assert np.array_equal(_row_amax(amax, B), want.reshape(B, -1).float().abs().max(dim=1).values.cpu().numpy())
     for a, b in zip(g1.pools(), g2.pools()):
         assert np.array_equal(a, b)
+    if single_launch:      # again (the appended row is rewritten with the same bytes), tickets re-used, riders on the grid
+        wq = torch.zeros((4096, 2048), dtype=torch.int8, device=dev())
+        for rep in range(3):
+            out.fill_(7.0)
+            amax.zero_()
+            fused_ext.prefetch_arm_gemm(wq, B, 4096, 4096, 0, True, 8 << 20, 160)
+            fused_ext.decode_attention_f16_amax(out, amax, q, k, v, g2.table, lens, 64, T, BASE)
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int16), want.reshape(B, Hq * D).view(torch.int16)), rep
+            assert np.array_equal(_row_amax(amax, B), want.reshape(B, -1).float().abs().max(dim=1).values.cpu().numpy())
+        assert not fused_ext._tickets(dev()).any()
 
 
 # ---- W8A8 forms (LServe models): same hand-off, no zero-point term, no row sums ---------------------------------------
