@@ -43,6 +43,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--context", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--warm", type=int, default=0, help="rotate over this many layers' pools only (1: K / V stay L2-resident)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = LlamaConfig.llama3_8b(-1)
@@ -52,11 +53,11 @@ def main():
     q = r.qkv_buf[:, : hq * d].view(B, hq, d); k = r.qkv_buf[:, hq * d:(hq + hk) * d].view(B, hk, d)
     v = r.qkv_buf[:, (hq + hk) * d:].view(B, hk, d)
     r.qkv_buf.normal_()
-    for ns in (0, 1, 2, 3, 4, 6, 8):
+    for ns in ((0, 2, 4) if args.warm else (0, 1, 2, 3, 4, 6, 8)):
         _lib.lib().omni_kv4_decode_set_split_override(ns)
 
         def fn(i):
-            fa.single_query_attention(q, k, v, r.block_tables[i % nl], r.lengths, None, 65536, r.tpb, hk * d // 2, r.max_context, d,
+            fa.single_query_attention(q, k, v, r.block_tables[i % (args.warm or nl)], r.lengths, None, 65536, r.tpb, hk * d // 2, r.max_context, d,
                                       cfg.rope_theta, True, True, True)
         us = graph_time(fn, nl)
         print("nsplit %s: %7.2f us per layer (B = %d, T = %d)" % ("auto" if ns == 0 else ns, us, B, args.context))
