@@ -212,7 +212,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_fused_kernel(MlpArgs a) {
   if (service) {
     const int r = b;
     if (r < a.M) {
-      SrcSlabAddChn src{a.res, a.o_slab, (size_t)a.M * a.H, a.sk_o, a.H, a.o_ws, a.o_wsz, a.o_as, a.o_asum, 0.f, 0.f};
+      SrcSlabAddChn src{a.res, a.o_slab, (size_t)a.M * a.H, a.sk_o, a.H, a.o_ws, a.o_wsz, a.o_as, a.o_asum, (half_t)0.0f, (half_t)0.0f};
       const SrcSlabAddChn row = src.at_row(r);
       SinkLds sink{codes_lds, pair_lds};
       general_norm_v2_row<MLP_THREADS, 4, true, SrcSlabAddChn, SinkLds>(row, a.gamma, sink, a.eps, a.H, 1024, xs, red);

@@ -22,13 +22,18 @@ struct SrcSlabAddT {  // residual += h(GEMM epilogue(sum of split-K slabs)), in 
   const half_t* wsz;      // [N]
   const half_t* ascales;  // [M] scales / sums of the GEMM's int8 input
   const half_t* asum;
-  float sa, as;
+  half_t sa_h, as_h;      // the row's activation scale / sum: REQUESTED by at_row, converted where finish() uses them (a
+                          // conversion in at_row made hipcc wait for these two loads -- a full memory round trip with
+                          // vmcnt(0) -- before it issued the row's slab / residual loads: ISA of round 4, profiles/r04_e)
+  __device__ __forceinline__ void pin() const {   // kernel arguments of the row path, requested with a rider test's (elementwise.hip)
+    asm volatile("" ::"s"(res), "s"(slab), "s"(sstride), "s"(sk), "s"(stride), "s"(wscales), "s"(wsz), "s"(ascales), "s"(asum));
+  }
   __device__ __forceinline__ SrcSlabAddT at_row(int m) const {
     SrcSlabAddT r = *this;
     r.res = res + (size_t)m * stride;
     r.slab = slab + (size_t)m * stride;
-    r.sa = (float)ascales[m];
-    if constexpr (ZP) r.as = (float)asum[m];
+    r.sa_h = ascales[m];
+    if constexpr (ZP) r.as_h = asum[m];
     return r;
   }
   __device__ __forceinline__ void fetch(int i, Raw& r) const {
@@ -70,6 +75,9 @@ struct SrcSlabAddT {  // residual += h(GEMM epilogue(sum of split-K slabs)), in 
   }
   __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
     v8h o;
+    const float sa = (float)sa_h;
+    float as = 0.0f;
+    if constexpr (ZP) as = (float)as_h;
 #pragma unroll
     for (int e = 0; e < VT; ++e) {
       const int acc = e < 4 ? r.s0[e] : r.s1[e - 4];
@@ -100,6 +108,7 @@ struct SrcAttnMerge {  // merged decode-attention output (flash-decoding partial
   const float* part_ml;   // [B,Hq,S,2]
   const float* part_o;    // [B,Hq,S,128]
   int nsplit, num_heads, token;
+  __device__ __forceinline__ void pin() const { asm volatile("" ::"s"(part_ml), "s"(part_o), "s"(nsplit), "s"(num_heads)); }
   __device__ __forceinline__ SrcAttnMerge at_row(int m) const { SrcAttnMerge r = *this; r.token = m; return r; }
   __device__ __forceinline__ void fetch(int i, Raw& r) const {
     const size_t bh = (size_t)token * num_heads + (i >> 7);
