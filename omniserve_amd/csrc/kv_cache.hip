@@ -371,6 +371,13 @@ constexpr int FVTILE = 32 * FVROW;
 template <int G, bool DIRECT, bool FG = false, bool KV8 = false, bool LASTM = false>
 __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode_flash_kernel(DecodeArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // One batch of scalar loads for the kernel arguments of trip 1 (and the rider test): hipcc otherwise requests them where
+  // they are first used -- three dependent kernarg round trips (rider test, geometry, pointers) in front of the first vector
+  // load of a kernel that is a chain of memory round trips (ISA of round 4, profiles/r04_e).
+  asm volatile("" ::"s"(p.out), "s"(p.q), "s"(p.k), "s"(p.v), "s"(p.q_stride), "s"(p.kv_stride), "s"(p.kv_pointers), "s"(p.lengths),
+               "s"(p.batch), "s"(p.max_blocks), "s"(p.num_heads), "s"(p.num_kv_heads), "s"(p.lay.tpb), "s"(p.lay.tpb_log2),
+               "s"(p.lay.num_kv_heads), "s"(p.lay.bytes_per_seq), "s"(p.nsplit), "s"(p.split_tokens), "s"(p.rope), "s"(p.rope_max_pos),
+               "s"(p.part_ml), "s"(p.part_o), "s"(p.qs.slab), "s"(p.tickets), "s"(p.amax));
   if constexpr (LASTM) {
     if ((int)blockIdx.z >= p.batch) {       // rider workgroups: L2 prefetch of the next projection's weights
       prefetch_weights_to_l2(p.pf, smem, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)));

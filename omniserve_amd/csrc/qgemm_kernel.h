@@ -662,6 +662,10 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
   __shared__ __attribute__((aligned(16))) uint8_t lds_all[KW * MZ][2][MT * RK];
   __shared__ float epi_red[A16 ? 96 : 1];   // A16 rider: scratch of the reduction tree
 
+  // One batch of scalar loads for the kernel arguments in front of the weight stream: hipcc otherwise requests the pointers
+  // behind its first branch on N (the SiLU form: a second, dependent kernarg round trip in front of the first weight load).
+  if constexpr (A16) asm volatile("" ::"s"(p.A16), "s"(p.W), "s"(p.amax), "s"(p.N), "s"(p.K), "s"(p.kslice), "s"(p.M));
+  else asm volatile("" ::"s"(p.A), "s"(p.W), "s"(p.wscales), "s"(p.ascales), "s"(p.wsz), "s"(p.asum), "s"(p.N), "s"(p.K), "s"(p.kslice), "s"(p.M));
   if constexpr (A16) {
     if (blockIdx.y == 0) {      // rider workgroups (dispatched first): ordered row sum + scale of activation row blockIdx.x
       if (!OMNI_GEMV_DBG_BIT(p, 1)) a16_rider<64 * KW>(p, reinterpret_cast<float*>(&lds_all[0][0][0]), epi_red);
