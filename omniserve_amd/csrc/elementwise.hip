@@ -290,8 +290,8 @@ struct SrcAdd {  // residual += delta (fp16 add), in place
 // tensor parallel: residual += h( sum over ranks of the peers' fp16 partial projections ) -- the all-reduce of
 // llama_w4a8_unpad.py's row-parallel outputs folded into the consumer (tp_comm.h)
 struct SrcPeerAdd {
-  static constexpr bool BATCH = false;
-  struct Raw { v8h a, s; };
+  static constexpr bool BATCH = true;     // (all vectors' peer requests in flight together: one peer round trip per row)
+  struct Raw { v8h a; v8h t[TP_MAX_WORLD]; };
   half_t* res;
   TpPeers tp;
   int stride;
@@ -304,12 +304,13 @@ struct SrcPeerAdd {
   }
   __device__ __forceinline__ void fetch(int i, Raw& r) const {
     r.a = *reinterpret_cast<const v8h*>(res + i);
-    r.s = tp_sum8(tp, (size_t)i, tp.epoch);
+    tp_fetch8(tp, (size_t)i, r.t);          // (a timed-out epoch still reads the slots -- mapped memory -- and drops them)
   }
   __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
+    const v8h s = tp_reduce8(tp, r.t, tp.epoch);
     v8h o;
 #pragma unroll
-    for (int e = 0; e < VT; ++e) { o[e] = (half_t)((float)r.a[e] + (float)r.s[e]); x[e] = (float)o[e]; }
+    for (int e = 0; e < VT; ++e) { o[e] = (half_t)((float)r.a[e] + (float)s[e]); x[e] = (float)o[e]; }
     *reinterpret_cast<v8h*>(res + i) = o;
   }
 };
@@ -439,8 +440,10 @@ __global__ __launch_bounds__(RT) void tp_add_norm_v2_kernel(int8_t* __restrict__
   extern __shared__ __attribute__((aligned(16))) float xs[];
   __shared__ float red[96];
   const uint32_t e = tp_publish_and_wait(src0.tp);
-  src0.tp.epoch = e;        // 0 = a peer never arrived: the row is poisoned (NaN), the epoch stays
-  general_norm_v2_body<RT, RV, FUSE_SUM, SrcPeerAdd>(out, src0, gamma, sum_out, scale_out, eps, hidden, nv, xs, red);
+  SrcPeerAdd src = src0.at_row(blockIdx.x);     // (a local copy: writing the epoch into the kernel argument parked it in scratch)
+  src.tp.epoch = e;         // 0 = a peer never arrived: the row is poisoned (NaN), the epoch stays
+  SinkGlobal sink{out + (size_t)blockIdx.x * hidden, sum_out, scale_out, (int)blockIdx.x};
+  general_norm_v2_row<RT, RV, FUSE_SUM, SrcPeerAdd, SinkGlobal>(src, gamma, sink, eps, hidden, nv, xs, red);
   tp_finish(src0.tp, e);
 }
 
@@ -811,6 +814,18 @@ extern "C" int omni_splitk_add_rms_norm_general_fuse_sum(void* out_i8, void* res
   SrcSlabAddChn src{(half_t*)residual_f16, (const int32_t*)slab_i32, (size_t)tokens * hidden, sk, hidden,
                     (const half_t*)wscales_f16, (const half_t*)w_szs_f16, (const half_t*)ascales_in_f16,
                     (const half_t*)a_ssums_in_f16, (half_t)0.0f, (half_t)0.0f};
+  if (tokens < ROWS_MANY && hidden > 512 * VT && hidden <= 512 * 2 * VT) {
+    // decode-size rows of 4097 .. 8192 columns (Llama-2-70B): two vectors per thread with BATCHED requests -- the unbatched
+    // source made the second vector's slab loads a second memory round trip of the row chain
+    typedef SrcSlabAddT<true, true> SrcB;
+    SrcB srcb{src.res, src.slab, src.sstride, src.sk, src.stride, src.wscales, src.wsz, src.ascales, src.asum, (half_t)0.0f, (half_t)0.0f};
+    const PrefetchArgs pf = take_prefetch(tokens);
+    size_t lds = (size_t)hidden * sizeof(float);
+    if (pf.blocks > 0 && lds < 8 * 1024) lds = 8 * 1024;
+    hipLaunchKernelGGL((general_norm_v2_kernel<512, 2, true, SrcB>), dim3(tokens + pf.blocks), dim3(512), lds, (hipStream_t)stream,
+                       (int8_t*)out_i8, srcb, (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv, pf);
+    return omni_launch_status();
+  }
   const bool v2_batched = false;
   #undef KQ_
   #define KQ_(RT_, RV_) general_norm_v2_kernel<RT_, RV_, true, SrcSlabAddChn>
@@ -982,12 +997,21 @@ extern "C" int omni_tp_add_rms_norm_general_fuse_sum(void* out_i8, void* residua
   // armed for "the next row kernel" is dropped here instead of riding on an unrelated launch later
   (void)take_armed_prefetch();
   const size_t lds = (size_t)hidden * sizeof(float);
-  if (sum_f16)
-    hipLaunchKernelGGL((tp_add_norm_v2_kernel<512, 4, true>), dim3(tokens), dim3(512), lds, (hipStream_t)stream, (int8_t*)out_i8,
-                       src, (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv);
-  else
-    hipLaunchKernelGGL((tp_add_norm_v2_kernel<512, 4, false>), dim3(tokens), dim3(512), lds, (hipStream_t)stream, (int8_t*)out_i8,
-                       src, (const half_t*)weight_f16, (half_t*)nullptr, (half_t*)scale_f16, eps, hidden, nv);
+  // vectors per thread = what the row needs (the source batches its requests: an unused vector would re-read element 0 of
+  // every peer): 1 up to 4096 columns, 2 up to 8192 (Llama-2-70B), 4 beyond
+#define OMNI_TP_NORM(RV_)                                                                                                         \
+  do {                                                                                                                            \
+    if (sum_f16)                                                                                                                  \
+      hipLaunchKernelGGL((tp_add_norm_v2_kernel<512, RV_, true>), dim3(tokens), dim3(512), lds, (hipStream_t)stream,              \
+                         (int8_t*)out_i8, src, (const half_t*)weight_f16, (half_t*)sum_f16, (half_t*)scale_f16, eps, hidden, nv); \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((tp_add_norm_v2_kernel<512, RV_, false>), dim3(tokens), dim3(512), lds, (hipStream_t)stream,             \
+                         (int8_t*)out_i8, src, (const half_t*)weight_f16, (half_t*)nullptr, (half_t*)scale_f16, eps, hidden, nv); \
+  } while (0)
+  if (hidden <= 512 * VT) OMNI_TP_NORM(1);
+  else if (hidden <= 512 * 2 * VT) OMNI_TP_NORM(2);
+  else OMNI_TP_NORM(4);
+#undef OMNI_TP_NORM
   return omni_launch_status();
 }
 

@@ -8,12 +8,13 @@
 namespace omni {
 
 // ZP = true: the per-channel W4A8 epilogue ((acc*sw)*sa) - (sz*asum); ZP = false: the W8A8 / per-group one acc*(sw*sa)
-// BATCH_: all of a thread's vectors fetched back to back before any arithmetic (76 registers per vector: the stand-alone row
-// kernels run one vector per thread and leave it off; the fused MLP launch's 256-thread service rows hold two)
+// BATCH_: all of a thread's vectors requested back to back before any arithmetic (76 registers per vector: the stand-alone
+// 4096-column row kernels run one vector per thread and leave it off; the 8192-column ones and the fused MLP launch's
+// 256-thread service rows hold two)
 template <bool ZP, bool BATCH_ = false>
 struct SrcSlabAddT {  // residual += h(GEMM epilogue(sum of split-K slabs)), in place
   static constexpr bool BATCH = BATCH_;
-  struct Raw { v4i s0, s1; v8h a, sw, sz; };
+  struct Raw { v4i t0[8], t1[8]; v8h a, sw, sz; };   // raw slab vectors: fetch() only requests, finish() sums (exact in any order)
   half_t* res;
   const int32_t* slab;    // [sk][M][N]
   size_t sstride;         // M*N
@@ -36,24 +37,28 @@ struct SrcSlabAddT {  // residual += h(GEMM epilogue(sum of split-K slabs)), in 
     if constexpr (ZP) r.as_h = asum[m];
     return r;
   }
-  __device__ __forceinline__ void fetch(int i, Raw& r) const {
+  __device__ __forceinline__ void fetch(int i, Raw& r) const {   // requests only: the sums wait in finish()
     r.a = *reinterpret_cast<const v8h*>(res + i);
     r.sw = *reinterpret_cast<const v8h*>(wscales + i);
     if constexpr (ZP) r.sz = *reinterpret_cast<const v8h*>(wsz + i);
+    // up to 8 slabs: all loads in flight at once (slabs beyond sk re-read slab 0 and are dropped)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t off = (size_t)(k < sk ? k : 0) * sstride + i;
+      r.t0[k] = *reinterpret_cast<const v4i*>(slab + off);
+      r.t1[k] = *reinterpret_cast<const v4i*>(slab + off + 4);
+    }
+  }
+  __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
+    v8h o;
+    const float sa = (float)sa_h;
+    float as = 0.0f;
+    if constexpr (ZP) as = (float)as_h;
     v4i s0 = (v4i){0, 0, 0, 0}, s1 = s0;
-    {  // up to 8 slabs: all loads in flight at once (slabs beyond sk re-read slab 0 and are dropped)
-      v4i t0[8], t1[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const size_t off = (size_t)(k < sk ? k : 0) * sstride + i;
-        t0[k] = *reinterpret_cast<const v4i*>(slab + off);
-        t1[k] = *reinterpret_cast<const v4i*>(slab + off + 4);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        s0 += k < sk ? t0[k] : (v4i){0, 0, 0, 0};
-        s1 += k < sk ? t1[k] : (v4i){0, 0, 0, 0};
-      }
+    for (int k = 0; k < 8; ++k) {
+      s0 += k < sk ? r.t0[k] : (v4i){0, 0, 0, 0};
+      s1 += k < sk ? r.t1[k] : (v4i){0, 0, 0, 0};
     }
     // slabs beyond 8 (the W8A8 down projection of the LServe driver leaves 14): further batches of 8 -- a plain loop made
     // every slab a dependent round trip for the one workgroup of a batch-1 row.  Integer sums: any order is exact.
@@ -71,16 +76,9 @@ struct SrcSlabAddT {  // residual += h(GEMM epilogue(sum of split-K slabs)), in 
         s1 += k0 + k < sk ? t1[k] : (v4i){0, 0, 0, 0};
       }
     }
-    r.s0 = s0; r.s1 = s1;
-  }
-  __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
-    v8h o;
-    const float sa = (float)sa_h;
-    float as = 0.0f;
-    if constexpr (ZP) as = (float)as_h;
 #pragma unroll
     for (int e = 0; e < VT; ++e) {
-      const int acc = e < 4 ? r.s0[e] : r.s1[e - 4];
+      const int acc = e < 4 ? s0[e] : s1[e - 4];
       half_t ep;                                               // = the GEMM's fp16 output (qgemm_kernel.h: epilogue<>)
       if constexpr (ZP) {
         float t = (float)acc * (float)r.sw[e];

@@ -36,6 +36,34 @@ struct TpPeers {
   uint32_t epoch;                      // filled in by the consumer kernel after tp_publish_and_wait (0 = timed out)
 };
 
+// Peer table lookups by a RUNTIME index: select chains over the constant indices, every element made opaque first (an empty
+// asm) -- hipcc turns a plain select chain over array elements back into a dynamically indexed access, and a dynamically
+// indexed by-value kernel argument is parked in scratch memory: 176 B of private segment per thread and four DEPENDENT
+// scratch round trips in the prologue of every tp_* kernel (ISA of round 4, profiles/r04_e).
+template <class T>
+__device__ __forceinline__ T* tp_opaque(T* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+__device__ __forceinline__ uint32_t* tp_flags_of(const TpPeers& tp, int r) {
+  uint32_t* f = tp_opaque(tp.flags[0]);
+#pragma unroll
+  for (int p = 1; p < TP_MAX_WORLD; ++p) {
+    uint32_t* fp = tp_opaque(tp.flags[p]);
+    f = r == p ? fp : f;
+  }
+  return f;
+}
+__device__ __forceinline__ const half_t* tp_data_of(const TpPeers& tp, int r) {
+  const half_t* d = tp_opaque(tp.data[0]);
+#pragma unroll
+  for (int p = 1; p < TP_MAX_WORLD; ++p) {
+    const half_t* dp = tp_opaque(tp.data[p]);
+    d = r == p ? dp : d;
+  }
+  return d;
+}
+
 __device__ __forceinline__ uint32_t tp_load_sys(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -49,11 +77,11 @@ __device__ __forceinline__ uint32_t tp_publish_and_wait(const TpPeers& tp) {
   __shared__ uint32_t s_fail;
   if (threadIdx.x == 0) s_fail = 0;
   __syncthreads();
-  uint32_t* mine = tp.flags[tp.rank];
+  uint32_t* mine = tp_flags_of(tp, tp.rank);
   const uint32_t e = tp_load_sys(mine + TP_W_EPOCH) + 1;
   if (blockIdx.x == 0 && (int)threadIdx.x < tp.world) {
     // the slot was written by the previous kernel on this stream (complete and released at the kernel boundary)
-    __hip_atomic_store(tp.flags[threadIdx.x] + tp.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(tp_flags_of(tp, (int)threadIdx.x) + tp.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if ((int)threadIdx.x < tp.world) {
     uint32_t seen = tp_load_sys(mine + threadIdx.x);
@@ -78,7 +106,7 @@ __device__ __forceinline__ uint32_t tp_publish_and_wait(const TpPeers& tp) {
 __device__ __forceinline__ void tp_finish(const TpPeers& tp, uint32_t e) {
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t* mine = tp.flags[tp.rank];
+    uint32_t* mine = tp_flags_of(tp, tp.rank);
     const uint32_t done = __hip_atomic_fetch_add(mine + TP_W_TICKET, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (done == gridDim.x - 1) {
       __hip_atomic_store(mine + TP_W_TICKET, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -90,16 +118,19 @@ __device__ __forceinline__ void tp_finish(const TpPeers& tp, uint32_t e) {
 }
 
 // h( sum over ranks 0 .. world-1 of f32(data_p[i .. i+8)) ): the all-reduced fp16 vector, identical on every rank
-// (epoch 0 = the wait timed out: NaN, so that nothing downstream mistakes the sum of half-written slots for a result)
-__device__ __forceinline__ v8h tp_sum8(const TpPeers& tp, size_t i, uint32_t epoch = 1) {
+// (epoch 0 = the wait timed out: NaN, so that nothing downstream mistakes the sum of half-written slots for a result).
+// Split into the requests (tp_fetch8: all peers' loads in flight, branch-free) and the arithmetic (tp_reduce8), so that a
+// row kernel can issue the requests of ALL its vectors before the first sum: every vector was a peer round trip of its own.
+__device__ __forceinline__ void tp_fetch8(const TpPeers& tp, size_t i, v8h (&t)[TP_MAX_WORLD]) {
+#pragma unroll
+  for (int p = 0; p < TP_MAX_WORLD; ++p)
+    t[p] = *reinterpret_cast<const v8h*>((p < tp.world ? tp.data[p] : tp.data[0]) + tp.slot_off + i);
+}
+__device__ __forceinline__ v8h tp_reduce8(const TpPeers& tp, const v8h (&t)[TP_MAX_WORLD], uint32_t epoch) {
   if (epoch == 0) {
     const half_t qnan = __builtin_bit_cast(half_t, (uint16_t)0x7E00);
     return (v8h){qnan, qnan, qnan, qnan, qnan, qnan, qnan, qnan};
   }
-  v8h t[TP_MAX_WORLD];
-#pragma unroll
-  for (int p = 0; p < TP_MAX_WORLD; ++p)
-    t[p] = *reinterpret_cast<const v8h*>(tp.data[p < tp.world ? p : 0] + tp.slot_off + i);   // branch-free: all loads in flight
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
@@ -114,6 +145,15 @@ __device__ __forceinline__ v8h tp_sum8(const TpPeers& tp, size_t i, uint32_t epo
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
   return o;
+}
+__device__ __forceinline__ v8h tp_sum8(const TpPeers& tp, size_t i, uint32_t epoch = 1) {
+  v8h t[TP_MAX_WORLD];
+  if (epoch != 0) tp_fetch8(tp, i, t);
+  else {
+#pragma unroll
+    for (int p = 0; p < TP_MAX_WORLD; ++p) t[p] = (v8h){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  return tp_reduce8(tp, t, epoch);
 }
 
 }  // namespace omni

@@ -16,7 +16,7 @@ from omniserve_amd.runtime import DecodeRunner, LlamaConfig  # noqa: E402
 
 dev = torch.device("cuda:0")
 cfg = LlamaConfig.llama3_8b(-1)
-r = DecodeRunner(cfg, 16, 1024, 32, dev, seed=1, use_graph=True, fused=2)
+r = DecodeRunner(cfg, 16, 1024, 32, dev, seed=1, use_graph=True, fused=int(os.environ.get('OMNI_FUSED', '3')))
 for _ in range(6):
     r.step()
 torch.cuda.synchronize()
@@ -38,7 +38,7 @@ def show(fn, names, base):
 print("general_norm_v2 (slab + add + norm + quant + sum):")
 show("omni_debug_clocks_elementwise", [(0, "entry"), (1, "inputs loaded, xs written"), (2, "ordered partials done"),
                                         (3, "tree_sum8<2> done"), (4, "normalised, y in xs"), (5, "block max done"),
-                                        (6, "fp16 sum tree done"), (7, "int8 stored")], 0)
+                                        (6, "int8 codes stored"), (7, "fp16 sum replayed, stored")], 0)
 print("quant_v2 (last instance: attention merge or silu):")
 show("omni_debug_clocks_elementwise", [(8, "entry"), (9, "batched fetch done"), (10, "values computed"),
                                         (11, "block max done"), (12, "sum tree done"), (13, "int8 stored")], 8)
