@@ -1330,6 +1330,14 @@ extern "C" int omni_kv4_decode_attention_f16_amax(void* out_f16, void* amax_slot
     return OMNI_EINVAL;
   a.tickets = (uint32_t*)tickets_u32; a.amax = (uint32_t*)amax_slots_u32;
   a.pf = take_armed_prefetch();
+  {
+    // The fetching workgroups wait ~6 us (12 x s_sleep 16) before they start: the attention workgroups' first two load trips
+    // (length / page table / q, then every K / V byte of the split) are latency chains that the weight stream of 160 fetching
+    // workgroups slowed down, and the o projection's 8.4 MB need 2.5 of the launch's ~13 us (step -1.2 %, profiles/r04_e).
+    // Short splits (a short launch): 2 us.
+    static const int attn_pf_delay = omni_knob("OMNI_ATTN_PF_DELAY", -1);
+    a.pf.delay = attn_pf_delay >= 0 ? attn_pf_delay : (pl.split_tokens >= 128 ? 12 : 4);
+  }
   const int per_slice = pl.nsplit * gy;
   int rider_slices = 0;
   if (a.pf.blocks > 0) {
