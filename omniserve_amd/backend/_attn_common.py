@@ -7,6 +7,12 @@ from ..rope import rope_table
 
 
 def _check_cfg(rotary_embedding_dim, neox_rotary_style, int4_kv_cache, kv_cache_with_zeros, head_dim):
+    if int4_kv_cache and not kv_cache_with_zeros:
+        # upstream writes SIGNED 4-bit codes for this format (cast_to_packed_int4, decoderMaskedMultiheadAttentionUtils.h:
+        # 1890-1904) and reads them back UNSIGNED (float_from_int4: u & 0x0F, :1642-1647): no working behaviour to match
+        raise NotImplementedError("KV4 without zero points (int4_kv_cache, kv_cache_with_zeros=False) is not implemented: the "
+                                  "reference decodes its signed codes as unsigned (DESIGN.md section 7); use the fine_grained "
+                                  "(zeros) format")
     if not (int4_kv_cache and kv_cache_with_zeros):
         raise NotImplementedError("only the KV4 + zeros (fine_grained) cache format is implemented")
     if not neox_rotary_style:

@@ -77,6 +77,10 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_exact_kernel(GemmArgs p) {
   uint32_t* const epi_w = reinterpret_cast<uint32_t*>(smem + LDS_A);            // {wscale, w_sz} per channel of the tile
   uint32_t* const epi_a = reinterpret_cast<uint32_t*>(smem + LDS_A + LDS_EW);   // {ascale, asum} per row of the tile
   uint8_t* const wtr = smem + LDS_A + LDS_EW + LDS_EA;
+  // one batch of scalar loads for the prologue's kernel arguments (hipcc otherwise fetches them in three dependent groups --
+  // tile order, K slice, pointers -- in front of the first tile request)
+  asm volatile("" ::"s"(p.A), "s"(p.W), "s"(p.wscales), "s"(p.ascales), "s"(p.wsz), "s"(p.asum), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.kslice),
+               "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.tile_linear), "s"((int)gridDim.x), "s"((int)gridDim.y));
 
 #ifdef OMNI_DEBUG_CLOCKS
   const unsigned long long tl0 = wall_clock64();

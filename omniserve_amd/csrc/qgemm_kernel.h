@@ -165,6 +165,9 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   constexpr int NTHREADS = 64 * WAVES;
   constexpr int A_LOADS = (MT * KCHUNK / 16 + NTHREADS - 1) / NTHREADS;  // 16-B pieces per thread
   __shared__ __attribute__((aligned(16))) uint8_t lds[2][MT * KCHUNK];
+  // (one batch of scalar loads for the prologue's kernel arguments, as in w4a8_gemm_exact_kernel)
+  asm volatile("" ::"s"(p.A), "s"(p.W), "s"(p.wscales), "s"(p.ascales), "s"(p.wsz), "s"(p.asum), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.kslice),
+               "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.tile_linear), "s"((int)gridDim.x), "s"((int)gridDim.y));
   // W8A8: the int8 weight rows are plain [N][K].  With the MFMA operand's own lane map (row = lane & 15, 16-B piece =
   // lane >> 4) a wave instruction touches 16 rows with every lane quad spanning four of them, and the L1 pulls 15 B/clk per
   // CU out of L2 (tools/l1_pattern_probe.hip) where this tile needs 32.  Row-coalesced (row = lane >> 2, piece = lane & 3:
