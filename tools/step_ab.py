@@ -14,6 +14,8 @@ if os.environ.get("OMNI_TUNE_LIB"):
 from omniserve_amd.runtime import DecodeRunner, LlamaConfig  # noqa: E402
 
 dev = torch.device("cuda:0")
+if os.environ.get("OMNI_NSPLIT"):      # KV split override of the decode attention (0 = the planner's choice)
+    _lib.lib().omni_kv4_decode_set_split_override(int(os.environ["OMNI_NSPLIT"]))
 for gs, bs in ((-1, 16), (128, 64)):
     r = DecodeRunner(LlamaConfig.llama3_8b(gs), bs, 1024, 200, dev, seed=0, fused=int(os.environ.get('OMNI_FUSED', '3' if bs <= 16 else '2')))
     for _ in range(8):
