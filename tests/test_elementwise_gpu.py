@@ -121,14 +121,15 @@ def test_fused_silu_mul_quant_matches_the_two_kernels(tokens, d):
     assert torch.equal(q1, q2) and torch.equal(s1.view(torch.int16), s2.view(torch.int16)) and torch.equal(m1.view(torch.int16), m2.view(torch.int16))
 
 
-def test_deferred_splitk_epilogue_matches_gemm_then_add_norm():
+@pytest.mark.parametrize("M,N,K", [(16, 4096, 4096), (16, 8192, 1024), (7, 5120, 2048)])
+def test_deferred_splitk_epilogue_matches_gemm_then_add_norm(M, N, K):
     """o_proj / down_proj path of the fused runner: partial GEMM + slab-consuming add+norm must equal
-    the reference sequence GEMM -> residual add -> rms_norm_general_fuse_sum bit for bit."""
+    the reference sequence GEMM -> residual add -> rms_norm_general_fuse_sum bit for bit.  Rows of 4096 columns run one
+    vector per thread, 4097 .. 8192 two with batched requests (Llama-2-70B's hidden size; round 4)."""
     import omniserve_backend.layernorm_ops as ln
     import omniserve_backend.qgemm_w4a8_per_chn as gemm
     from omniserve_amd.backend import fused_ext
     from oracle import w4a8
-    M, N, K = 16, 4096, 4096
     u, z, s1 = w4a8.synth_per_channel(N, K, 3)
     qw, s1h, szh = w4a8.pack_per_channel(u, z, s1)
     a, sa, asum = oe.quant_per_token(_x(M, K, 5, 1.0), True)

@@ -223,6 +223,64 @@ def _peer_allreduce_rank(rank, world, port, shapes, ret):
         dist.destroy_process_group()
 
 
+def _peer_add_norm_rank(rank, world, port, cases, ret):
+    """PeerComm.add_rms_norm (the all-reduce folded into add + norm + quant) against all_reduce + the reference sequence, for row
+    widths that take one, two and four vectors per thread (tp_add_norm_v2_kernel<512, 1 | 2 | 4>)."""
+    import torch.distributed as dist
+    from omniserve_amd import tp
+    import omniserve_backend.layernorm_ops as ln
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        comm = tp.PeerComm(rank, world, max(t * h for t, h in cases), dev)
+        outs = []
+        for ci, (tokens, hidden) in enumerate(cases):
+            n = tokens * hidden
+            g = torch.Generator(device="cpu").manual_seed(77 * ci + rank)
+            part = torch.randn((n,), generator=g).half()
+            gs = torch.Generator(device="cpu").manual_seed(500 + ci)          # the same on both ranks
+            resid = (2.0 * torch.randn((tokens, hidden), generator=gs)).half().to(dev)
+            gamma = (1.0 + 0.1 * torch.randn((hidden,), generator=gs)).half().to(dev)
+            # reference sequence: all-reduce, residual add, rms_norm_general_fuse_sum
+            comm.slot(n).copy_(part)
+            red = torch.empty((n,), dtype=torch.float16, device=dev)
+            comm.all_reduce(red)
+            x1 = resid.clone(); x1.add_(red.view(tokens, hidden))
+            q1 = torch.empty((tokens, hidden), dtype=torch.int8, device=dev)
+            sc1 = torch.empty((tokens,), dtype=torch.float16, device=dev); sm1 = sc1.clone()
+            ln.rms_norm_general_fuse_sum(q1, x1, gamma, sm1, sc1, 1e-5, True)
+            # fused: the peers' slots summed inside the norm kernel
+            comm.slot(n).copy_(part)
+            x2 = resid.clone()
+            q2 = torch.empty_like(q1); sc2 = torch.empty_like(sc1); sm2 = torch.empty_like(sc1)
+            comm.add_rms_norm(q2, x2, gamma, sm2, sc2, 1e-5)
+            torch.cuda.synchronize()
+            outs.append((bool(torch.equal(x1.view(torch.int16), x2.view(torch.int16))), bool(torch.equal(q1, q2)),
+                         bool(torch.equal(sc1.view(torch.int16), sc2.view(torch.int16))),
+                         bool(torch.equal(sm1.view(torch.int16), sm2.view(torch.int16))), x2.cpu().numpy()))
+        comm.check_error()
+        ret[rank] = outs
+        dist.barrier()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_add_rms_norm_row_widths_two_ranks_one_gpu():
+    """tp_add_norm_v2_kernel batches the peer loads of all of a thread's vectors (round 4): rows of 4096 / 8192 / 12288
+    columns = one / two / four vectors per thread, bit-identical to all-reduce -> add -> rms_norm_general_fuse_sum, same
+    residual on both ranks."""
+    cases = [(16, 4096), (128, 8192), (5, 12288), (3, 2048)]
+    ret = _spawn2(_peer_add_norm_rank, (cases,))
+    for ci, case in enumerate(cases):
+        for rk in range(2):
+            same_x, same_q, same_sc, same_sm, _ = ret[rk][ci]
+            assert same_x and same_q and same_sc and same_sm, (case, rk, same_x, same_q, same_sc, same_sm)
+        assert np.array_equal(ret[0][ci][4].view(np.uint16), ret[1][ci][4].view(np.uint16)), case
+
+
 def test_peer_allreduce_two_ranks_one_gpu():
     """The library's own all-reduce over hipIpc-mapped peer buffers (tp.PeerComm), two processes on the one test GPU:
     sums are bit-exact (f32 accumulate in rank order, one rounding) and identical on both ranks, eagerly and replayed from a
