@@ -232,12 +232,16 @@ def roofline_gate_up(runner, ms_per_step=None):
                                      "frac": round(alg_plain / (ms_plain * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     try:
         a_ms, a_bytes, T = _time_attention(runner)
-        out["attention"] = {"kernel": "kv4_decode_flash_kernel<4> + merge (one layer, B=%d, T=%d)" % (B, T),
+        single = runner.fused >= 3 and getattr(runner, "attn_single", False)
+        out["attention"] = {"kernel": ("kv4_decode_flash_kernel<4, ..., LASTM> (one launch: the last-arriving split workgroup merges; "
+                                       "one layer, B=%d, T=%d)" if single else
+                                       "kv4_decode_flash_kernel<4> + merge (one layer, B=%d, T=%d)") % (B, T),
                             "us_per_layer": round(a_ms * 1e3, 2), "bytes_per_layer": a_bytes,
                             "achieved": round(a_bytes / (a_ms * 1e-3) / 1e9, 1),
                             "frac": round(a_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                            "note": "algorithmic KV bytes 1088*T*B per layer; two dependent launches (split partials, merge); "
-                                    "at T=1024 the kernel is a latency chain (page table -> K/V -> softmax -> combine), not a stream"}
+                            "note": "algorithmic KV bytes 1088*T*B per layer; isolated launches over the layers' (cold) pools, as the "
+                                    "step issues them (%s); at T=1024 the kernel is a latency chain (page table -> K/V -> softmax "
+                                    "-> combine), not a stream" % ("one launch" if single else "split partials, then the merge launch")}
     except Exception as exc:   # noqa: BLE001
         out["attention"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if ms_per_step:
