@@ -146,3 +146,17 @@ def test_release_library_reads_no_environment():
                  b"OMNI_DECODE_RT", b"OMNI_PREFETCH_DELAY"):
         assert knob not in blob, knob
     assert not hasattr(_lib.lib(), "omni_gemm_set_weight_policy")      # the load policy is per call (omni_prefetch_arm_gemm)
+
+
+def test_kv_formats_without_a_working_upstream_behaviour_are_named_in_the_error():
+    """KV4 without zero points: upstream packs signed codes and decodes them unsigned -- the mirror refuses
+    the format by name instead of guessing an arithmetic; per_tensor + int4 likewise."""
+    import pytest
+    from omniserve_amd.backend import _attn_common
+    with pytest.raises(NotImplementedError, match="unsigned"):
+        _attn_common._check_cfg(128, True, True, False, 128)
+    with pytest.raises(NotImplementedError):
+        _attn_common._check_cfg_kv8(128, True, True, False, 128)
+    _attn_common._check_cfg(128, True, True, True, 128)          # the fine_grained KV4 format
+    _attn_common._check_cfg_kv8(128, True, False, False, 128)    # the per_tensor KV8 format
+
