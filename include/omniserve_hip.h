@@ -40,6 +40,10 @@ size_t omni_gemm_workspace_bytes(int M, int N, int K);
  * override the decode-shape plan (waves per workgroup: 1 or 4; K splits), 0/0 restores the
  * heuristic; query the plan the library would use. */
 void omni_gemm_set_plan_override(int waves, int sk);
+/* The mid-M kernel (M = 33 .. 128, csrc/qgemm_midm.h; the regime of gemm_cuda.cu:621-655's 32x64x128 / 64x64x64 tiles):
+ * mode -1 = the planner's heuristic, 0 = never, 1 = wherever its shape conditions hold (N % 128 == 0, K % 256 == 0);
+ * sk > 0 forces its K split.  Per calling thread, like the override above. */
+void omni_gemm_set_midm_override(int mode, int sk);
 void omni_gemm_get_plan(int M, int N, int K, int kalign, int* mb, int* waves, int* sk);
 /* 1 when the row-kernel-free decode forms below (omni_*_gemm_silu for gate_up [2*inter, hidden], omni_*_gemm_partial_f16
  * for o [hidden, attn_dim] and down [hidden, inter]) accept a layer of these dimensions at M rows, 0 otherwise: the plan

@@ -23,6 +23,7 @@ PROTOTYPES = {
     "omni_abi_version": (_i, []),
     "omni_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "omni_gemm_set_plan_override": (None, [_i, _i]),
+    "omni_gemm_set_midm_override": (None, [_i, _i]),
     "omni_prefetch_arm_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i64, _i]),
     "omni_gemm_get_plan": (None, [_i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     "omni_gemm_rowfree_ok": (_i, [_i, _i, _i, _i, _i]),

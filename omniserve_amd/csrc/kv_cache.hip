@@ -850,7 +850,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   }
   if constexpr (LASTM) {
     // ticket of (sequence b, head group blockIdx.y): the last of the nsplit workgroups merges.  Every storing wave drains
-    // its write-through stores first; the partials are first touched by the merging wave after the ticket (no stale line).
+    // its write-through (sc1) stores first; the merging wave reads them with agent-scope (sc1) loads behind the ticket.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     uint32_t* tk = p.tickets + (size_t)b * gridDim.y + blockIdx.y;
@@ -864,8 +864,8 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
     if (red[0] != 0.0f && wave == DEC_WAVES - 1) {      // (the last wave: waves 0 / 1 go on to append the current token)
       const int i = hq0 * DH + lane * VT;                // 8 outputs per lane: G * 128 = up to 512 per workgroup
       if (lane * VT < G * DH) {
-        SrcAttnMerge src{p.part_ml, p.part_o, p.nsplit, p.num_heads, b};
-        SrcAttnMerge::Raw raw;
+        SrcAttnMergeT<true> src{p.part_ml, p.part_o, p.nsplit, p.num_heads, b};      // agent-scope loads: see row_kernels.h
+        SrcAttnMergeT<true>::Raw raw;
         float x[VT];
         src.fetch(i, raw);
         src.finish(i, raw, x);

@@ -546,6 +546,7 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
 
 }  // namespace omni
 #include "qgemm_exact.h"
+#include "qgemm_midm.h"
 namespace omni {
 
 // Rider workgroup of the fp16-input GEMV (A16): activation row blockIdx.x.  Replays invoke_quant_fuse_sum's row sum --
@@ -1134,10 +1135,13 @@ struct GemmPlan {
   int kw;      // K parts inside a workgroup (decode kernel)
   int mz;      // row tiles (grid.z) of the decode kernel: 2 for M = 65..128 (64-row tiles), up to 4 (32-row tiles)
   int narrow;  // 1: M = 33..128 on 32-row tiles (GemvCfg VAR = 1)
+  int midm;    // 1: w4a8_midm_kernel (qgemm_midm.h): 128 channels x mb * 16 rows per workgroup, mz row tiles in grid.z
 };
 
 // Tuning hook (tests / bench sweeps): waves<=0 and sk<=0 restore the heuristic.
 extern "C" void omni_gemm_set_plan_override(int waves, int sk);
+// mode: -1 heuristic, 0 never the mid-M kernel, 1 wherever its shape conditions hold; sk > 0 forces its K split
+extern "C" void omni_gemm_set_midm_override(int mode, int sk);
 extern "C" void omni_gemm_get_plan(int M, int N, int K, int kalign, int* mb, int* waves, int* sk);
 GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred = false, bool w8 = false);
 
@@ -1246,6 +1250,20 @@ static void launch_gemv_kernel(const GemmArgs& a, const GemmPlan& pl, hipStream_
   else launch_gemv_kernel_nt<MODE, MB, TO_SLAB, true>(a, pl, st);
 }
 
+// mid-M kernel (qgemm_midm.h): grid = (128-channel tiles, K slices, row tiles)
+template <int MODE, bool TO_SLAB>
+static void launch_midm(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
+  const dim3 grid(a.N / 128, pl.sk, pl.mz), block(512);
+  const bool nt = !take_prefetched_weight(a.W);
+  if (pl.mb == 8) {
+    if (nt) hipLaunchKernelGGL((w4a8_midm_kernel<8, MODE, TO_SLAB, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((w4a8_midm_kernel<8, MODE, TO_SLAB, false>), grid, block, 0, st, a);
+  } else {
+    if (nt) hipLaunchKernelGGL((w4a8_midm_kernel<4, MODE, TO_SLAB, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((w4a8_midm_kernel<4, MODE, TO_SLAB, false>), grid, block, 0, st, a);
+  }
+}
+
 template <int MODE, int MB>
 static void launch_gemv(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
   if (pl.sk > 1) {
@@ -1268,6 +1286,16 @@ static int launch_gemm(GemmArgs a, void* ws, size_t ws_bytes, hipStream_t st) {
     a.slab = static_cast<int32_t*>(ws);
   }
   a.kslice = pl.kslice;
+  if (pl.midm) {
+    if (pl.sk > 1) {
+      launch_midm<MODE, true>(a, pl, st);
+      const size_t total = (size_t)a.M * (a.N / 4);
+      hipLaunchKernelGGL((splitk_epilogue_kernel<MODE>), dim3((total + 63) / 64), dim3(64), 0, st, a, pl.sk);
+    } else {
+      launch_midm<MODE, false>(a, pl, st);
+    }
+    return omni_launch_status();
+  }
   if (a.M > 128) {
 #ifdef OMNI_GEMM_TILE_M64
     launch_variant<MODE, 4, 4>(a, pl, st);
@@ -1351,6 +1379,11 @@ static int launch_gemm_partial(GemmArgs a, void* slab, size_t slab_bytes, int* s
   if (slab_bytes < (size_t)pl.sk * a.M * a.N * sizeof(int32_t)) return OMNI_ENOMEM;
   a.slab = static_cast<int32_t*>(slab);
   a.kslice = pl.kslice;
+  if (pl.midm) {
+    launch_midm<MODE, true>(a, pl, st);
+    *sk_out = pl.sk;
+    return omni_launch_status();
+  }
   if (a.M > 128) {      // decode batches of 129 .. 512 rows: the 128 x 256 tile with K slices over grid.y, slabs only
     GemmArgs b = a;
     b.tiles_n = (a.N / 64 + 3) / 4;

@@ -6,6 +6,8 @@ namespace omni {
 // (plan overrides: test / sweep hooks, per enqueueing thread like everything else here)
 static thread_local int g_override_waves = 0;
 static thread_local int g_override_sk = 0;
+static thread_local int g_midm_mode = -1;     // omni_gemm_set_midm_override
+static thread_local int g_midm_sk = 0;
 static thread_local PrefetchArgs g_armed_prefetch = {};   // per enqueueing thread: armed and consumed by the same caller
 // weight tensors named by omni_prefetch_arm_gemm whose GEMV has not been enqueued yet (one-shot, per thread): that GEMV
 // reads its weights with plain loads (they sit in L2), every other one streams non-temporally.  A decode layer has at
@@ -36,6 +38,25 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
   pl.kw = 1;
   pl.mz = 1;
   pl.narrow = 0;
+  pl.midm = 0;
+  // Mid-M kernel (qgemm_midm.h): M = 33 .. 128 rows (one row tile), N in whole 128-channel tiles, K slices of whole
+  // 256-k chunks.  K is split over the grid only while the 128-channel tiles leave CUs idle: the smallest split with
+  // >= 192 workgroups that keeps >= 4 chunks per slice (the int32 slabs cost M x N x 4 bytes per slice, written and read).
+  if (g_midm_mode != 0 && g_override_waves == 0 && g_override_sk == 0 && M > 32 && M <= 128 && N % 128 == 0 && K % KCHUNK == 0) {
+    const int tiles = N / 128;
+    int best = 1;
+    if (tiles < 160) {
+      for (int s2 = 2; s2 <= 16; ++s2) {
+        if (K % (s2 * KCHUNK) != 0 || (K / s2) % kalign != 0 || K / s2 < 4 * KCHUNK) continue;
+        best = s2;
+        if (tiles * s2 >= 192) break;
+      }
+    }
+    if (g_midm_sk > 0 && K % (g_midm_sk * KCHUNK) == 0) best = g_midm_sk;
+    pl.midm = 1; pl.mb = M <= 64 ? 4 : 8; pl.mz = 1; pl.waves = 2; pl.kw = 1;
+    pl.sk = best; pl.kslice = K / best;
+    return pl;
+  }
   if (M > 128) {  // MFMA-bound regime: 128 x 256 tile per workgroup
     pl.mb = 8; pl.waves = 4; pl.sk = 1; pl.kslice = K;
     // Few tiles (decode at batch 129..512: the published A100 figure is quoted at bs = 256): Llama-3-8B's down_proj is
@@ -159,6 +180,11 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
 extern "C" void omni_gemm_set_plan_override(int waves, int sk) {
   omni::g_override_waves = waves;
   omni::g_override_sk = sk;
+}
+
+extern "C" void omni_gemm_set_midm_override(int mode, int sk) {
+  omni::g_midm_mode = mode;
+  omni::g_midm_sk = sk;
 }
 
 extern "C" void omni_gemm_get_plan(int M, int N, int K, int kalign, int* mb, int* waves, int* sk) {

@@ -99,7 +99,14 @@ typedef SrcSlabAddT<true> SrcSlabAddChn;
 typedef SrcSlabAddT<false> SrcSlabAddW8;
 
 // rms_norm_general[_fuse_sum] (+ fused residual sources): NV = roundup32(min(hidden,1024))
-struct SrcAttnMerge {  // merged decode-attention output (flash-decoding partials) of one token: [Hq*128] fp16
+// COH = true (the in-launch merge of kv4_decode_flash_kernel<..., LASTM>): the partials were written by OTHER workgroups of
+// the SAME launch with agent-scope (sc1, write-through) stores; they are read with agent-scope (sc1) loads -- 8-byte relaxed
+// atomics, which the compiler tracks like any load -- that bypass this CU's L1 (MI355X_MICROARCH.md, "Correctness boundaries":
+// sc1 stores AND sc1 loads; plain loads could hit a line an earlier merger of this CU pulled in before the neighbouring
+// ticket group's splits had written their part of it: part_ml holds 8 B per (head, split), so groups share 128-B lines
+// whenever nsplit % 4 != 0).  Same values, same arithmetic: bit-identical to the two-launch form.
+template <bool COH>
+struct SrcAttnMergeT {  // merged decode-attention output (flash-decoding partials) of one token: [Hq*128] fp16
   static constexpr bool BATCH = false;
   static constexpr int NS = 8;   // splits whose loads are issued together (further ones: plain loop)
   struct Raw { float m[NS], l[NS]; v4f a[NS], b[NS]; };
@@ -107,18 +114,34 @@ struct SrcAttnMerge {  // merged decode-attention output (flash-decoding partial
   const float* part_o;    // [B,Hq,S,128]
   int nsplit, num_heads, token;
   __device__ __forceinline__ void pin() const { asm volatile("" ::"s"(part_ml), "s"(part_o), "s"(nsplit), "s"(num_heads)); }
-  __device__ __forceinline__ SrcAttnMerge at_row(int m) const { SrcAttnMerge r = *this; r.token = m; return r; }
+  __device__ __forceinline__ SrcAttnMergeT at_row(int m) const { SrcAttnMergeT r = *this; r.token = m; return r; }
+  static __device__ __forceinline__ float2 ld2(const float* q) {
+    if constexpr (COH) {
+      const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return make_float2(__builtin_bit_cast(float, (uint32_t)v), __builtin_bit_cast(float, (uint32_t)(v >> 32)));
+    } else {
+      return *reinterpret_cast<const float2*>(q);
+    }
+  }
+  static __device__ __forceinline__ v4f ld4(const float* q) {
+    if constexpr (COH) {
+      const float2 lo = ld2(q), hi = ld2(q + 2);
+      return (v4f){lo.x, lo.y, hi.x, hi.y};
+    } else {
+      return *reinterpret_cast<const v4f*>(q);
+    }
+  }
   __device__ __forceinline__ void fetch(int i, Raw& r) const {
     const size_t bh = (size_t)token * num_heads + (i >> 7);
     const int d = i & 127;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {   // branch-free: splits >= nsplit re-read split 0 and get weight 0
       const size_t pi = bh * nsplit + (s < nsplit ? s : 0);
-      const float2 ml = *reinterpret_cast<const float2*>(part_ml + pi * 2);
+      const float2 ml = ld2(part_ml + pi * 2);
       r.m[s] = s < nsplit ? ml.x : -1e30f;
       r.l[s] = ml.y;
-      r.a[s] = *reinterpret_cast<const v4f*>(part_o + pi * 128 + d);
-      r.b[s] = *reinterpret_cast<const v4f*>(part_o + pi * 128 + d + 4);
+      r.a[s] = ld4(part_o + pi * 128 + d);
+      r.b[s] = ld4(part_o + pi * 128 + d + 4);
     }
   }
   __device__ __forceinline__ void finish(int i, const Raw& r, float (&x)[VT]) const {
@@ -133,7 +156,7 @@ struct SrcAttnMerge {  // merged decode-attention output (flash-decoding partial
     for (int s0 = NS; s0 < nsplit; s0 += NS) {
       float mm[NS];
 #pragma unroll
-      for (int u = 0; u < NS; ++u) mm[u] = part_ml[(bh * nsplit + (s0 + u < nsplit ? s0 + u : 0)) * 2];
+      for (int u = 0; u < NS; ++u) mm[u] = ld2(part_ml + (bh * nsplit + (s0 + u < nsplit ? s0 + u : 0)) * 2).x;
 #pragma unroll
       for (int u = 0; u < NS; ++u) M = __builtin_fmaxf(M, s0 + u < nsplit ? mm[u] : -1e30f);
     }
@@ -156,9 +179,9 @@ struct SrcAttnMerge {  // merged decode-attention output (flash-decoding partial
 #pragma unroll
       for (int u = 0; u < NS; ++u) {   // branch-free: splits >= nsplit re-read split 0 and are skipped below
         const size_t pi = bh * nsplit + (s0 + u < nsplit ? s0 + u : 0);
-        ml[u] = *reinterpret_cast<const float2*>(part_ml + pi * 2);
-        a[u] = *reinterpret_cast<const v4f*>(part_o + pi * 128 + d);
-        b[u] = *reinterpret_cast<const v4f*>(part_o + pi * 128 + d + 4);
+        ml[u] = ld2(part_ml + pi * 2);
+        a[u] = ld4(part_o + pi * 128 + d);
+        b[u] = ld4(part_o + pi * 128 + d + 4);
       }
 #pragma unroll
       for (int u = 0; u < NS; ++u) {
@@ -175,6 +198,7 @@ struct SrcAttnMerge {  // merged decode-attention output (flash-decoding partial
     for (int e = 0; e < VT; ++e) x[e] = (float)(half_t)rounded_f32(o[e] * inv);   // = kv4_decode_merge_kernel's fp16 output
   }
 };
+typedef SrcAttnMergeT<false> SrcAttnMerge;
 
 // `src`: the row's source (already at_row()); `sink`: where the row's int8 codes / fp16 scale / fp16 sum go (SinkGlobal:
 // the row kernels' own outputs; the fused MLP launch parks the codes in LDS and publishes them in MFMA operand order).

@@ -225,6 +225,65 @@ def test_decode_attention_f16_amax(hist, Hq, Hk, single_launch):
         assert not fused_ext._tickets(dev()).any()
 
 
+@pytest.mark.parametrize("nsplit", [3, 5, 6, 10])
+def test_decode_attention_single_launch_fresh_inputs_stale_lines(nsplit):
+    """The in-launch merge reads other workgroups' partials of the SAME launch (agent-scope stores, ticket, agent-scope loads:
+    csrc/row_kernels.h SrcAttnMergeT<true>).  Every repeat has NEW q / k / v and NEW page contents, is compared with a fresh
+    two-launch result, and runs right after (a) the two-launch path has left the PREVIOUS repeat's partials in the same
+    workspace and (b) a reduction over the whole workspace has pulled those lines into the L1s / L2s of the chip: a merger
+    that hit a stale line would reproduce the previous repeat's values.  nsplit % 4 != 0 makes neighbouring ticket groups
+    share 128-B lines of the (m, l) array (8 B per (head, split))."""
+    import omniserve_backend.fused_attention_pure_dense as fa  # noqa: F401  (page layout helpers live with the mirrors)
+    from omniserve_amd import _lib
+    from omniserve_amd.backend import fused_ext
+    from oracle import kv4
+    from tests.util import GpuPagedKV
+    D, BASE, Hq, Hk = 128, 500000.0, 32, 8
+    hist = [1000, 900, 1023, 700, 650, 1010]
+    B = len(hist)
+    rng = np.random.default_rng(nsplit)
+    pages = (max(hist) + 64) // 64 + 1
+    n_pages = B * pages
+    kc, vc = kv4.PagedKV4(n_pages, Hk, D), kv4.PagedKV4(n_pages, Hk, D)
+    for c in (kc, vc):
+        c.pool[:] = rng.integers(0, 256, c.pool.shape, dtype=np.uint8)
+        for p in range(n_pages):
+            c.scales(p)[:] = (0.05 + 0.15 * rng.random((Hk, 64))).astype(np.float16)
+            c.zeros(p)[:] = (6.0 + 3.0 * rng.random((Hk, 64))).astype(np.float16)
+    kidx = rng.permutation(n_pages).reshape(B, pages)
+    vidx = rng.permutation(n_pages).reshape(B, pages)
+    g1, g2 = GpuPagedKV(kc, vc, kidx, vidx), GpuPagedKV(kc, vc, kidx, vidx)
+    data_bytes = Hk * 64 * D // 2
+    lens = to_dev(np.asarray(hist, np.int32) + 1)
+    T = max(hist) + 1
+    gen = torch.Generator(device=dev()).manual_seed(100 + nsplit)
+    lib = _lib.lib()
+    ws = _lib.workspace(lib.omni_kv4_decode_workspace_bytes(B, Hq, D, T), dev(), "attn")
+    lib.omni_kv4_decode_set_split_override(nsplit)
+    try:
+        for rep in range(24):
+            qkv = torch.randn((B, (Hq + 2 * Hk) * D), generator=gen, device=dev(), dtype=torch.float32).half() * (1.0 + rep % 3)
+            q = qkv[:, : Hq * D].view(B, Hq, D)
+            k = qkv[:, Hq * D:(Hq + Hk) * D].view(B, Hk, D)
+            v = qkv[:, (Hq + Hk) * D:].view(B, Hk, D)
+            for a, b in ((g1.kpool, g2.kpool), (g1.vpool, g2.vpool)):
+                a[:, :data_bytes] = torch.randint(0, 256, (a.shape[0], data_bytes), generator=gen, device=dev(), dtype=torch.uint8)
+                b.copy_(a)
+            want = torch.empty((B, Hq * D), dtype=torch.float16, device=dev())
+            amax1, amax2 = fused_ext.new_amax_slots(B, dev()), fused_ext.new_amax_slots(B, dev())
+            fused_ext.decode_attention_f16_amax(want, amax1, q, k, v, g1.table, lens, 64, T, BASE, single_launch=False)
+            _ = float(ws.view(torch.int32).sum())          # every CU reads the workspace: the two-launch partials are cached
+            out = torch.full((B, Hq * D), 7.0, dtype=torch.float16, device=dev())
+            fused_ext.decode_attention_f16_amax(out, amax2, q, k, v, g2.table, lens, 64, T, BASE, single_launch=True)
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int16), want.view(torch.int16)), (nsplit, rep)
+            assert torch.equal(amax1, amax2), (nsplit, rep)
+            assert torch.equal(g1.kpool, g2.kpool) and torch.equal(g1.vpool, g2.vpool)
+        assert not fused_ext._tickets(dev()).any()
+    finally:
+        lib.omni_kv4_decode_set_split_override(0)
+
+
 # ---- W8A8 forms (LServe models): same hand-off, no zero-point term, no row sums ---------------------------------------
 def _w8(N, K, seed):
     rng = np.random.default_rng(seed)
