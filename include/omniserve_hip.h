@@ -31,9 +31,11 @@ int omni_abi_version(void);
  * W4A8 / W8A8 GEMM         out[m,n] = fp16( epilogue( sum_k A[m,k] * W[n,k] ) )
  * -------------------------------------------------------------------------------------------- */
 
-/* Bytes of int32 split-K scratch the GEMM entry points may need for an (M,N,K) problem.  Callers
- * keep one scratch buffer per device/stream of at least this size (it is not persistent state:
- * contents are dead after the call). */
+/* Bytes of int32 split-K scratch the GEMM entry points may need for an (M,N,K) problem -- the plain entry points (which
+ * return OMNI_ENOMEM when their plan splits K and the scratch is missing or smaller) AND the slab-only forms
+ * (omni_*_gemm_partial, M <= 512: at least one M x N int32 slab even when K stays whole).  Callers keep one scratch buffer
+ * per device/stream of at least this size (it is not persistent state: contents are dead after the call).
+ * ABI 3 (omni_abi_version): before, M > 128 returned 0 for plans without a K split, which under-sized the slab-only forms. */
 size_t omni_gemm_workspace_bytes(int M, int N, int K);
 
 /* Tuning / introspection hooks (tests and bench sweeps; not used by the serving path):

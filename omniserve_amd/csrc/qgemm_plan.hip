@@ -219,22 +219,26 @@ extern "C" int omni_gemm_rowfree_ok(int M, int hidden, int attn_dim, int inter, 
 
 extern "C" size_t omni_gemm_workspace_bytes(int M, int N, int K) {
   if (M < 1 || N < 64 || K < 64) return 0;
-  if (M > 128) {                                          // prefill tile: split K only where few tiles would leave the chip idle
-    const omni::GemmPlan pl = omni::plan_gemm(M, N, K, K % 128 == 0 ? 128 : 64, false, false);
-    return pl.sk > 1 ? (size_t)pl.sk * M * N * sizeof(int32_t) : 0;
-  }
-  // sized from the very plans the launches use: the maximum over the K alignments of the three GEMM flavours
-  // (64; 128 for per-group) and over the plain / deferred (slab-only) variants
-  int sk = 1;
-  for (int kalign = 64; kalign <= 128; kalign *= 2) {
-    if (K % kalign != 0) continue;
-    for (int deferred = 0; deferred < 2; ++deferred) {
-      for (int w8 = 0; w8 < 2; ++w8) {
-        const omni::GemmPlan pl = omni::plan_gemm(M, N, K, kalign, deferred != 0, w8 != 0);
-        if (pl.sk > sk) sk = pl.sk;
+  // Sized from the very plans the launches use: the maximum over the K alignments of the three GEMM flavours (64; 128 for
+  // per-group), over the plain / deferred (slab-only) variants and over the mid-M kernel on / off (so that a buffer sized
+  // once stays large enough under omni_gemm_set_midm_override).  Up to 512 rows the slab-only entry points
+  // (omni_*_gemm_partial) write their accumulators even when the plan keeps K whole: at least one slab.
+  using namespace omni;
+  int sk = M <= 512 ? 1 : 0;
+  const int keep_mode = g_midm_mode;
+  for (int midm = 0; midm < 2; ++midm) {
+    g_midm_mode = midm ? (keep_mode == 0 ? 1 : keep_mode) : 0;
+    for (int kalign = 64; kalign <= 128; kalign *= 2) {
+      if (K % kalign != 0) continue;
+      for (int deferred = 0; deferred < 2; ++deferred) {
+        for (int w8 = 0; w8 < 2; ++w8) {
+          const GemmPlan pl = plan_gemm(M, N, K, kalign, deferred != 0, w8 != 0);
+          if (pl.sk > 1 && pl.sk > sk) sk = pl.sk;
+        }
       }
     }
   }
+  g_midm_mode = keep_mode;
   return (size_t)sk * M * N * sizeof(int32_t);
 }
 
@@ -301,4 +305,6 @@ extern "C" int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, i
   return OMNI_OK;
 }
 
-extern "C" int omni_abi_version(void) { return 2; }
+// 3: omni_gemm_set_weight_policy removed (the load policy is per call: omni_prefetch_arm_gemm mode bit 0x20);
+//    omni_gemm_workspace_bytes covers the slab-only forms (>= one slab up to 512 rows); omni_gemm_set_midm_override added.
+extern "C" int omni_abi_version(void) { return 3; }

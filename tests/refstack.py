@@ -128,7 +128,7 @@ class OracleLib:
 
     # ---- introspection / sizing ------------------------------------------------------------------------------
     def omni_abi_version(self):
-        return 2
+        return 3
 
     def omni_gemm_workspace_bytes(self, M, N, K):
         return 1 << 16

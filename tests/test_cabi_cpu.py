@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(h, s), "library does not export %s" % s
     assert syms == set(_lib.PROTOTYPES), "ctypes prototypes out of sync with the header"
-    assert h.omni_abi_version() == 2
+    assert h.omni_abi_version() == 3
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():

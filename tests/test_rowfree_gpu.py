@@ -277,7 +277,7 @@ def test_decode_attention_single_launch_fresh_inputs_stale_lines(nsplit):
             fused_ext.decode_attention_f16_amax(out, amax2, q, k, v, g2.table, lens, 64, T, BASE, single_launch=True)
             torch.cuda.synchronize()
             assert torch.equal(out.view(torch.int16), want.view(torch.int16)), (nsplit, rep)
-            assert torch.equal(amax1, amax2), (nsplit, rep)
+            assert np.array_equal(_row_amax(amax1, B), _row_amax(amax2, B)), (nsplit, rep)
             assert torch.equal(g1.kpool, g2.kpool) and torch.equal(g1.vpool, g2.vpool)
         assert not fused_ext._tickets(dev()).any()
     finally:

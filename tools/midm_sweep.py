@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omniserve_amd import _lib  # noqa: E402
-from omniserve_amd.backend import fused_ext, qgemm_w4a8_per_chn, qgemm_w4a8_per_group, qgemm_w8a8  # noqa: E402
+from omniserve_amd.backend import _gemm_common, fused_ext, qgemm_w4a8_per_chn, qgemm_w4a8_per_group, qgemm_w8a8  # noqa: E402
 
 dev = torch.device("cuda:0")
 lib = _lib.lib()
@@ -84,6 +84,8 @@ def run(model, M, N, K, mode):
         if sk and (K % (sk * 256) or K // sk < 512):
             continue
         lib.omni_gemm_set_midm_override(1, sk)
+        _gemm_common._ws_bytes.clear()
+        _lib.workspace(16 * M * N * 4, dev, "gemm")
         out.zero_()
         full(0)
         skm = partial(0)
