@@ -53,6 +53,10 @@ extern "C" int omni_w4a8_per_chn_gemm_partial_f16(const void* act_f16, const voi
 
 OMNI_CLK_READER(omni_debug_clocks_gemm_chn)
 #ifdef OMNI_DEBUG_CLOCKS
+// timeline probe of the mid-M kernel (tools/midm_timeline.py): 2 workgroups x 8 waves x 104 stamps
+extern "C" int omni_debug_timeline_midm_chn(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(omni::omni_dbg_midm), sizeof(omni::omni_dbg_midm)) == hipSuccess ? 0 : -5;
+}
 // timeline probe of the exact prefill kernel (tools/gemm_timeline.py): 4 marks per workgroup
 extern "C" int omni_debug_timeline_gemm_chn(unsigned long long* out, int nwg) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(omni::omni_dbg_tl), (size_t)nwg * 5 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;

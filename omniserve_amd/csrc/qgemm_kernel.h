@@ -1255,12 +1255,13 @@ template <int MODE, bool TO_SLAB>
 static void launch_midm(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
   const dim3 grid(a.N / 128, pl.sk, pl.mz), block(512);
   const bool nt = !take_prefetched_weight(a.W);
+  const GemmArgs& b = a;
   if (pl.mb == 8) {
-    if (nt) hipLaunchKernelGGL((w4a8_midm_kernel<8, MODE, TO_SLAB, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((w4a8_midm_kernel<8, MODE, TO_SLAB, false>), grid, block, 0, st, a);
+    if (nt) hipLaunchKernelGGL((w4a8_midm_kernel<8, MODE, TO_SLAB, true>), grid, block, 0, st, b);
+    else hipLaunchKernelGGL((w4a8_midm_kernel<8, MODE, TO_SLAB, false>), grid, block, 0, st, b);
   } else {
-    if (nt) hipLaunchKernelGGL((w4a8_midm_kernel<4, MODE, TO_SLAB, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((w4a8_midm_kernel<4, MODE, TO_SLAB, false>), grid, block, 0, st, a);
+    if (nt) hipLaunchKernelGGL((w4a8_midm_kernel<4, MODE, TO_SLAB, true>), grid, block, 0, st, b);
+    else hipLaunchKernelGGL((w4a8_midm_kernel<4, MODE, TO_SLAB, false>), grid, block, 0, st, b);
   }
 }
 

@@ -1,5 +1,5 @@
-// Mid-M kernel (M = 33 .. 128 rows per tile; grid.z row tiles beyond): the decode GEMMs at the batches between the
-// single-wave GEMV tiles (M <= 32) and the MFMA-bound prefill tile (M > 256).  Included by qgemm_kernel.h.
+// Mid-M kernel (M = 33 .. 128 rows per tile): the decode GEMMs at the batches between the single-wave GEMV tiles (M <= 32)
+// and the MFMA-bound prefill tile (M > 128).  Included by qgemm_kernel.h.
 //
 // At 64 .. 128 rows a weight byte meets 64 .. 128 activation bytes: the launch is bound by HBM AND close to the MFMA floor
 // (Llama-3-8B gate_up at M = 128: 58.7 MB = 10.2 us of stream, 30 GOP = 7.6 us of int8 MFMA), so every byte may enter a
@@ -10,60 +10,136 @@
 //
 //   * workgroup = 128 output channels (two 64-channel groups) x all rows of the tile (MB x 16 <= 128) x one K slice
 //     (the whole K where N / 128 tiles fill the chip: no slab), 8 waves = 2 groups x 4 K PHASES: wave (g, s) owns k-step
-//     s of every 256-k chunk for group g and all rows.  A weight byte is loaded once, by one wave, straight into VGPRs
-//     (the packed tile IS the MFMA A operand, as everywhere in this library; 1-KiB coalesced non-temporal wave loads, a
-//     ring of R chunks per wave = 8 x R x 2 KiB in flight per CU); the unpack runs once per byte (40 VALU per 32 MFMAs
-//     at 128 rows -- the 32-row tiles spend 40 per 8);
-//   * the activation chunk (rows x 256 B) goes global -> LDS by LDS-DMA, once per workgroup, double buffered, one barrier
-//     per chunk; all 8 waves read their k-step of it as MFMA B operands (image and lane transposition of the packed
-//     registers as in w4a8_gemm_exact_kernel: LDS row m keeps piece q at slot q ^ (m & 15));
-//   * the four K-phase partials of a group meet in LDS after the K loop (two exchange rounds over the activation
-//     buffers' memory, static accumulator indices only); wave (g, s) finishes row quarter s: epilogue to fp16, or the
-//     int32 slab of its K slice for the slab consumers / splitk_epilogue_kernel.
+//     s of every 256-k chunk for group g and all rows.  A weight byte is fetched once, by one wave; the unpack runs once per
+//     byte (48 VALU per 32 MFMAs at 128 rows -- the 32-row tiles spend 40 per 8);
+//   * EVERYTHING the K loop reads arrives by LDS-DMA (global_load_lds, issued from inline asm, completion owned by explicit
+//     vmcnt waits): the activation chunk (rows x 256 B, once per workgroup, NBUF buffers, one barrier per chunk; image
+//     and lane transposition of the packed registers as in w4a8_gemm_exact_kernel: LDS row m keeps piece q at slot q ^
+//     (m & 15)), the wave's own 2 KiB of packed weights per chunk (a private NBUF-slot ring, read back with two
+//     ds_read_b128 as the MFMA A operand source) and the per-group parameters.  Why not registers for the weights: the CU's
+//     vector memory path returns in order, so an L2-hit activation piece queued behind an HBM-miss weight load lands with
+//     HBM latency; every chunk needs its activation tile, so with the tile requested one chunk ahead (the first version:
+//     weights in a register ring, counted compiler waits) a chunk took one loaded HBM latency -- 1.56 us against 0.49 us of
+//     MFMA, 25 us per launch on the shape above (profiles/r05_a).  All requests of chunk c + D are now issued in chunk c
+//     (D = NBUF - 1), and hipcc's own waitcnt pass sees no vector memory operation in the loop: it cannot fold a fresh DMA
+//     piece into a counted wait for an old register load, and there is no loop-carried register that an async load targets;
+//   * the four K-phase partials of a group meet in LDS after the K loop (two exchange rounds over the ring memory, static
+//     accumulator indices only); wave (g, s) finishes row quarter s: epilogue to fp16, or the int32 slab of its K slice for
+//     the slab consumers / splitk_epilogue_kernel.
 // Activation traffic per launch = (N / 128) x M x K bytes from L2 (2x the weight bytes at M = 128), weights 1x from HBM.
+// LDS-DMA reaches all 160 KiB of gfx950's LDS (tools/lds_dma_hi_probe.hip).
 #pragma once
 
 namespace omni {
 
-#ifndef OMNI_MIDM_RING
-// chunks of weights in flight per wave.  Loads return in order and every chunk's top waits for this wave's DMA pieces,
-// i.e. for every refill but the newest: a deeper ring holds nothing more in flight (and 3 .. 4 slots spilled at 128 rows).
-#define OMNI_MIDM_RING 2
-#endif
 #ifndef OMNI_MIDM_PIPE
 #define OMNI_MIDM_PIPE 1          // B-operand reads pinned PRE row blocks ahead of their MFMAs (sched_group_barrier)
 #endif
 
-// NI LDS-DMA pieces of one wave (piece = 4 rows x 256 B, LDS image lane-linear from lds_dst + i * 1024), one scalar base
-// (the chunk's first byte of row 0) + a per-piece lane offset (row * K + swizzled 16-B piece).  One statement: M0
-// (compiler-reserved) is saved once and restored at the end.
+// LDS-DMA statements of one wave.  A piece = one wave instruction: lane l's 16 B (dwordx4) or 4 B (dword) land at
+// lds_dst + piece * (64 * bytes) + l * bytes.  Source = scalar base + the lane's 32-bit offset (+ an immediate).  M0
+// (compiler-reserved) is saved once per statement and restored at its end.
+#define OMNI_DMA_HEAD "s_nop 4\n\ts_mov_b32 %0, m0\n\t"
+#define OMNI_DMA_TAIL "s_mov_b32 m0, %0"
+// activation pieces: 4 rows x 256 B each
 __device__ __forceinline__ void lds_dma16_x2(const void* sbase, uint32_t v0, uint32_t v1, uint32_t lds_dst) {
   uint32_t keep;
-  asm volatile(
-      "s_nop 4\n\ts_mov_b32 %0, m0\n\t"
+  asm volatile(OMNI_DMA_HEAD
       "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "s"(sbase), "v"(v0), "v"(v1), "s"(lds_dst)
-      : "memory", "scc");
+      OMNI_DMA_TAIL
+      : "=&s"(keep) : "s"(sbase), "v"(v0), "v"(v1), "s"(lds_dst) : "memory", "scc");
 }
 __device__ __forceinline__ void lds_dma16_x4(const void* sbase, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3,
                                              uint32_t lds_dst) {
   uint32_t keep;
-  asm volatile(
-      "s_nop 4\n\ts_mov_b32 %0, m0\n\t"
+  asm volatile(OMNI_DMA_HEAD
       "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "s"(sbase), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds_dst)
-      : "memory", "scc");
+      OMNI_DMA_TAIL
+      : "=&s"(keep) : "s"(sbase), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds_dst) : "memory", "scc");
 }
+// packed int4 weights of one k-step: 1 KiB (two consecutive 512-B tiles) of each of the group's two tile rows.
+// (No immediate offsets on LDS-DMA instructions: the instruction offset is added to the LDS address as well.)
+template <bool NT>
+__device__ __forceinline__ void lds_dma_w4(const void* sbase, uint32_t v0, uint32_t v1, uint32_t lds_dst) {
+  uint32_t keep;
+  if constexpr (NT)
+    asm volatile(OMNI_DMA_HEAD
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 nt\n\t"
+        OMNI_DMA_TAIL
+        : "=&s"(keep) : "s"(sbase), "v"(v0), "v"(v1), "s"(lds_dst) : "memory", "scc");
+  else
+    asm volatile(OMNI_DMA_HEAD
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+        OMNI_DMA_TAIL
+        : "=&s"(keep) : "s"(sbase), "v"(v0), "v"(v1), "s"(lds_dst) : "memory", "scc");
+}
+// int8 weights of one k-step: four 16-row blocks
+template <bool NT>
+__device__ __forceinline__ void lds_dma_w8(const void* sbase, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t lds_dst) {
+  uint32_t keep;
+  if constexpr (NT)
+    asm volatile(OMNI_DMA_HEAD
+        "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1 nt\n\t"
+        OMNI_DMA_TAIL
+        : "=&s"(keep) : "s"(sbase), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds_dst) : "memory", "scc");
+  else
+    asm volatile(OMNI_DMA_HEAD
+        "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+        OMNI_DMA_TAIL
+        : "=&s"(keep) : "s"(sbase), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds_dst) : "memory", "scc");
+}
+// per-group second-level scales and zeros of one k-step: one dword per lane each (256 B per piece)
+__device__ __forceinline__ void lds_dma_gp(const void* sb_scales, const void* sb_zeros, uint32_t v0, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(OMNI_DMA_HEAD
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %3, %1\n\t"
+      "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %3, %2\n\t"
+      OMNI_DMA_TAIL
+      : "=&s"(keep) : "s"(sb_scales), "s"(sb_zeros), "v"(v0), "s"(lds_dst) : "memory", "scc");
+}
+// one piece (16 B per lane, or 4 B per lane with DW) as its own statement: the K loop spreads a chunk's pieces over its MFMAs
+template <bool NT, bool DW>
+__device__ __forceinline__ void lds_dma_piece(const void* sbase, uint32_t v0, uint32_t lds_dst) {
+  uint32_t keep;
+  if constexpr (DW)
+    asm volatile(OMNI_DMA_HEAD "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %2, %1\n\t" OMNI_DMA_TAIL
+                 : "=&s"(keep) : "s"(sbase), "v"(v0), "s"(lds_dst) : "memory");
+  else if constexpr (NT)
+    asm volatile(OMNI_DMA_HEAD "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 nt\n\t" OMNI_DMA_TAIL
+                 : "=&s"(keep) : "s"(sbase), "v"(v0), "s"(lds_dst) : "memory");
+  else
+    asm volatile(OMNI_DMA_HEAD "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t" OMNI_DMA_TAIL
+                 : "=&s"(keep) : "s"(sbase), "v"(v0), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int V> struct IntTag { static constexpr int value = V; };
+
+#ifdef OMNI_DEBUG_CLOCKS
+// timeline probe (tools/midm_timeline.py): per wave of workgroups 0 and gridDim.x - 1, shader-clock stamps
+//   [0] entry, [1] prologue requests issued, then per chunk c < 24: [4 + 4c] before the DMA wait, [+1] behind it, [+2] behind the
+//   barrier, [+3] behind the chunk's last MFMA issue; [100] K loop done, [101] partials exchanged, [102] stores issued
+static __device__ unsigned long long omni_dbg_midm[2 * 8 * 104];
+#define MIDM_STAMP(i)                                                                                              \
+  do {                                                                                                             \
+    if (dbg_on && lane == 0) dbg_t[(i)] = __builtin_readcyclecounter();                                            \
+  } while (0)
+#else
+#define MIDM_STAMP(i) do {} while (0)
+#endif
 
 template <int MB, int MODE, bool TO_SLAB, bool NT>
 __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
@@ -71,17 +147,27 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
   constexpr int MT = MB * 16;
   constexpr int NG = 2, NW = 8;
   constexpr int CH = KCHUNK;                               // k per chunk: four 64-k steps, one per K phase
-  constexpr int NI = MT / 32;                              // DMA pieces per wave and chunk (MT rows / 8 waves / 4 rows)
-  constexpr int WL = (MODE == MODE_W8) ? 4 : 2;
-  constexpr int GP = (MODE == MODE_GRP) ? 2 : 0;           // second-level parameter loads per k-step
-  constexpr int R = OMNI_MIDM_RING;
+  constexpr int NI = MT / 32;                              // activation pieces per wave and chunk (MT rows / 8 waves / 4 rows)
+  constexpr int WL = (MODE == MODE_W8) ? 4 : 2;            // weight pieces per wave and chunk
+  constexpr int GP = (MODE == MODE_GRP) ? 2 : 0;           // second-level parameter pieces
+  constexpr int OPS = NI + WL + GP;                        // vector memory operations per wave and chunk
+  // ring depth: what fits 160 KiB next to the epilogue operands.  128 rows: 3 x (32 KiB tile + 8 x 2 KiB of weights) =
+  // 144 KiB (W8A8 rows are twice the bytes: 2 slots); 64 rows: 4 x (16 + 16) = 128 KiB.  D = chunks in flight behind the one
+  // being multiplied; vmcnt counts at most 63 operations: (NBUF - 1) x OPS <= 32.
+  constexpr int NBUF = MB == 8 ? (MODE == MODE_W8 ? 2 : 3) : (MODE == MODE_W8 ? 3 : 4);
+  constexpr int D = NBUF - 1;
+  static_assert(D * OPS < 64, "vmcnt is a 6-bit counter");
   constexpr int HB = MB / 2, QB = MB / 4;
-  constexpr int LDS_A = 2 * MT * CH;                       // two activation buffers (LDS-DMA destinations stay below 64 KiB)
+  constexpr int ABUF = MT * CH;                            // one activation buffer
+  constexpr int WSLOT = WL * 1024 + (GP ? 512 : 0);        // one ring slot of one wave
+  constexpr int LDS_A = NBUF * ABUF;
+  constexpr int LDS_W = NW * NBUF * WSLOT;
   constexpr int LDS_RED = NW * HB * 4 * 1024;              // first exchange round: every wave parks half of its accumulators
-  constexpr int LDS_MAIN = LDS_RED > LDS_A ? LDS_RED : LDS_A;
+  constexpr int LDS_MAIN = LDS_RED > LDS_A + LDS_W ? LDS_RED : LDS_A + LDS_W;
   constexpr int LDS_EPI = TO_SLAB ? 0 : (64 * NG + MT) * 4;
+  static_assert(LDS_MAIN + LDS_EPI <= 160 * 1024, "LDS");
   static_assert(STEPS == 4 && KCHUNK == 256, "one k-step of a 256-k chunk per K phase");
-  __shared__ __attribute__((aligned(1024))) uint8_t smem[LDS_MAIN + LDS_EPI + 16];
+  __shared__ __attribute__((aligned(1024))) uint8_t smem[LDS_MAIN + LDS_EPI];
   uint32_t* const epi_w = reinterpret_cast<uint32_t*>(smem + LDS_MAIN);              // {wscale, w_sz} per channel of the tile
   uint32_t* const epi_a = reinterpret_cast<uint32_t*>(smem + LDS_MAIN) + 64 * NG;    // {ascale, asum} per row of the tile
   // one batch of scalar loads for the prologue's kernel arguments
@@ -95,29 +181,40 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
   const int m0 = blockIdx.z * MT;
   const int k0 = (int)blockIdx.y * p.kslice;
   const int nchunks = p.kslice / CH;
+#ifdef OMNI_DEBUG_CLOCKS
+  const bool dbg_on = blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+  unsigned long long* const dbg_t = omni_dbg_midm + ((blockIdx.x == 0 ? 0 : 8) + wave) * 104;
+  MIDM_STAMP(0);
+#endif
 
-  // ---- weights: HBM -> VGPR ring, one k-step per chunk ----------------------------------------------------
+  // ---- request addressing ---------------------------------------------------------------------------------------
   const int lx = (lane >> 3) & 1, lc = lane & 7, le = lane >> 4;
-  const uint8_t* wbase;
-  if constexpr (MODE == MODE_W8) wbase = p.W + (size_t)(ng * 64 + (lane & 15)) * p.K + (lane >> 4) * 16 + k0 + s * KSTEP;
-  else wbase = p.W + ((size_t)(2 * ng + lx) * (p.K / 32) + (k0 + s * KSTEP) / 32) * 512 + (lc * 4 + le) * 16;
-  auto load_w = [&](int c, int j) -> uint4 {      // chunk c of the slice; W4: j = tile parity, W8: j = 16-row block
-    const uint8_t* ptr;
-    if constexpr (MODE == MODE_W8) ptr = wbase + (size_t)j * 16 * p.K + (size_t)c * CH;
-    else ptr = wbase + (size_t)(c * (CH / 32) + j) * 512;
-    v4i v;
-    if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(ptr));
-    else v = *reinterpret_cast<const v4i*>(ptr);
-    return make_uint4((uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
-  };
-  const size_t gcol = (size_t)(2 * ng + lx) * 32 + lc * 4;
-  auto load_gp = [&](const uint8_t* base, int c) -> uint32_t {     // 128-k group of (chunk c, phase s)
-    return *reinterpret_cast<const uint32_t*>(base + (size_t)(k0 / 128 + 2 * c + (s >> 1)) * p.N + gcol);
-  };
-  uint4 wq[R][WL];
-  uint32_t gs[R], gz[R];
-
-  // ---- activations: LDS-DMA, LDS row m = 256 B with piece q at slot q ^ (m & 15) -----------------------------
+  // Every request is QUAD-COALESCED: four consecutive lanes ask for 64 consecutive bytes in ascending order.  The CU's
+  // texture-address unit takes one such quad per clock; a quad whose lanes point at four different 64-B segments (the MFMA
+  // operand's own lane map over the packed tile: lanes 64 B apart) or at one segment in permuted order (a full XOR swizzle of
+  // the activation row) goes through at a quarter of that -- 16 B/clk per CU, which IS what the first two versions of this
+  // kernel ran at (48 KiB per chunk and CU at 128 rows: 1.5 us; profiles/r05_a).  An LDS-DMA image is lane-linear, but the
+  // lane that fetches a piece need not be the lane that consumes it: the requests below are laid out for the memory path,
+  // and the consumers pick their pieces out of LDS (2-way bank conflicts on those reads: 10 + 2 per 32 MFMAs).
+  // weights: instruction j of a k-step = 1 KiB contiguous.  W4: tiles 2 s, 2 s + 1 of tile row 2 ng + j (lane l: bytes
+  // 16 l ..); W8: the 16 rows of block j, 64 B each (lane l: row l >> 2, 16-B piece l & 3).  Offsets from p.W, chunk 0.
+  uint32_t wvo[MODE == MODE_W8 ? 4 : 2];
+  if constexpr (MODE == MODE_W8) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      wvo[j] = (uint32_t)(ng * 64 + j * 16 + (lane >> 2)) * (uint32_t)p.K + (uint32_t)((lane & 3) * 16 + k0 + s * KSTEP);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      wvo[j] = ((uint32_t)(2 * ng + j) * (uint32_t)(p.K / 32) + (uint32_t)((k0 + s * KSTEP) / 32)) * 512u + (uint32_t)(lane * 16);
+  }
+  // where this lane's operand pieces landed inside a ring slot.  W4: chunk (n3 = lc, k6 = le) of tile (parity tp) of tile
+  // row lx: lx * 1024 + tp * 512 + (lc * 4 + le) * 16; W8: row lane & 15 of block j, piece lane >> 4: j * 1024 + row * 64 + piece * 16
+  const uint32_t wrd = MODE == MODE_W8 ? (uint32_t)((lane & 15) * 64 + (lane >> 4) * 16) : (uint32_t)(lx * 1024 + (lc * 4 + le) * 16);
+  const uint32_t gvo = (uint32_t)((2 * ng + lx) * 32 + lc * 4);        // per-group parameter column of this lane
+  // activations: a piece = 4 rows x 256 B; LDS row m keeps its 16-B piece q at slot q ^ ((m & 3) << 2) -- whole 64-B groups
+  // move, the order inside a group stays (a full q ^ (m & 15) is conflict-free for the B reads but permutes the quads).
+  // lane -> (row dr of the piece's 4, slot ds)
   uint32_t dvo[NI];
   {
     const int dr = lane >> 4, ds = lane & 15;
@@ -125,18 +222,38 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
     for (int i = 0; i < NI; ++i) {
       const int rl = wave * (MT / NW) + i * 4 + dr;                 // row inside the tile
       const int row = (m0 + rl) < p.M ? (m0 + rl) : (p.M - 1);      // rows beyond M re-read the last row (never stored)
-      dvo[i] = (uint32_t)row * (uint32_t)p.K + (uint32_t)((ds ^ (rl & 15)) << 4);
+      dvo[i] = (uint32_t)row * (uint32_t)p.K + (uint32_t)((ds ^ ((rl & 3) << 2)) << 4);
     }
   }
   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)smem;
-  auto dma_chunk = [&](int c) {
-    const uint8_t* sb = reinterpret_cast<const uint8_t*>(p.A) + (size_t)k0 + (size_t)c * CH;
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(c & 1) * (MT * CH) + (uint32_t)wave * (MT / NW) * 256);
-    if constexpr (NI == 4) lds_dma16_x4(sb, dvo[0], dvo[1], dvo[2], dvo[3], dst);
-    else lds_dma16_x2(sb, dvo[0], dvo[1], dst);
+  const uint32_t wring = __builtin_amdgcn_readfirstlane((uint32_t)(LDS_A + wave * NBUF * WSLOT));   // this wave's ring, from smem
+  // all requests of chunk c into buffer / slot b
+  // request number k (static) of chunk c into buffer / slot b: activation pieces first, then weights, then parameters
+  auto issue_piece = [&](auto k_tag, int c, int b) {
+    constexpr int k = decltype(k_tag)::value;
+    if constexpr (k < NI) {
+      const uint8_t* sa = reinterpret_cast<const uint8_t*>(p.A) + (size_t)k0 + (size_t)c * CH;
+      const uint32_t adst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)b * ABUF + (uint32_t)wave * (MT / NW) * 256 + k * 1024);
+      lds_dma_piece<false, false>(sa, dvo[k], adst);
+    } else if constexpr (k < NI + WL) {
+      constexpr int j = k - NI;
+      const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds_base + wring + (uint32_t)b * WSLOT + j * 1024);
+      if constexpr (MODE == MODE_W8) lds_dma_piece<NT, false>(p.W + (size_t)c * CH, wvo[j], wdst);
+      else lds_dma_piece<NT, false>(p.W + (size_t)c * (CH / 32) * 512, wvo[j], wdst);
+    } else if constexpr (k < OPS) {
+      constexpr int j = k - NI - WL;      // 0: scales, 1: zeros
+      const size_t grow = (size_t)(k0 / 128 + 2 * c + (s >> 1)) * p.N;      // 128-k group of (chunk c, phase s)
+      const uint32_t gdst = __builtin_amdgcn_readfirstlane(lds_base + wring + (uint32_t)b * WSLOT + WL * 1024 + j * 256);
+      lds_dma_piece<false, true>((j ? p.s2z : p.s2s) + grow, gvo, gdst);
+    }
+  };
+  auto issue = [&](int c, int b) {      // all of them (prologue)
+    issue_piece(IntTag<0>{}, c, b); issue_piece(IntTag<1>{}, c, b); issue_piece(IntTag<2>{}, c, b); issue_piece(IntTag<3>{}, c, b);
+    issue_piece(IntTag<4>{}, c, b); issue_piece(IntTag<5>{}, c, b); issue_piece(IntTag<6>{}, c, b); issue_piece(IntTag<7>{}, c, b);
+    static_assert(OPS <= 8, "pieces are enumerated");
   };
   // B operand of row block 0 at this wave's k-step (per lane); row block mb adds an immediate
-  const uint32_t boff = (uint32_t)(lane & 15) * 256 + ((uint32_t)(((lane >> 4) ^ (lane & 15)) << 4) ^ (uint32_t)(s << 6));
+  const uint32_t boff = (uint32_t)(lane & 15) * 256 + ((uint32_t)(((lane >> 4) ^ ((lane & 3) << 2)) << 4) ^ (uint32_t)(s << 6));
 
   v4i acc[MB][4];
 #pragma unroll
@@ -144,17 +261,12 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) acc[mb][ab] = (v4i){0, 0, 0, 0};
 
-  // ---- prologue ------------------------------------------------------------------------------------------
-  dma_chunk(0);
+  // ---- prologue: the first D chunks are requested; epilogue operands -> LDS (published by the first chunk's barrier) ----
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int cr = r < nchunks ? r : nchunks - 1;       // (short slices) re-read the last chunk, never consumed
-#pragma unroll
-    for (int j = 0; j < WL; ++j) wq[r][j] = load_w(cr, j);
-    if constexpr (MODE == MODE_GRP) { gs[r] = load_gp(p.s2s, cr); gz[r] = load_gp(p.s2z, cr); }
-    else { gs[r] = 0; gz[r] = 0; }
-  }
-  if constexpr (!TO_SLAB) {   // epilogue operands -> LDS (published by the first chunk's barrier)
+  for (int d = 0; d < D; ++d)
+    if (d < nchunks) issue(d, d);
+  MIDM_STAMP(1);
+  if constexpr (!TO_SLAB) {
     if (tid < 64 * NG) {
       const int n = blockIdx.x * 64 * NG + tid;
       const uint32_t sw = __builtin_bit_cast(uint16_t, p.wscales[n]);
@@ -170,117 +282,149 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
       epi_a[i] = sa | (as << 16);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // chunk 0's pieces (and the head of the ring) have landed
 
-  // unpack (+ lane transposition / per-group dequant) of one k-step into the four MFMA A operands
-  auto unpack = [&](const uint4 (&w)[WL], uint32_t sc4, uint32_t zr4, v4i (&wa)[4]) {
-    if constexpr (MODE == MODE_W8) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) wa[rb] = (v4i){(int)w[rb].x, (int)w[rb].y, (int)w[rb].z, (int)w[rb].w};
+  // ---- one chunk: this wave's k-step of it, out of buffer / slot B (static).  STEADY: chunk c + D exists ----------------
+  auto body = [&](int c, auto buf_tag, auto steady_tag) {
+    constexpr int B = decltype(buf_tag)::value;
+    constexpr bool STEADY = decltype(steady_tag)::value;
+    // my pieces of chunk c have landed: behind them the requests of the chunks c + 1 .. min(c + D - 1, last)
+    if (c < 24) MIDM_STAMP(4 + 4 * c);
+    if constexpr (STEADY) {
+      vm_wait<(D - 1) * OPS>();
     } else {
+      const int after = nchunks - 1 - c < D - 1 ? nchunks - 1 - c : D - 1;
+      if (after <= 0) vm_wait<0>();
+      else if (after == 1) vm_wait<1 * OPS>();
+      else vm_wait<(D > 2 ? 2 : 1) * OPS>();
+      static_assert(D <= 3, "tail waits are enumerated");
+    }
+    if (c < 24) MIDM_STAMP(5 + 4 * c);
+    __syncthreads();          // chunk c is visible in buffer B; everybody is done reading buffer (B + D) % NBUF (chunk c - 1)
+    if (c < 24) MIDM_STAMP(6 + 4 * c);
+    const bool more = STEADY || c + D < nchunks;      // chunk c + D is requested during this chunk
+    const uint8_t* abuf = smem + B * ABUF;
+    const uint8_t* wsl = smem + wring + B * WSLOT + wrd;
+    // The chunk runs as STAGES fenced against each other (sched_barrier): a few MFMAs, the LDS reads the stage after next
+    // needs, and ONE request of chunk c + D.  Issued in a burst behind the barrier, the 48 requests of a workgroup queue up in
+    // the CU's address unit (16 clocks each) while every wave waits to get its next one accepted and the matrix pipe idles:
+    // chunks took 2450 cycles against 1024 of MFMA per SIMD (tools/midm_timeline.py, profiles/r05_a).  The first PRE row
+    // blocks go operand by operand (ab outer), so that the MFMAs of operand ab cover the unpack of operand ab + 1.
+    constexpr int PRE = MB < 3 ? MB : 3;
+    constexpr int NSTAGE = 4 + (MB - PRE);                    // 4 operand stages + one per further row block
+    v4i wa[4];
+    v4i bf[MB];
+    uint32_t d[2][4];
+    uint32_t sc4 = 0, zr4 = 0;
+    uint4 wraw[MODE == MODE_W8 ? 4 : 2];
+#pragma unroll
+    for (int j = 0; j < (MODE == MODE_W8 ? 4 : 2); ++j) wraw[j] = *reinterpret_cast<const uint4*>(wsl + j * (MODE == MODE_W8 ? 1024 : 512));
+    if constexpr (MODE == MODE_GRP) {
+      sc4 = *reinterpret_cast<const uint32_t*>(smem + wring + B * WSLOT + WL * 1024 + lane * 4);
+      zr4 = *reinterpret_cast<const uint32_t*>(smem + wring + B * WSLOT + WL * 1024 + 256 + lane * 4);
+    }
+#pragma unroll
+    for (int mb = 0; mb < PRE; ++mb) bf[mb] = *reinterpret_cast<const v4i*>(abuf + boff + mb * 16 * 256);
+    if constexpr (MODE != MODE_W8) {
       // dwords of a 16-B piece: x = (k5 = 0, n2 = 0) y = (0, 1) z = (1, 0) w = (1, 1); d[n2][(tile parity, k5)]
-      const uint4 t0 = w[0], t1 = w[1];
-      uint32_t d[2][4] = {{t0.x, t0.z, t1.x, t1.z}, {t0.y, t0.w, t1.y, t1.w}};
-      // (explicit copies out of the ring registers: the swaps below work in place, and with the ring slot itself as their
-      //  operand the allocator carries the slot across the loop's back edge with two components exchanged -- the refill is
-      //  then loaded elsewhere and copied in behind a vmcnt(0).  Eight moves per 32 MFMAs.)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) asm volatile("v_mov_b32 %0, %1" : "=v"(d[b][q]) : "v"(d[b][q]));
+      const uint32_t dd[2][4] = {{wraw[0].x, wraw[0].z, wraw[1].x, wraw[1].z}, {wraw[0].y, wraw[0].w, wraw[1].y, wraw[1].w}};
       // register index (tile parity, k5) <-> 16-lane row k6: afterwards d[b][q] = k6 = q of (parity, k5) = lane >> 4,
       // i.e. 16 consecutive k per lane -- what a DMA-written activation row offers (w4a8_gemm_exact_kernel)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const auto s02 = __builtin_amdgcn_permlane32_swap(d[b][0], d[b][2], false, false);
-        const auto s13 = __builtin_amdgcn_permlane32_swap(d[b][1], d[b][3], false, false);
+        const auto s02 = __builtin_amdgcn_permlane32_swap(dd[b][0], dd[b][2], false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(dd[b][1], dd[b][3], false, false);
         const auto s01 = __builtin_amdgcn_permlane16_swap((uint32_t)s02[0], (uint32_t)s13[0], false, false);
         const auto s23 = __builtin_amdgcn_permlane16_swap((uint32_t)s02[1], (uint32_t)s13[1], false, false);
         d[b][0] = (uint32_t)s01[0]; d[b][1] = (uint32_t)s01[1]; d[b][2] = (uint32_t)s23[0]; d[b][3] = (uint32_t)s23[1];
       }
+    }
+    auto operand = [&](auto ab_tag) {      // MFMA A operand ab = a * 2 + b of this k-step
+      constexpr int ab = decltype(ab_tag)::value;
+      if constexpr (MODE == MODE_W8) {
+        wa[ab] = (v4i){(int)wraw[ab].x, (int)wraw[ab].y, (int)wraw[ab].z, (int)wraw[ab].w};
+      } else {
+        constexpr int a = ab >> 1, b = ab & 1;
+        uint32_t u[4];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+        for (int q = 0; q < 4; ++q) u[q] = (d[b][q] >> (4 * a)) & 0x0F0F0F0Fu;
+        if constexpr (MODE == MODE_GRP) {
+          const uint32_t sc = (sc4 >> (8 * ab)) & 0xFFu;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          uint32_t u[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) u[q] = (d[b][q] >> (4 * a)) & 0x0F0F0F0Fu;
-          if constexpr (MODE == MODE_GRP) {
-            const uint32_t sc = (sc4 >> (8 * (a * 2 + b))) & 0xFFu;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) u[q] = u[q] * sc;
-            vadd4_zbyte_x4(u, zr4, a * 2 + b);
-          }
-          wa[a * 2 + b] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
+          for (int q = 0; q < 4; ++q) u[q] = u[q] * sc;
+          vadd4_zbyte_x4(u, zr4, ab);
         }
-    }
-  };
-
-  // ---- one chunk: this wave's k-step of it.  RS = ring slot (static); STEADY = a next chunk exists and the refill is
-  // issued unconditionally (clamped to the slice): no control flow, every compiler wait is a counted vmcnt ---------
-  constexpr int VM_AFTER_DMA = WL + GP;       // loads issued behind a chunk's DMA before the next chunk's top (steady)
-  auto body = [&](int c, auto slot_tag, auto steady_tag) {
-    constexpr int RS = decltype(slot_tag)::value;
-    constexpr bool STEADY = decltype(steady_tag)::value;
-    // my pieces of chunk c have landed (steady: behind them only the previous body's refill; tail: nothing)
-    if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_AFTER_DMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();          // chunk c is visible in buffer c & 1; everybody is done reading buffer (c + 1) & 1
-    const uint8_t* abuf = smem + (c & 1) * (MT * CH);
-    v4i wa[4];
-    unpack(wq[RS], gs[RS], gz[RS], wa);
-    // the next tile's DMA goes out BEHIND the unpack: hipcc's counted waits for the ring slot do not see DMA operations, so
-    // a vmcnt(N) behind fresh pieces also waits for N-relative pieces (w4a8_gemm_exact_kernel: same finding)
-    if (STEADY || c + 1 < nchunks) dma_chunk(c + 1);
-    if constexpr (STEADY) {
-      const int cn = c + R < nchunks ? c + R : nchunks - 1;
-      // (fence in front as well: with a refill scheduled among the unpack's reads of the slot it replaces, the slot gets a
-      //  second register tuple and the loaded value is COPIED into the loop-carried one -- a vmcnt(0) right behind the load)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < WL; ++j) wq[RS][j] = load_w(cn, j);
-      if constexpr (MODE == MODE_GRP) { gs[RS] = load_gp(p.s2s, cn); gz[RS] = load_gp(p.s2z, cn); }
-      // the refill stays HERE, R chunks of MFMAs ahead of its use (left alone it sinks to the end of the body, and the
-      // next body's unpack rises above the loop's back edge: register copies of in-flight loads, vmcnt(0) per round)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    v4i bf[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) bf[mb] = *reinterpret_cast<const v4i*>(abuf + boff + mb * 16 * 256);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int ab = 0; ab < 4; ++ab)
-        acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf[mb], acc[mb][ab], 0, 0, 0);
-#if OMNI_MIDM_PIPE
-    {   // B reads PRE row blocks ahead of the MFMAs that use them (left alone: read, read, wait, 8 MFMAs, ...)
-      constexpr int PRE = MB < 3 ? MB : 3;
-      __builtin_amdgcn_sched_group_barrier(0x100, PRE, 0);
-#pragma unroll
-      for (int i = 0; i < MB - PRE; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        wa[ab] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * PRE, 0);
-    }
+    };
+    // request k goes out in stage k * NSTAGE / OPS (spread evenly; several per stage where there are more requests than stages)
+    auto stage_requests = [&](auto st_tag) {
+      constexpr int st = decltype(st_tag)::value;
+      if (more) {
+        if constexpr (0 * NSTAGE / OPS == st && 0 < OPS) issue_piece(IntTag<0>{}, c + D, (B + D) % NBUF);
+        if constexpr (1 * NSTAGE / OPS == st && 1 < OPS) issue_piece(IntTag<1>{}, c + D, (B + D) % NBUF);
+        if constexpr (2 * NSTAGE / OPS == st && 2 < OPS) issue_piece(IntTag<2>{}, c + D, (B + D) % NBUF);
+        if constexpr (3 * NSTAGE / OPS == st && 3 < OPS) issue_piece(IntTag<3>{}, c + D, (B + D) % NBUF);
+        if constexpr (4 * NSTAGE / OPS == st && 4 < OPS) issue_piece(IntTag<4>{}, c + D, (B + D) % NBUF);
+        if constexpr (5 * NSTAGE / OPS == st && 5 < OPS) issue_piece(IntTag<5>{}, c + D, (B + D) % NBUF);
+        if constexpr (6 * NSTAGE / OPS == st && 6 < OPS) issue_piece(IntTag<6>{}, c + D, (B + D) % NBUF);
+        if constexpr (7 * NSTAGE / OPS == st && 7 < OPS) issue_piece(IntTag<7>{}, c + D, (B + D) % NBUF);
+      }
+    };
+    auto operand_stage = [&](auto ab_tag) {
+      constexpr int ab = decltype(ab_tag)::value;
+      operand(ab_tag);
+#pragma unroll
+      for (int mb = 0; mb < PRE; ++mb) acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf[mb], acc[mb][ab], 0, 0, 0);
+      // B operands of the row-block stages: two stages ahead of their MFMAs
+      if constexpr (ab >= 2 && PRE + ab - 2 < MB)
+        bf[PRE + ab - 2] = *reinterpret_cast<const v4i*>(abuf + boff + (PRE + ab - 2) * 16 * 256);
+      stage_requests(ab_tag);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    operand_stage(IntTag<0>{});
+    operand_stage(IntTag<1>{});
+    operand_stage(IntTag<2>{});
+    operand_stage(IntTag<3>{});
+    auto row_stage = [&](auto mb_tag) {
+      constexpr int mb = decltype(mb_tag)::value;
+      if constexpr (mb < MB) {
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf[mb], acc[mb][ab], 0, 0, 0);
+        if constexpr (mb + 2 < MB) bf[mb + 2] = *reinterpret_cast<const v4i*>(abuf + boff + (mb + 2) * 16 * 256);
+        stage_requests(IntTag<4 + mb - PRE>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    row_stage(IntTag<PRE>{});
+    row_stage(IntTag<PRE + 1>{});
+    row_stage(IntTag<PRE + 2>{});
+    row_stage(IntTag<PRE + 3>{});
+    row_stage(IntTag<PRE + 4>{});
+    static_assert(MB - PRE <= 5, "row-block stages are enumerated");
+#ifdef OMNI_DEBUG_CLOCKS
+    __builtin_amdgcn_sched_barrier(0);
+    if (c < 24) MIDM_STAMP(7 + 4 * c);
 #endif
   };
   {
     int c = 0;
-    for (; c + R < nchunks; c += R) {      // whole ring rounds with a chunk behind them
+    for (; c + (NBUF - 1) + D < nchunks; c += NBUF) {      // whole ring rounds whose every chunk has a chunk c + D behind it
       body(c, IntTag<0>{}, BoolTag<true>{});
-      if constexpr (R > 1) body(c + 1, IntTag<1 % R>{}, BoolTag<true>{});
-      if constexpr (R > 2) body(c + 2, IntTag<2 % R>{}, BoolTag<true>{});
-      if constexpr (R > 3) body(c + 3, IntTag<3 % R>{}, BoolTag<true>{});
-      static_assert(R <= 4, "ring rounds are unrolled by hand");
+      body(c + 1, IntTag<1 % NBUF>{}, BoolTag<true>{});
+      if constexpr (NBUF > 2) body(c + 2, IntTag<2 % NBUF>{}, BoolTag<true>{});
+      if constexpr (NBUF > 3) body(c + 3, IntTag<3 % NBUF>{}, BoolTag<true>{});
+      static_assert(NBUF >= 2 && NBUF <= 4, "ring rounds are unrolled by hand");
     }
-    const int rem = nchunks - c;            // 1 .. R chunks left: nothing to refill
-    body(c, IntTag<0>{}, BoolTag<false>{});
-    if (R > 1 && rem > 1) body(c + 1, IntTag<1 % R>{}, BoolTag<false>{});
-    if (R > 2 && rem > 2) body(c + 2, IntTag<2 % R>{}, BoolTag<false>{});
-    if (R > 3 && rem > 3) body(c + 3, IntTag<3 % R>{}, BoolTag<false>{});
+    for (; c < nchunks; c += NBUF) {                        // the last chunks: conditions on workgroup-uniform values
+      body(c, IntTag<0>{}, BoolTag<false>{});
+      if (c + 1 < nchunks) body(c + 1, IntTag<1 % NBUF>{}, BoolTag<false>{});
+      if (NBUF > 2 && c + 2 < nchunks) body(c + 2, IntTag<2 % NBUF>{}, BoolTag<false>{});
+      if (NBUF > 3 && c + 3 < nchunks) body(c + 3, IntTag<3 % NBUF>{}, BoolTag<false>{});
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
+  MIDM_STAMP(100);
 
   // ---- the four K phases of a group meet in LDS (static accumulator indices only) ------------------------------
   // round 1: phases {0,1} keep the low half of the row blocks and park the high half, phases {2,3} the other way round;
@@ -350,6 +494,7 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
     else take2(IntTag<HB + QB>{});
   }
 
+  MIDM_STAMP(101);
   // ---- write back: row blocks s * QB .. + QB - 1 of group g -----------------------------------------------------
   // D layout (16x16): col = lane & 15 -> row m of the block, row = (lane >> 4) * 4 + r -> channel slot i.
   // W4: channel = ng * 64 + (i >> 3) * 32 + ab * 8 + (i & 7) (4 consecutive channels per lane); W8: ng * 64 + ab * 16 + i.
@@ -395,6 +540,7 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
   else if (s == 1) finish(IntTag<QB>{});
   else if (s == 2) finish(IntTag<HB>{});
   else finish(IntTag<HB + QB>{});
+  MIDM_STAMP(102);
 }
 
 }  // namespace omni

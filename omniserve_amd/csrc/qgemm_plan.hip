@@ -39,23 +39,34 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
   pl.mz = 1;
   pl.narrow = 0;
   pl.midm = 0;
-  // Mid-M kernel (qgemm_midm.h): M = 33 .. 128 rows (one row tile), N in whole 128-channel tiles, K slices of whole
-  // 256-k chunks.  K is split over the grid only while the 128-channel tiles leave CUs idle: the smallest split with
-  // >= 192 workgroups that keeps >= 4 chunks per slice (the int32 slabs cost M x N x 4 bytes per slice, written and read).
+  // Mid-M kernel (qgemm_midm.h): M = 33 .. 128 rows (one row tile), N in whole 128-channel tiles, K slices of whole 256-k
+  // chunks.  A launch of it carries ~7 us that do not depend on K (first requests, the K-phase exchange, stores) and streams
+  // at about twice the single-wave tiles' rate beyond them, so it takes the BIG matrices (measured, tools/midm_sweep.py,
+  // profiles/r05_a: Llama-3-8B gate_up at M = 128 35.4 -> 23.1 us, Llama-2-70B gate_up 138 -> 71, down 106 -> 41 -- and
+  // Llama-3-8B qkv 11.7 -> 19.6, which stays where it was): N x K >= 80 M weights, or >= 50 M where the caller wants the
+  // slabs anyway (the deferred forms at 65 .. 128 rows: no slab epilogue launch to pay for).  Per-group weights at <= 64 rows
+  // tie on Llama-3-8B's gate_up (21.4 vs 20.7 .. 22.5 us) and keep their plan below 200 M.
+  // K split: one workgroup per CU and launch (its LDS rings fill the CU) -- the largest split that keeps the grid inside one
+  // round of 256 and >= 4 chunks per slice (Llama-2-70B qkv, 80 tiles: 2 slices 28.5 us, 4 slices 34.7).
   if (g_midm_mode != 0 && g_override_waves == 0 && g_override_sk == 0 && M > 32 && M <= 128 && N % 128 == 0 && K % KCHUNK == 0) {
-    const int tiles = N / 128;
-    int best = 1;
-    if (tiles < 160) {
-      for (int s2 = 2; s2 <= 16; ++s2) {
-        if (K % (s2 * KCHUNK) != 0 || (K / s2) % kalign != 0 || K / s2 < 4 * KCHUNK) continue;
-        best = s2;
-        if (tiles * s2 >= 192) break;
-      }
+    const long long weights = (long long)N * K;
+    bool take = g_midm_mode > 0;
+    if (g_midm_mode < 0) {
+      if (M <= 64) take = weights >= (kalign == 128 ? 200000000LL : 80000000LL);
+      else take = weights >= 80000000LL || (deferred && weights >= 50000000LL);
     }
-    if (g_midm_sk > 0 && K % (g_midm_sk * KCHUNK) == 0) best = g_midm_sk;
-    pl.midm = 1; pl.mb = M <= 64 ? 4 : 8; pl.mz = 1; pl.waves = 2; pl.kw = 1;
-    pl.sk = best; pl.kslice = K / best;
-    return pl;
+    if (take) {
+      const int tiles = N / 128;
+      int best = 1;
+      for (int s2 = 2; s2 <= 16; ++s2) {
+        if (K % (s2 * KCHUNK) != 0 || (K / s2) % kalign != 0 || K / s2 < 4 * KCHUNK || tiles * s2 > 256) continue;
+        best = s2;
+      }
+      if (g_midm_sk > 0 && K % (g_midm_sk * KCHUNK) == 0) best = g_midm_sk;
+      pl.midm = 1; pl.mb = M <= 64 ? 4 : 8; pl.mz = 1; pl.waves = 2; pl.kw = 1;
+      pl.sk = best; pl.kslice = K / best;
+      return pl;
+    }
   }
   if (M > 128) {  // MFMA-bound regime: 128 x 256 tile per workgroup
     pl.mb = 8; pl.waves = 4; pl.sk = 1; pl.kslice = K;

@@ -269,3 +269,88 @@ def test_gemm_linearity_full_size():
     torch.cuda.synchronize()
     assert torch.equal(outs[0] + outs[1], outs[2])
     assert outs[2].abs().max() < 2048
+
+
+# ---- mid-M kernel (csrc/qgemm_midm.h): forced on through omni_gemm_set_midm_override so that every row-tile height, ragged M,
+# short slices (fewer chunks than ring slots), forced K splits and all three flavours meet the oracle -- the planner itself
+# only sends it the big matrices (test_midm_planner_takes_the_big_matrices) ----
+class _ForcedMidm:
+    def __init__(self, sk=0):
+        self.sk = sk
+
+    def __enter__(self):
+        from omniserve_amd import _lib
+        from omniserve_amd.backend import _gemm_common
+        _lib.lib().omni_gemm_set_midm_override(1, self.sk)
+        _gemm_common._ws_bytes.clear()
+
+    def __exit__(self, *exc):
+        from omniserve_amd import _lib
+        from omniserve_amd.backend import _gemm_common
+        _lib.lib().omni_gemm_set_midm_override(-1, 0)
+        _gemm_common._ws_bytes.clear()
+
+
+MIDM_SMALL = [(33, 128, 256, 0), (64, 256, 512, 0), (65, 128, 1024, 0), (100, 384, 2048, 2), (128, 256, 4096, 4), (48, 128, 768, 0),
+              (127, 256, 1280, 0), (64, 128, 2048, 8), (128, 128, 256, 0), (96, 640, 1536, 2)]
+
+
+@pytest.mark.parametrize("M,N,K,sk", MIDM_SMALL)
+def test_midm_forced_per_chn(M, N, K, sk):
+    with _ForcedMidm(sk):
+        _run_chn(M, N, K, seed=M + K)
+        _run_chn(M, N, K, seed=M + K + 1, out_view=True)
+
+
+@pytest.mark.parametrize("wrap", [False, True])
+@pytest.mark.parametrize("M,N,K,sk", MIDM_SMALL)
+def test_midm_forced_per_group(M, N, K, sk, wrap):
+    with _ForcedMidm(sk):
+        _run_grp(M, N, K, wrap)
+
+
+@pytest.mark.parametrize("M,N,K,sk", MIDM_SMALL)
+def test_midm_forced_w8a8(M, N, K, sk):
+    with _ForcedMidm(sk):
+        _run_w8(M, N, K)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 28672, 4096), (64, 28672, 4096), (128, 4096, 14336), (100, 7168, 8192), (128, 8192, 3584)])
+def test_midm_forced_model_shapes(M, N, K):
+    with _ForcedMidm():
+        _run_chn(M, N, K, seed=N)
+        _run_grp(M, N, K, wrap=True)
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(128, 4096, 14336, 0), (64, 512, 2048, 2), (100, 256, 1024, 1), (128, 8192, 8192, 4)])
+def test_midm_forced_partial_slabs(M, N, K, sk):
+    """The slab-only forms (o_proj / down_proj of the decode drivers at fusion level 2): the slabs sum to the exact accumulator."""
+    from omniserve_amd.backend import fused_ext
+    u, z, s1 = w4a8.synth_per_channel(N, K, M)
+    qw, _, _ = w4a8.pack_per_channel(u, z, s1)
+    a, _, _ = _acts(M, K, M + 1)
+    slab = torch.zeros((16, M, N), dtype=torch.int32, device=dev())
+    with _ForcedMidm(sk):
+        got = fused_ext.gemm_partial_per_chn(to_dev(a), to_dev(qw), slab)
+        torch.cuda.synchronize()
+    assert got >= 1 and (sk == 0 or got == sk) and not slab[got:].any()
+    assert np.array_equal(slab[:got].sum(dim=0).cpu().numpy(), w4a8.gemm_per_chn_acc(a, qw))
+
+
+def test_midm_planner_takes_the_big_matrices():
+    """Unforced: Llama-3-8B gate_up at 64 / 128 rows and the Llama-2-70B projections go to the mid-M kernel (plan: 8 waves per
+    workgroup reported as 2 channel groups), Llama-3-8B qkv / o and the TP = 8 shards stay on the single-wave tiles."""
+    import ctypes
+    from omniserve_amd import _lib
+    lib = _lib.lib()
+
+    def waves(M, N, K):
+        w = ctypes.c_int(0)
+        lib.omni_gemm_get_plan(M, N, K, 64, None, ctypes.byref(w), None)
+        return w.value
+    for M, N, K in [(128, 28672, 4096), (64, 28672, 4096), (128, 57344, 8192), (128, 8192, 28672), (65, 10240, 8192)]:
+        assert waves(M, N, K) == 2, (M, N, K)
+    for M, N, K in [(128, 6144, 4096), (128, 4096, 4096), (128, 1280, 8192), (16, 28672, 4096), (32, 28672, 4096), (128, 8192, 1024)]:
+        assert waves(M, N, K) == 1, (M, N, K)
+    _run_chn(128, 28672, 4096, seed=5)
+    _run_chn(64, 28672, 4096, seed=6)

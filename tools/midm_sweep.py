@@ -14,7 +14,7 @@ from omniserve_amd.backend import _gemm_common, fused_ext, qgemm_w4a8_per_chn, q
 
 dev = torch.device("cuda:0")
 lib = _lib.lib()
-quick = "--quick" in sys.argv
+quick = "--quick" in sys.argv or "--big" in sys.argv
 SHAPES = {
     "8b": [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)],
     "70b_tp8": [(1280, 8192), (8192, 1024), (7168, 8192), (8192, 3584)],
@@ -80,10 +80,11 @@ def run(model, M, N, K, mode):
     t_part = timed(partial, copies)
     print("%-8s %-3s M=%3d N=%5d K=%5d legacy      : full %7.2f us  slab-only %7.2f us (sk %d)   [stream %5.2f us, mfma %5.2f us]"
           % (model, mode, M, N, K, t_full, t_part, sk0, alg / HBM / 1e3, ops / INT8 / 1e6), flush=True)
-    for sk in ([0] if quick else [0, 1, 2, 4, 8]):
+    variants = [(1, 0)] if quick else [(1, 0), (1, 1), (1, 2), (1, 4), (1, 8)]
+    for mode_bits, sk in variants:
         if sk and (K % (sk * 256) or K // sk < 512):
             continue
-        lib.omni_gemm_set_midm_override(1, sk)
+        lib.omni_gemm_set_midm_override(mode_bits, sk)
         _gemm_common._ws_bytes.clear()
         _lib.workspace(16 * M * N * 4, dev, "gemm")
         out.zero_()
@@ -94,14 +95,24 @@ def run(model, M, N, K, mode):
         ok2 = torch.equal(slab[: skm * M * N].view(skm, M, N).sum(dim=0), ref_acc)
         t_full = timed(full, copies)
         t_part = timed(partial, copies)
-        print("%-8s %-3s M=%3d N=%5d K=%5d midm sk=%-4s: full %7.2f us  slab-only %7.2f us (sk %d)   %5.2f TB/s %6.0f TOPS  %s"
-              % (model, mode, M, N, K, sk if sk else "auto", t_full, t_part, skm, alg / t_full / 1e6, ops / t_full / 1e6,
+        print("%-8s %-3s M=%3d N=%5d K=%5d midm m%d sk=%-4s: full %7.2f us  slab-only %7.2f us (sk %d)   %5.2f TB/s %6.0f TOPS  %s"
+              % (model, mode, M, N, K, mode_bits, sk if sk else "auto", t_full, t_part, skm, alg / t_full / 1e6, ops / t_full / 1e6,
                  "bit-equal" if ok and ok2 else "MISMATCH full=%s slab=%s" % (ok, ok2)), flush=True)
     lib.omni_gemm_set_midm_override(-1, 0)
     del ws
 
 
 if __name__ == "__main__":
+    if "--big" in sys.argv:      # the shapes the mid-M kernel is for (one line per plan: legacy, mid-M at its own K split)
+        quick = True
+        for model, N, K in (("8b", 28672, 4096), ("8b", 4096, 14336), ("70b_tp8", 7168, 8192), ("70b_tp1", 57344, 8192),
+                            ("70b_tp1", 8192, 28672), ("70b_tp1", 10240, 8192)):
+            for M in (128, 64):
+                run(model, M, N, K, "chn")
+        run("8b", 64, 28672, 4096, "grp")
+        run("8b", 64, 4096, 14336, "grp")
+        run("8b", 128, 28672, 4096, "w8")
+        sys.exit(0)
     for model, shapes in SHAPES.items():
         for (N, K) in shapes:
             for M in (128, 64):
