@@ -254,6 +254,32 @@ def roofline_gate_up(runner, ms_per_step=None):
     return out
 
 
+def mid_m_leg(device):
+    """The decode GEMM between the GEMV and the prefill regime: Llama-3-8B gate_up [28672, 4096] per-channel at
+    M = 64 / 128 (w4a8_midm_kernel, csrc/qgemm_midm.h) and 256 (the 128 x 256 prefill tile), weights rotated over 6 copies
+    (352 MB > the 256 MB memory-side cache), HIP events on the launch stream; fractions of BOTH ceilings."""
+    from omniserve_amd.backend import qgemm_w4a8_per_chn
+    N, K = 28672, 4096
+    g = torch.Generator(device=device); g.manual_seed(0)
+    ws = [torch.randint(0, 256, (N, K // 2), dtype=torch.uint8, device=device, generator=g).view(torch.int8) for _ in range(6)]
+    sw = torch.full((N,), 0.01, dtype=torch.float16, device=device)
+    sz = torch.full((N,), 0.05, dtype=torch.float16, device=device)
+    out = {}
+    for M in (64, 128, 256):
+        a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=device, generator=g)
+        sa = torch.full((M,), 0.01, dtype=torch.float16, device=device)
+        asum = torch.zeros((M,), dtype=torch.float16, device=device)
+        o = torch.empty((M, N), dtype=torch.float16, device=device)
+        ms = event_time_ms(lambda i: qgemm_w4a8_per_chn.gemm_forward_cuda(a, ws[i % 6], sw, sa, sz, asum, o), iters=36, warm=6)
+        nbytes = M * K + N * K // 2 + 2 * M * N + 4 * N + 4 * M
+        ops = 2.0 * M * N * K
+        out["gate_up_M%d" % M] = {"us": round(ms * 1e3, 2), "bytes": nbytes,
+                                  "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "int8_tops": round(ops / (ms * 1e-3) / 1e12, 1),
+                                  "frac_of_int8_mfma_peak": round(ops / (ms * 1e-3) / 1e12 / INT8_PEAK_TOPS, 4)}
+    return out
+
+
 def gemm_4096(device):
     from omniserve_amd.backend import qgemm_w4a8_per_chn
     M = N = K = 4096
@@ -761,6 +787,7 @@ def main():
         result["config"]["l2_prefetch_mib_per_row_kernel"] = prefetch_mb
         if world == 1:
             leg("w4a8_gemm_4096", lambda: gemm_4096(device))
+            leg("mid_m", lambda: mid_m_leg(device))
             del runner
             torch.cuda.empty_cache()
             leg("protocol", lambda: protocol_leg(cfg, args, device))
