@@ -13,10 +13,10 @@
 //     s of every 256-k chunk for group g and all rows.  A weight byte is fetched once, by one wave; the unpack runs once per
 //     byte (48 VALU per 32 MFMAs at 128 rows -- the 32-row tiles spend 40 per 8);
 //   * EVERYTHING the K loop reads arrives by LDS-DMA (global_load_lds, issued from inline asm, completion owned by explicit
-//     vmcnt waits): the activation chunk (rows x 256 B, once per workgroup, NBUF buffers, one barrier per chunk; image
-//     and lane transposition of the packed registers as in w4a8_gemm_exact_kernel: LDS row m keeps piece q at slot q ^
-//     (m & 15)), the wave's own 2 KiB of packed weights per chunk (a private NBUF-slot ring, read back with two
-//     ds_read_b128 as the MFMA A operand source) and the per-group parameters.  Why not registers for the weights: the CU's
+//     vmcnt waits): the activation chunk (rows x 256 B, once per workgroup, NBUF buffers, one barrier per chunk; lane
+//     transposition of the packed registers as in w4a8_gemm_exact_kernel, so that a DMA-written row is the B operand), the
+//     wave's own 2 KiB of packed weights per chunk (a private NBUF-slot ring, read back with two ds_read_b128 as the MFMA A
+//     operand source) and the per-group parameters.  Every request is quad-coalesced (see "request addressing").  Why not registers for the weights: the CU's
 //     vector memory path returns in order, so an L2-hit activation piece queued behind an HBM-miss weight load lands with
 //     HBM latency; every chunk needs its activation tile, so with the tile requested one chunk ahead (the first version:
 //     weights in a register ring, counted compiler waits) a chunk took one loaded HBM latency -- 1.56 us against 0.49 us of
@@ -32,8 +32,8 @@
 
 namespace omni {
 
-#ifndef OMNI_MIDM_PIPE
-#define OMNI_MIDM_PIPE 1          // B-operand reads pinned PRE row blocks ahead of their MFMAs (sched_group_barrier)
+#ifndef OMNI_MIDM_PRIO
+#define OMNI_MIDM_PRIO 0          // 1: alternate the favoured wave of each SIMD stage by stage (see the K loop; measured neutral)
 #endif
 
 // LDS-DMA statements of one wave.  A piece = one wave instruction: lane l's 16 B (dwordx4) or 4 B (dword) land at
@@ -109,19 +109,18 @@ __device__ __forceinline__ void lds_dma_gp(const void* sb_scales, const void* sb
       OMNI_DMA_TAIL
       : "=&s"(keep) : "s"(sb_scales), "s"(sb_zeros), "v"(v0), "s"(lds_dst) : "memory", "scc");
 }
-// one piece (16 B per lane, or 4 B per lane with DW) as its own statement: the K loop spreads a chunk's pieces over its MFMAs
+// one piece (16 B per lane, or 4 B per lane with DW) as its own statement: the K loop spreads a chunk's pieces over its MFMAs.
+// Three instructions: M0 is declared clobbered instead of saved and restored (nothing else in these kernels uses it), and the
+// scalar base / destination come out of SALU arithmetic (no VALU-written SGPR in front of the VMEM instruction: no wait states
+// beyond the one between the M0 write and its use).
 template <bool NT, bool DW>
 __device__ __forceinline__ void lds_dma_piece(const void* sbase, uint32_t v0, uint32_t lds_dst) {
-  uint32_t keep;
   if constexpr (DW)
-    asm volatile(OMNI_DMA_HEAD "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %2, %1\n\t" OMNI_DMA_TAIL
-                 : "=&s"(keep) : "s"(sbase), "v"(v0), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(v0), "s"(lds_dst) : "memory", "m0");
   else if constexpr (NT)
-    asm volatile(OMNI_DMA_HEAD "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 nt\n\t" OMNI_DMA_TAIL
-                 : "=&s"(keep) : "s"(sbase), "v"(v0), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0 nt" ::"s"(sbase), "v"(v0), "s"(lds_dst) : "memory", "m0");
   else
-    asm volatile(OMNI_DMA_HEAD "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t" OMNI_DMA_TAIL
-                 : "=&s"(keep) : "s"(sbase), "v"(v0), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(v0), "s"(lds_dst) : "memory", "m0");
 }
 template <int N>
 __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -133,6 +132,7 @@ template <int V> struct IntTag { static constexpr int value = V; };
 //   [0] entry, [1] prologue requests issued, then per chunk c < 24: [4 + 4c] before the DMA wait, [+1] behind it, [+2] behind the
 //   barrier, [+3] behind the chunk's last MFMA issue; [100] K loop done, [101] partials exchanged, [102] stores issued
 static __device__ unsigned long long omni_dbg_midm[2 * 8 * 104];
+
 #define MIDM_STAMP(i)                                                                                              \
   do {                                                                                                             \
     if (dbg_on && lane == 0) dbg_t[(i)] = __builtin_readcyclecounter();                                            \
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
       dvo[i] = (uint32_t)row * (uint32_t)p.K + (uint32_t)((ds ^ ((rl & 3) << 2)) << 4);
     }
   }
-  const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)smem;
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)smem);
   const uint32_t wring = __builtin_amdgcn_readfirstlane((uint32_t)(LDS_A + wave * NBUF * WSLOT));   // this wave's ring, from smem
   // all requests of chunk c into buffer / slot b
   // request number k (static) of chunk c into buffer / slot b: activation pieces first, then weights, then parameters
@@ -233,17 +233,17 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
     constexpr int k = decltype(k_tag)::value;
     if constexpr (k < NI) {
       const uint8_t* sa = reinterpret_cast<const uint8_t*>(p.A) + (size_t)k0 + (size_t)c * CH;
-      const uint32_t adst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)b * ABUF + (uint32_t)wave * (MT / NW) * 256 + k * 1024);
+      const uint32_t adst = lds_base + (uint32_t)b * ABUF + (uint32_t)wave * (MT / NW) * 256 + k * 1024;
       lds_dma_piece<false, false>(sa, dvo[k], adst);
     } else if constexpr (k < NI + WL) {
       constexpr int j = k - NI;
-      const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds_base + wring + (uint32_t)b * WSLOT + j * 1024);
+      const uint32_t wdst = lds_base + wring + (uint32_t)b * WSLOT + j * 1024;
       if constexpr (MODE == MODE_W8) lds_dma_piece<NT, false>(p.W + (size_t)c * CH, wvo[j], wdst);
       else lds_dma_piece<NT, false>(p.W + (size_t)c * (CH / 32) * 512, wvo[j], wdst);
     } else if constexpr (k < OPS) {
       constexpr int j = k - NI - WL;      // 0: scales, 1: zeros
       const size_t grow = (size_t)(k0 / 128 + 2 * c + (s >> 1)) * p.N;      // 128-k group of (chunk c, phase s)
-      const uint32_t gdst = __builtin_amdgcn_readfirstlane(lds_base + wring + (uint32_t)b * WSLOT + WL * 1024 + j * 256);
+      const uint32_t gdst = lds_base + wring + (uint32_t)b * WSLOT + WL * 1024 + j * 256;
       lds_dma_piece<false, true>((j ? p.s2z : p.s2s) + grow, gvo, gdst);
     }
   };
@@ -283,6 +283,25 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
     }
   }
 
+  // Software pipeline across the barrier: the MFMAs of a chunk's last DEF row blocks run at the HEAD of the next chunk, behind
+  // its barrier and its first LDS reads -- there the weight reads, the lane transposition and the first masks are in flight
+  // and no MFMA of the new chunk can issue yet (both waves of the SIMD: the matrix pipe idled ~300 cycles per chunk).  Their
+  // operands stay in registers: the A operands `wa` are rewritten only by the operand stages behind them, `bfl` keeps the B
+  // operands.  Zero operands in front of the first chunk: those MFMAs add nothing.
+  constexpr int DEF = MB == 8 ? 2 : 1;
+  v4i wa[4], bfl[DEF];
+#pragma unroll
+  for (int ab = 0; ab < 4; ++ab) wa[ab] = (v4i){0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < DEF; ++j) bfl[j] = (v4i){0, 0, 0, 0};
+  auto deferred_rows = [&]() {
+#pragma unroll
+    for (int j = 0; j < DEF; ++j)
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab)
+        acc[MB - DEF + j][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bfl[j], acc[MB - DEF + j][ab], 0, 0, 0);
+  };
+
   // ---- one chunk: this wave's k-step of it, out of buffer / slot B (static).  STEADY: chunk c + D exists ----------------
   auto body = [&](int c, auto buf_tag, auto steady_tag) {
     constexpr int B = decltype(buf_tag)::value;
@@ -310,8 +329,33 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
     // chunks took 2450 cycles against 1024 of MFMA per SIMD (tools/midm_timeline.py, profiles/r05_a).  The first PRE row
     // blocks go operand by operand (ab outer), so that the MFMAs of operand ab cover the unpack of operand ab + 1.
     constexpr int PRE = MB < 3 ? MB : 3;
-    constexpr int NSTAGE = 4 + (MB - PRE);                    // 4 operand stages + one per further row block
-    v4i wa[4];
+    constexpr int NSTAGE = 1 + 4 + (MB - PRE - DEF);          // the deferred rows, 4 operand stages, one per further row block
+    // The two waves of a SIMD (group 0, phase s: the older one; group 1, phase s) share its matrix pipe, and at equal priority
+    // the older wave wins every arbitration: it ran its chunk in ~1050 cycles and then sat at the barrier for ~900 while the
+    // younger one finished alone, an in-order wave whose non-MFMA instructions nobody covers (tools/midm_timeline.py).  With
+    // the favoured wave alternating stage by stage (OMNI_MIDM_PRIO=1) both waves take ~1550 cycles and nobody waits -- and
+    // the chunk takes the same 2050 cycles (profiles/r05_a: same-box A/B of 15 shapes, +-3 % either way): off.
+    auto stage_prio = [&](auto st_tag) {
+#if OMNI_MIDM_PRIO
+      constexpr int st = decltype(st_tag)::value;
+      if (g == (st & 1)) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    // request k goes out in stage k * NSTAGE / OPS (spread evenly; several per stage where there are more requests than stages)
+    auto stage_requests = [&](auto st_tag) {
+      constexpr int st = decltype(st_tag)::value;
+      if (more) {
+        if constexpr (0 * NSTAGE / OPS == st && 0 < OPS) issue_piece(IntTag<0>{}, c + D, (B + D) % NBUF);
+        if constexpr (1 * NSTAGE / OPS == st && 1 < OPS) issue_piece(IntTag<1>{}, c + D, (B + D) % NBUF);
+        if constexpr (2 * NSTAGE / OPS == st && 2 < OPS) issue_piece(IntTag<2>{}, c + D, (B + D) % NBUF);
+        if constexpr (3 * NSTAGE / OPS == st && 3 < OPS) issue_piece(IntTag<3>{}, c + D, (B + D) % NBUF);
+        if constexpr (4 * NSTAGE / OPS == st && 4 < OPS) issue_piece(IntTag<4>{}, c + D, (B + D) % NBUF);
+        if constexpr (5 * NSTAGE / OPS == st && 5 < OPS) issue_piece(IntTag<5>{}, c + D, (B + D) % NBUF);
+        if constexpr (6 * NSTAGE / OPS == st && 6 < OPS) issue_piece(IntTag<6>{}, c + D, (B + D) % NBUF);
+        if constexpr (7 * NSTAGE / OPS == st && 7 < OPS) issue_piece(IntTag<7>{}, c + D, (B + D) % NBUF);
+      }
+    };
     v4i bf[MB];
     uint32_t d[2][4];
     uint32_t sc4 = 0, zr4 = 0;
@@ -324,6 +368,9 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
     }
 #pragma unroll
     for (int mb = 0; mb < PRE; ++mb) bf[mb] = *reinterpret_cast<const v4i*>(abuf + boff + mb * 16 * 256);
+    stage_prio(IntTag<0>{});
+    deferred_rows();          // (chunk c - 1's last row blocks: stage 0)
+    stage_requests(IntTag<0>{});
     if constexpr (MODE != MODE_W8) {
       // dwords of a 16-B piece: x = (k5 = 0, n2 = 0) y = (0, 1) z = (1, 0) w = (1, 1); d[n2][(tile parity, k5)]
       const uint32_t dd[2][4] = {{wraw[0].x, wraw[0].z, wraw[1].x, wraw[1].z}, {wraw[0].y, wraw[0].w, wraw[1].y, wraw[1].w}};
@@ -356,29 +403,16 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
         wa[ab] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
       }
     };
-    // request k goes out in stage k * NSTAGE / OPS (spread evenly; several per stage where there are more requests than stages)
-    auto stage_requests = [&](auto st_tag) {
-      constexpr int st = decltype(st_tag)::value;
-      if (more) {
-        if constexpr (0 * NSTAGE / OPS == st && 0 < OPS) issue_piece(IntTag<0>{}, c + D, (B + D) % NBUF);
-        if constexpr (1 * NSTAGE / OPS == st && 1 < OPS) issue_piece(IntTag<1>{}, c + D, (B + D) % NBUF);
-        if constexpr (2 * NSTAGE / OPS == st && 2 < OPS) issue_piece(IntTag<2>{}, c + D, (B + D) % NBUF);
-        if constexpr (3 * NSTAGE / OPS == st && 3 < OPS) issue_piece(IntTag<3>{}, c + D, (B + D) % NBUF);
-        if constexpr (4 * NSTAGE / OPS == st && 4 < OPS) issue_piece(IntTag<4>{}, c + D, (B + D) % NBUF);
-        if constexpr (5 * NSTAGE / OPS == st && 5 < OPS) issue_piece(IntTag<5>{}, c + D, (B + D) % NBUF);
-        if constexpr (6 * NSTAGE / OPS == st && 6 < OPS) issue_piece(IntTag<6>{}, c + D, (B + D) % NBUF);
-        if constexpr (7 * NSTAGE / OPS == st && 7 < OPS) issue_piece(IntTag<7>{}, c + D, (B + D) % NBUF);
-      }
-    };
     auto operand_stage = [&](auto ab_tag) {
       constexpr int ab = decltype(ab_tag)::value;
+      stage_prio(IntTag<1 + ab>{});
       operand(ab_tag);
 #pragma unroll
       for (int mb = 0; mb < PRE; ++mb) acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf[mb], acc[mb][ab], 0, 0, 0);
       // B operands of the row-block stages: two stages ahead of their MFMAs
       if constexpr (ab >= 2 && PRE + ab - 2 < MB)
         bf[PRE + ab - 2] = *reinterpret_cast<const v4i*>(abuf + boff + (PRE + ab - 2) * 16 * 256);
-      stage_requests(ab_tag);
+      stage_requests(IntTag<1 + ab>{});
       __builtin_amdgcn_sched_barrier(0);
     };
     __builtin_amdgcn_sched_barrier(0);
@@ -388,11 +422,12 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
     operand_stage(IntTag<3>{});
     auto row_stage = [&](auto mb_tag) {
       constexpr int mb = decltype(mb_tag)::value;
-      if constexpr (mb < MB) {
+      if constexpr (mb < MB - DEF) {
+        stage_prio(IntTag<5 + mb - PRE>{});
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab) acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf[mb], acc[mb][ab], 0, 0, 0);
         if constexpr (mb + 2 < MB) bf[mb + 2] = *reinterpret_cast<const v4i*>(abuf + boff + (mb + 2) * 16 * 256);
-        stage_requests(IntTag<4 + mb - PRE>{});
+        stage_requests(IntTag<5 + mb - PRE>{});
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -402,6 +437,8 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
     row_stage(IntTag<PRE + 3>{});
     row_stage(IntTag<PRE + 4>{});
     static_assert(MB - PRE <= 5, "row-block stages are enumerated");
+#pragma unroll
+    for (int j = 0; j < DEF; ++j) bfl[j] = bf[MB - DEF + j];      // (read two stages ahead like every other row block)
 #ifdef OMNI_DEBUG_CLOCKS
     __builtin_amdgcn_sched_barrier(0);
     if (c < 24) MIDM_STAMP(7 + 4 * c);
@@ -423,6 +460,7 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
       if (NBUF > 3 && c + 3 < nchunks) body(c + 3, IntTag<3 % NBUF>{}, BoolTag<false>{});
     }
   }
+  deferred_rows();            // the last chunk's
   __builtin_amdgcn_sched_barrier(0);
   MIDM_STAMP(100);
 

@@ -10,6 +10,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omniserve_amd import _lib  # noqa: E402
+
+if os.environ.get("OMNI_TUNE_LIB"):     # A/B against a library variant (tools/build_variant.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["OMNI_TUNE_LIB"])
 from omniserve_amd.backend import _gemm_common, fused_ext, qgemm_w4a8_per_chn, qgemm_w4a8_per_group, qgemm_w8a8  # noqa: E402
 
 dev = torch.device("cuda:0")

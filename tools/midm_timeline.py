@@ -46,3 +46,4 @@ for wg in range(2):
     print("K loop done", " ".join("%6d" % (x - t0) for x in t[:, 100]))
     print("exchanged  ", " ".join("%6d" % (x - t0) for x in t[:, 101]))
     print("stored     ", " ".join("%6d" % (x - t0) for x in t[:, 102]))
+
