@@ -682,13 +682,25 @@ def main():
         return dry_run(args, cfg, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback: the HIP path is the product)")
+    # OMNI_BENCH_ONE_GPU=1 (tests/test_tp_gpu.py): every rank on cuda:0 -- the N-rank launch path on the one GPU a test box has.
+    # RCCL refuses two ranks on one device, so the process group is gloo there and the step's collective the library's own
+    # peer-mapped one; the RCCL-in-graph path itself needs N GPUs and is unmeasured on hardware.
+    one_gpu = world > 1 and os.environ.get("OMNI_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
+        if args.tp_mode:
+            args.tp_comm = "peer"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    red_dev = torch.device("cpu") if one_gpu else device       # where the line's own scalar reductions live
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from omniserve_amd.runtime import DecodeRunner
     tp = args.tp_mode
@@ -709,7 +721,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
         elapsed = float(t.item())
@@ -718,25 +730,32 @@ def main():
         raise SystemExit("non-finite activations in the decode step")
 
     ar = None
+    if dist is not None:
+        # did every rank take part?  A sum all-reduce of ones on the job's process group (RCCL unless OMNI_BENCH_ONE_GPU)
+        ones = torch.ones((1,), dtype=torch.float32, device=red_dev)
+        dist.all_reduce(ones)
+        ar = {"ranks_in_all_reduce": int(ones.item()), "process_group_backend": dist.get_backend(),
+              "graph_capture_fell_back_to_eager": runner.graph_error if runner.graph_error else False}
     if tp:
-        # the collective of the TP path on its own: in-place fp16 sum all-reduce of one [B, hidden] projection
-        # (2 MiB at bs = 128 x 8192), event-timed on the launch stream, max over ranks
-        buf = torch.zeros((args.batch, cfg.hidden), dtype=torch.float16, device=device)
-        for _ in range(5):
-            dist.all_reduce(buf)
-        torch.cuda.synchronize()
+        ar.update({"payload_bytes": args.batch * cfg.hidden * 2, "calls_per_step": 2 * cfg.layers, "step_collective": args.tp_comm})
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            dist.all_reduce(buf)
-        e1.record()
-        torch.cuda.synchronize()
-        t = torch.tensor([e0.elapsed_time(e1) / 50 * 1e3], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        us = float(t.item())
+        buf = torch.zeros((args.batch, cfg.hidden), dtype=torch.float16, device=device)
         nbytes = buf.numel() * 2
-        ar = {"all_reduce_us": round(us, 2), "payload_bytes": nbytes, "calls_per_step": 2 * cfg.layers,
-              "bus_GBps": round(2.0 * (world - 1) / world * nbytes / us / 1e3, 1), "step_collective": args.tp_comm}
+        if not one_gpu:
+            # the collective of the TP path on its own: in-place fp16 sum all-reduce of one [B, hidden] projection
+            # (2 MiB at bs = 128 x 8192), event-timed on the launch stream, max over ranks
+            for _ in range(5):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(50):
+                dist.all_reduce(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / 50 * 1e3], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            us = float(t.item())
+            ar.update({"all_reduce_us": round(us, 2), "bus_GBps": round(2.0 * (world - 1) / world * nbytes / us / 1e3, 1)})
         if runner.comm is not None:
             # the library's own collective on the same payload (an even number of calls keeps the slot parity of the step)
             for _ in range(6):
@@ -747,7 +766,7 @@ def main():
                 runner.comm.all_reduce(buf)
             e1.record()
             torch.cuda.synchronize()
-            t = torch.tensor([e0.elapsed_time(e1) / 50 * 1e3], dtype=torch.float64, device=device)
+            t = torch.tensor([e0.elapsed_time(e1) / 50 * 1e3], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ar["peer_all_reduce_us"] = round(float(t.item()), 2)
             runner.comm.check_error()
@@ -770,9 +789,9 @@ def main():
                    "kv_bytes_per_step": runner.kv_bytes_per_step(args.context)},
     }
     if ar is not None:
-        result["tensor_parallel"] = ar
-        if runner.graph_error:
-            result["tensor_parallel"]["graph_capture_fell_back_to_eager"] = runner.graph_error
+        result["tensor_parallel" if tp else "distributed"] = ar
+        if one_gpu:
+            result["config"]["all_ranks_on_one_gpu"] = True      # launch-path test mode: not a scaling measurement
 
     def leg(name, fn):
         """An extra leg must never cost the headline line: a failure is reported in place of its object."""

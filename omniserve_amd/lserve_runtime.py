@@ -61,28 +61,29 @@ class LServeDecodeRunner:
 
     def __init__(self, cfg: LlamaConfig, batch: int, context: int, max_new: int, device, seed=0, kv_format="kv8",
                  streaming_ratio=0.5, sink=128, local=256, budget_tokens=4096, selector_interval=4,
-                 sub_chunk_per_block=4, use_graph=True, fused=True, prefetch_mb=None, ctx_sink=128, ctx_local=8192):
+                 sub_chunk_per_block=4, use_graph=True, fused=True, prefetch_mb=None, ctx_sink=128, ctx_local=8192,
+                 prefetch_blocks=160, arm_o=False, defer=True, qkv_slabs=True, rowfree=True):
         """fused: use the opt-in fused entry points (residual add + norm + quant, silu*mul + quant) -- bit-identical to the
         reference call sequence, three launches fewer per layer.  fused=True (or 3) also takes the
         row-kernel-free forms where they apply (batch <= 16: the attention merge leaves fp16 + row maxima, gate_up runs
         with the SiLU*mul epilogue, o_proj / down_proj quantise on the fly -- runtime.py's fusion level 3 for the W8A8
-        layers); fused=2 keeps the quantiser row kernels."""
+        layers); fused=2 keeps the quantiser row kernels.  prefetch_mb / prefetch_blocks / arm_o / defer / qkv_slabs / rowfree: the
+        A/B switches of the step (this module reads no environment)."""
         c = cfg
         self.cfg, self.B, self.device = cfg, batch, device
         self.fused = bool(fused)
         level = 3 if fused is True else int(fused)
         # L2 weight prefetch riding on the row kernels (see omniserve_amd/runtime.py; a hint, results unaffected)
-        import os
         prefetch_default = prefetch_mb is None
         if prefetch_mb is None:
             # round 2 (quantiser row kernels as carriers): 4-5 % SLOWER at batch 1 with W8A8 weights, so it was off; with the
             # row-kernel-free layer (norms and the wide merge as the carriers) 24-64 MiB measure 1.5-2 % FASTER per step
             # (3.11-3.13 -> 3.05-3.07 ms, tools/r03_call60/61.sh); 8-16 MiB are neutral
-            prefetch_mb = float(os.environ.get("OMNI_LSERVE_PREFETCH_MB", "32")) if self.fused else 0.0
+            prefetch_mb = 32.0 if self.fused else 0.0
         self.prefetch_bytes = int(float(prefetch_mb) * (1 << 20)) if self.fused else 0
-        self.prefetch_blocks = int(os.environ.get("OMNI_PREFETCH_BLOCKS", "160"))
+        self.prefetch_blocks = int(prefetch_blocks)
         # (the wide merge as a carrier for o_proj's 16.8 MB costs it 2.8 us where o_proj gains 1.1: 3.07 -> 3.05 ms without)
-        self.arm_o = os.environ.get("OMNI_LSERVE_ARM_O", "0") != "0"
+        self.arm_o = bool(arm_o)
         if kv_format not in ("kv8", "kv4"):
             raise ValueError("kv_format must be 'kv8' (per_tensor) or 'kv4' (fine_grained)")
         self.kv8 = kv_format == "kv8"
@@ -174,17 +175,17 @@ class LServeDecodeRunner:
         self.act_sum = torch.empty((B,), dtype=f16, device=device)    # by-product of the fused entry points, unused
         self.act_scale2 = torch.empty((B,), dtype=f16, device=device)  # scales written by the quant-type kernels
         # fused: o_proj / down_proj leave int32 split-K slabs; the next add+norm kernel applies the GEMM epilogue
-        self.defer = self.fused and os.environ.get("OMNI_LSERVE_DEFER", "1") != "0"
+        self.defer = self.fused and bool(defer)
         self.slab = torch.empty((16 << 20,), dtype=torch.uint8, device=device) if self.defer else None
         # the qkv projection as slabs consumed by the attention kernel (fused_ext.decode_arm_qkv_slabs) on the steps
         # without a selector refresh: no slab epilogue launch behind the (96, 2)-workgroup qkv GEMV
-        self.qkv_slabs = self.defer and os.environ.get("OMNI_QKV_SLABS", "1") != "0"
+        self.qkv_slabs = self.defer and bool(qkv_slabs)
         # row-kernel-free decode layer (fused level 3): needs the deferred epilogue (slab consumers) and <= 16 rows
         # (and plans its entry points accept: omni_gemm_rowfree_ok, W8A8 form)
         self.rowfree = (self.defer and level >= 3 and B <= 16 and Hq % 4 == 0 and
-                        os.environ.get("OMNI_LSERVE_ROWFREE", "1") != "0" and
+                        bool(rowfree) and
                         _lib.lib().omni_gemm_rowfree_ok(B, c.hidden, Hq * d, c.inter, 2) == 1)
-        if prefetch_default and not self.rowfree and "OMNI_LSERVE_PREFETCH_MB" not in os.environ:
+        if prefetch_default and not self.rowfree:
             self.prefetch_bytes = 0     # (with the quantiser row kernels as carriers the prefetch measured slower)
         if self.rowfree:
             self.attn_f16 = torch.empty((B, Hq * d), dtype=f16, device=device)

@@ -120,19 +120,22 @@ class DecodeRunner:
 
     def __init__(self, cfg: LlamaConfig, batch: int, context: int, max_new: int, device, seed=0,
                  use_graph=True, fused=True, tp_rank=0, tp_size=1, tp_group=None, shard_full=False,
-                 prefetch_mb=None, prefetch_blocks=160, weight_policy=None, tp_comm=None):
+                 prefetch_mb=None, prefetch_blocks=160, weight_policy=1, tp_comm=None, max_fused=4, tp_l2_attn=True,
+                 l3_prefetch_down=1, qkv_slabs="auto", attn_single=True, arm_qkv=True, arm_o=True, l3_last=True):
         """tp_size > 1: Megatron-style tensor parallelism (omniserve_amd/tp.py): qkv / gate_up column-parallel,
         o / down row-parallel, attention by kv head, one fp16 sum all-reduce of the [B, hidden] projection after
         o_proj and after down_proj.  shard_full=True builds the full layers from the seed and keeps this
         rank's shards (tests: every rank then holds shards of the SAME model); otherwise only the local shapes
-        are drawn (bench: synthetic weights, no point in materialising 70B parameters per rank)."""
-        import os
+        are drawn (bench: synthetic weights, no point in materialising 70B parameters per rank).
+        The A/B switches of the decode step are constructor arguments (this module reads no environment): max_fused caps the
+        fusion level the runner may pick; tp_l2_attn / qkv_slabs ("auto", True, False) / attn_single / arm_qkv / arm_o /
+        l3_prefetch_down (0, 1, 2) / l3_last select the forms described where they are used below."""
         self.cfg, self.B, self.device = cfg, batch, device
         self.tp_rank, self.tp_size, self.tp_group = int(tp_rank), int(tp_size), tp_group
         # tp_comm = "peer": the decode step's collectives run on the library's own peer-mapped all-reduce (tp.PeerComm: one
         # launch per collective, folded into the add + norm kernel where one follows) instead of torch.distributed / RCCL
         self.comm = None
-        tp_comm = tp_comm if tp_comm is not None else os.environ.get("OMNI_TP_COMM", "")
+        tp_comm = tp_comm or ""
         if self.tp_size > 1 and tp_comm in ("peer", "loopback"):      # "loopback": one process, all peers = this rank (timing only)
             from . import tp
             self.comm = tp.PeerComm(self.tp_rank, self.tp_size, batch * cfg.hidden, device, tp_group,
@@ -158,7 +161,7 @@ class DecodeRunner:
         self.fused = 3 if fused is True else int(fused)
         # the attention-side fusions of level 2 (split merge inside the quantiser, q / k / v from the qkv projection's slabs)
         # involve no row-parallel projection, so they also apply under tensor parallelism, where the level drops to 1
-        self.l2_attn = self.fused >= 2 and batch <= 128 and os.environ.get("OMNI_TP_L2_ATTN", "1") != "0"
+        self.l2_attn = self.fused >= 2 and batch <= 128 and bool(tp_l2_attn)
         if (self.tp_size > 1 or batch > 512) and self.fused > 1:
             # tensor parallel: the all-reduce needs the fp16 projection; batch > 512: the prefill tile's slab-only form
             # (omni_*_gemm_partial) stops there -- no deferred epilogue in either case.  (batch 129 .. 512: o_proj / down_proj
@@ -168,10 +171,10 @@ class DecodeRunner:
         # without a grid-level K split, i.e. hidden <= 4096; one rider workgroup per row in a grid row of hidden / 64; the
         # rider's LDS copy of a row) and the wide attention merge's 4 heads per wave; otherwise level 2, which has no such
         # limits (a hidden = 5120 layer used to pass the old size test here and fail in its first step)
-        if self.fused >= 4 and not (cfg.group_size == -1 and self.tp_size == 1 and int(os.environ.get("OMNI_FUSED_MAX", "4")) >= 4 and
+        if self.fused >= 4 and not (cfg.group_size == -1 and self.tp_size == 1 and int(max_fused) >= 4 and
                                     fused_ext.mlp_fused_ok(batch, cfg.hidden, self.il)):
             self.fused = 3
-        if self.fused >= 3 and not (self.hl % 4 == 0 and int(os.environ.get("OMNI_FUSED_MAX", "4")) >= 3 and
+        if self.fused >= 3 and not (self.hl % 4 == 0 and int(max_fused) >= 3 and
                                     _lib.lib().omni_gemm_rowfree_ok(batch, cfg.hidden, self.hl * cfg.head_dim, self.il,
                                                                     0 if cfg.group_size == -1 else 1) == 1):
             self.fused = 2
@@ -179,21 +182,19 @@ class DecodeRunner:
         # next GEMV's weights each row kernel pulls into the L2s (0 = off), with how many extra workgroups, and
         # whether the GEMV on a prefetched tensor then uses plain instead of non-temporal weight loads (per call: the arm
         # names the tensor, omni_prefetch_arm_gemm; un-armed projections always stream non-temporally).  Defaults: on with the fused
-        # entry points (environment overrides for sweeps: OMNI_PREFETCH_MB, OMNI_PREFETCH_BLOCKS, OMNI_WEIGHT_POLICY).
+        # entry points (prefetch_mb / prefetch_blocks / weight_policy arguments for sweeps).
         if prefetch_mb is None:
             # measured (profiles/r02_*): +6-7 % at bs = 16 with 28-40 MiB per row kernel (the L2s hold 32 MiB; the
             # excess lands in MALL), nothing at bs = 128, -4 % at bs = 64 where the row kernels are no longer idle
             # (batch 33..64: 12 MiB per carrier measured best at configs[2] -- 3.50 -> 3.43 ms per step, 24 MiB and more lose.
             #  A tensor-parallel shard's projections are small enough to be fetched whole: one Llama-2-70B TP = 8 rank at
             #  bs = 128 7.22-7.26 -> 6.59-6.65 ms per step with 12 .. 48 MiB.  Other batches > 64: not measured, off)
-            dflt = "40" if batch <= 32 else ("12" if batch <= 64 else ("24" if self.tp_size > 1 else "0"))
-            prefetch_mb = float(os.environ.get("OMNI_PREFETCH_MB", dflt)) if self.fused else 0.0
+            dflt = 40.0 if batch <= 32 else (12.0 if batch <= 64 else (24.0 if self.tp_size > 1 else 0.0))
+            prefetch_mb = dflt if self.fused else 0.0
         self.prefetch_bytes = int(float(prefetch_mb) * (1 << 20)) if self.fused else 0
         # (fetching workgroups per carrier: 240 was round 2's optimum; with down_proj's 29.6 MB on the norm in front of gate_up
         #  128-192 measure 1.7 % faster per step at bs = 16 -- 2.28 -> 2.24 ms --, 64-96 slower; bs = 64 / TP / LServe: flat)
-        self.prefetch_blocks = int(os.environ.get("OMNI_PREFETCH_BLOCKS", prefetch_blocks))
-        if weight_policy is None:
-            weight_policy = int(os.environ.get("OMNI_WEIGHT_POLICY", "1"))
+        self.prefetch_blocks = int(prefetch_blocks)
         self.weight_policy = int(weight_policy) if self.prefetch_bytes > 0 else 0
         c = cfg
         gen = torch.Generator(device=device)
@@ -286,33 +287,31 @@ class DecodeRunner:
         # level 3: the norm in front of gate_up prefetches ALL of DOWN's weights (29.6 MB fit the 32 MB of L2s) instead of
         # the head of gate_up's 58.7 MB; gate_up then streams cold with non-temporal loads (they do not displace the
         # prefetched lines) and down reads L2: 2.322-2.334 -> 2.294-2.314 ms per step on the same box (profiles/r03_g;
-        # OMNI_L3_PF_DOWN=0: round 3's first arrangement, 2: gate_up with plain loads -- slower, 2.35)
-        self.pf_down = int(os.environ.get("OMNI_L3_PF_DOWN", "1"))
+        # l3_prefetch_down=0: round 3's first arrangement, 2: gate_up with plain loads -- slower, 2.35)
+        self.pf_down = int(l3_prefetch_down)
         # fused level >= 2: the qkv projection leaves int32 split-K slabs and the decode attention applies its epilogue in
         # its first load trip (fused_ext.decode_arm_qkv_slabs): no slab epilogue launch between the two.  "auto": on exactly
         # where the plain qkv GEMV's plan splits K (bs = 64: (96, 2) workgroups + a 4.9-us epilogue launch per layer; 3.51 ->
-        # 3.47 ms per step); at bs = 16 the plan has no split and the slab form measured 1.5 % slower.  OMNI_QKV_SLABS=0 / 1
+        # 3.47 ms per step); at bs = 16 the plan has no split and the slab form measured 1.5 % slower.  qkv_slabs=False / True
         # forces it off / on (A/B)
-        qs = os.environ.get("OMNI_QKV_SLABS", "auto")
-        if qs == "auto":      # on exactly where the plain qkv GEMV would split K and launch a slab epilogue
+        if qkv_slabs == "auto":      # on exactly where the plain qkv GEMV would split K and launch a slab epilogue
             import ctypes
             sk_q = ctypes.c_int(1)
             _lib.lib().omni_gemm_get_plan(batch, qkv_n, c.hidden, 128 if c.group_size == 128 else 64, None, None,
                                           ctypes.byref(sk_q))
             want = sk_q.value > 1
         else:
-            want = qs != "0"
+            want = bool(qkv_slabs)
         self.qkv_slabs = (self.fused >= 2 or self.l2_attn) and want
         # (A/B knobs: qkv's / o_proj's weights prefetched by the norm in front of qkv / the kernel behind the attention)
-        # level 3: the attention's split merge inside the attention launch (last-arriving workgroup; OMNI_ATTN_SINGLE=0: the
+        # level 3: the attention's split merge inside the attention launch (last-arriving workgroup; attn_single=False: the
         # two-launch form, A/B)
-        self.attn_single = os.environ.get("OMNI_ATTN_SINGLE", "1") != "0"
-        self.arm_qkv = os.environ.get("OMNI_ARM_QKV", "1") != "0"
-        self.arm_o = os.environ.get("OMNI_ARM_O", "1") != "0"
+        self.attn_single = bool(attn_single)
+        self.arm_qkv = bool(arm_qkv)
+        self.arm_o = bool(arm_o)
         # level 3 also in the LAST layer: its down projection's slabs are consumed by the model's final norm
-        # (fused_ext.splitk_add_rms_norm) instead of GEMV epilogue + residual add + rms_norm (OMNI_L3_LAST=0: off, A/B)
-        self.last_l3 = (self.fused >= 3 and self.tp_size == 1 and self.comm is None and
-                        os.environ.get("OMNI_L3_LAST", "1") != "0")
+        # (fused_ext.splitk_add_rms_norm) instead of GEMV epilogue + residual add + rms_norm (l3_last=False: off, A/B)
+        self.last_l3 = self.fused >= 3 and self.tp_size == 1 and self.comm is None and bool(l3_last)
         self.normed = torch.empty((B, c.hidden), dtype=f16, device=device)
         self.lengths = torch.full((B,), context, dtype=torch.int32, device=device)
         self.tokens = torch.randint(0, c.vocab, (B,), device=device, generator=gen)

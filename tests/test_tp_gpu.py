@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _run_rank(rank, world, port, group_size, steps, ret, tp_comm=None, graph=False, fused=1):
+def _run_rank(rank, world, port, group_size, steps, ret, tp_comm=None, graph=False, fused=1, qkv_slabs="auto"):
     import torch.distributed as dist
     from omniserve_amd.runtime import DecodeRunner, LlamaConfig
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,7 +33,7 @@ def _run_rank(rank, world, port, group_size, steps, ret, tp_comm=None, graph=Fal
         cfg = LlamaConfig.tiny()
         cfg.group_size = group_size
         r = DecodeRunner(cfg, BATCH, 0, steps + 2, torch.device("cuda:0"), seed=5, use_graph=graph, fused=fused,
-                         tp_rank=rank, tp_size=world, shard_full=True, tp_comm=tp_comm)
+                         tp_rank=rank, tp_size=world, shard_full=True, tp_comm=tp_comm, qkv_slabs=qkv_slabs)
         assert r.fused <= 1 or world == 1     # the level of the row-parallel projections drops to 1 under TP
         for _ in range(steps):
             r.step()
@@ -323,8 +323,8 @@ def _run_rank_peer(rank, world, port, group_size, steps, graph, ret):
 
 
 def _run_rank_l2_attn(rank, world, port, group_size, steps, graph, ret):
-    os.environ["OMNI_QKV_SLABS"] = "1"       # (batch 4: "auto" would leave the slab form of the qkv projection off)
-    _run_rank(rank, world, port, group_size, steps, ret, tp_comm="peer", graph=graph, fused=True)
+    # (batch 4: qkv_slabs="auto" would leave the slab form of the qkv projection off)
+    _run_rank(rank, world, port, group_size, steps, ret, tp_comm="peer", graph=graph, fused=True, qkv_slabs=True)
 
 
 @pytest.mark.parametrize("group_size,graph", [(-1, False), (128, True)])
@@ -339,3 +339,27 @@ def test_tp2_attention_side_fusions_match_level_1_bitwise(group_size, graph):
         xr, tr = ref[(2, rk)]
         xg, tg = got[(2, rk)]
         assert np.array_equal(xr, xg) and np.array_equal(tr, tg), "rank %d: attention-side fusions differ" % rk
+
+
+def test_bench_spawns_two_ranks_on_the_one_gpu():
+    """`python bench.py --gpus 2` end to end on hardware: it re-executes itself under torch.distributed.run, both ranks build their
+    TP = 2 shard of Llama-3-8B on cuda:0 (OMNI_BENCH_ONE_GPU=1: gloo process group, the library's peer collective inside the
+    graph-captured step -- RCCL refuses two ranks on one device), and rank 0 prints the line with the rank count of an
+    all-reduce of ones.  (The RCCL-in-graph path needs N GPUs: unmeasured on hardware, see DESIGN.md.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMNI_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--model", "llama3-8b",
+                        "--no-extras"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0 and line["scaling"] == "strong"
+    tp = line["tensor_parallel"]
+    assert tp["ranks_in_all_reduce"] == 2 and tp["step_collective"] == "peer" and tp["process_group_backend"] == "gloo"
+    assert tp["graph_capture_fell_back_to_eager"] is False, tp
+    assert line["config"]["all_ranks_on_one_gpu"] is True and "tp2" in line["config"]["parallelism"]

@@ -1,6 +1,5 @@
 #!/bin/bash
-# One parametrised runner for a gpurun call (replaces the per-call scripts of rounds 1-3, kept under tools/archive/ because
-# profiles/*.md cite them by name).  Usage, from the repo root on the GPU box:
+# One parametrised runner for a gpurun call (replaces the per-call scripts of rounds 1-3).  Usage, from the repo root on the GPU box:
 #     tools/gpu_call.sh TAG RECIPE [RECIPE ...]
 # Recipes (recipe number i writes gpurun_out/TAG/<i>_<recipe>.log and prints its tail):
 #     suite            python -m pytest tests -m gpu -x -q
