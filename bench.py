@@ -652,7 +652,7 @@ def main():
     ap.add_argument("--group-size", type=int, default=-1)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="reference call sequence (no fused extension kernels)")
-    ap.add_argument("--fused-level", type=int, default=3, help="0 reference sequence, 1 fused add+norm / silu+quant, 2 + deferred split-K epilogue, 3 + no quantiser row kernels (SiLU in the gate_up epilogue, o / down quantise on the fly), 4 + the MLP half of a layer as one persistent launch (opt-in: measured slower, profiles/r04_a_*)")
+    ap.add_argument("--fused-level", type=int, default=3, help="0 reference sequence, 1 fused add+norm / silu+quant, 2 + deferred split-K epilogue, 3 + no quantiser row kernels (SiLU in the gate_up epilogue, o / down quantise on the fly))")
     ap.add_argument("--no-lserve", action="store_true", help="skip the configs[3] (LServe, 256K context) leg")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / gemm_4096 legs")
     ap.add_argument("--tp-comm", choices=["rccl", "peer"], default="rccl",

@@ -511,33 +511,6 @@ int omni_kv4_decode_attention_f16_amax(void* out_f16, void* amax_slots_u32, cons
                                        int rope_max_pos, void* workspace, size_t workspace_bytes, void* tickets_u32,
                                        size_t tickets_words, void* stream);
 
-/* ---- fused extension (nothing upstream): the MLP half of the per-channel W4A8 decode layer as
- * ONE persistent launch (csrc/mlp_fused.hip) -- llama_w4a8_unpad.py:425-436 at decode shape:
- *     residual += h(o_proj epilogue(sum of sk_o int32 split-K slabs))        [omni_splitk_add_rms_norm_general_fuse_sum]
- *     rms_norm_general_fuse_sum(gamma)  -> int8 codes, scale, sum            [same]
- *     gate_up GEMV + silu_and_mul -> fp16 activation, row maxima             [omni_w4a8_per_chn_gemm_silu]
- *     per-token quantisation + down GEMV -> int32 split-K slabs, row sums / scales  [omni_w4a8_per_chn_gemm_partial_f16]
- * with in-kernel hand-offs instead of two kernel boundaries (256 resident workgroups, weights streamed through a register
- * ring that never stops at a boundary).  Bit-identical to the three entry points named on the right.
- * counters: omni_mlp_fused_counter_words(layers) uint32 words the CALLER ZEROES ONCE PER DECODE STEP; phase: the layer's
- * index within the step (0 .. layers - 1; arrivals are compared against (phase + 1) x the per-launch count, so the launches
- * of a step need no memset between them and a captured graph replays correctly); scratch: omni_mlp_fused_scratch_bytes()
- * bytes, contents dead between launches; clocks != 0: phase marks of every workgroup land in the scratch tail.
- * *sk_out = inter / 2048 slabs in dn_slab ([sk][M][hidden] int32).  omni_mlp_fused_ok: 1 when a layer (M <= 16, hidden 4096,
- * inter % 2048 == 0, 8192 <= inter <= 16384) can run here (256 CUs).  omni_mlp_fused_error: 1 when a bounded in-kernel wait
- * gave up since the counters were zeroed (synchronises the stream).  Only enqueues otherwise. */
-size_t omni_mlp_fused_counter_words(int layers);
-size_t omni_mlp_fused_scratch_bytes(int hidden, int inter);
-int omni_mlp_fused_ok(int M, int hidden, int inter);
-int omni_mlp_fused_error(const void* counters, void* stream);
-int omni_w4a8_per_chn_mlp_fused(void* residual_f16, const void* o_slab_i32, int sk_o, const void* o_wscales,
-                                const void* o_wsz, const void* o_ascales, const void* o_asum, const void* gamma_f16,
-                                float eps, const void* gu_qweight, const void* gu_wscales, const void* gu_wsz,
-                                const void* dn_qweight, void* dn_slab_i32, size_t dn_slab_bytes, int* sk_out,
-                                void* act_sum_f16, void* act_scale_f16, void* counters, int layers, int phase,
-                                void* scratch, size_t scratch_bytes, int clocks, int M, int hidden, int inter,
-                                void* stream);
-
 /* omni_kv4_decode_attention_fine_grained replaces
  *   omniserve_backend.fused_attention_fine_grained_dense.single_query_attention
  *     (fused_attention_fine_grained/dense_attention/fused_attention.h:18-46) and, with

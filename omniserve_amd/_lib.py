@@ -55,12 +55,6 @@ PROTOTYPES = {
     "omni_w4a8_per_group_gemm_silu": (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
     "omni_w4a8_per_chn_gemm_partial_f16": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _i, _i, _c.POINTER(_i), _vp]),
     "omni_w4a8_per_group_gemm_partial_f16": (_i, [_vp] * 6 + [_sz, _vp, _vp, _i, _i, _i, _c.POINTER(_i), _vp]),
-    "omni_mlp_fused_counter_words": (_sz, [_i]),
-    "omni_mlp_fused_scratch_bytes": (_sz, [_i, _i]),
-    "omni_mlp_fused_ok": (_i, [_i, _i, _i]),
-    "omni_mlp_fused_error": (_i, [_vp, _vp]),
-    "omni_w4a8_per_chn_mlp_fused": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_i),
-                                         _vp, _vp, _vp, _i, _i, _vp, _sz, _i, _i, _i, _i, _vp]),
     "omni_kv4_decode_attention_f16_amax": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp,
                                                 _sz, _vp, _sz, _vp]),
     "omni_attn_merge_f16_amax": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp]),

@@ -244,57 +244,6 @@ def gemm_partial_f16_per_chn(act, amax, qweight, slab, sum_out, scale_out):
     return sk.value
 
 
-def mlp_fused_ok(M, hidden, inter):
-    """True when mlp_fused_per_chn takes a layer of these dimensions on the current device (M <= 16, hidden 4096,
-    inter a multiple of 2048 in [8192, 16384], 256 CUs)."""
-    return int(_lib.lib().omni_mlp_fused_ok(int(M), int(hidden), int(inter))) == 1
-
-
-def mlp_fused_buffers(layers, hidden, inter, device):
-    """(counters, scratch) for mlp_fused_per_chn: `counters` (int32 words) must be ZEROED ONCE PER DECODE STEP before the
-    first layer's launch (decode_step_begin's `zero` argument does it for free); `scratch` is dead between launches."""
-    lib = _lib.lib()
-    counters = torch.zeros((int(lib.omni_mlp_fused_counter_words(int(layers))),), dtype=torch.int32, device=device)
-    scratch = torch.empty((int(lib.omni_mlp_fused_scratch_bytes(int(hidden), int(inter))),), dtype=torch.uint8, device=device)
-    return counters, scratch
-
-
-def mlp_fused_per_chn(residual, o_slab, sk_o, o_wscales, o_wsz, o_ascales, o_asum, gamma, epsilon, gu_qweight, gu_wscales,
-                      gu_wsz, dn_qweight, dn_slab, act_sum, act_scale, counters, layers, phase, scratch, clocks=False):
-    """The MLP half of the W4A8 per-channel decode layer in ONE persistent launch (csrc/mlp_fused.hip):
-    residual += o_proj epilogue(sum of its sk_o split-K slabs) -> rms_norm_general_fuse_sum(gamma) -> gate_up GEMV +
-    silu_and_mul -> per-token quantisation -> down GEMV, leaving down_proj's int32 split-K slabs in dn_slab (returns their
-    count) and the activation's fp16 row sums / scales in act_sum / act_scale for the slab consumer -- bit-identical to
-    splitk_add_rms_norm_general_fuse_sum + gemm_silu_per_chn + gemm_partial_f16_per_chn.  `phase` = index of the layer within
-    the step (launch l of a step), `counters` zeroed once per step (mlp_fused_buffers)."""
-    import ctypes
-    _lib.require_cuda(residual, o_slab, o_wscales, o_wsz, o_ascales, o_asum, gamma, gu_qweight, gu_wscales, gu_wsz, dn_qweight,
-                      dn_slab, act_sum, act_scale, counters, scratch)
-    M, hidden = residual.shape
-    inter = gu_qweight.shape[0] // 2
-    if residual.dtype != torch.float16 or not residual.is_contiguous():
-        raise RuntimeError("mlp_fused_per_chn: residual must be a contiguous fp16 [M, hidden] tensor")
-    if gu_qweight.shape[1] * 2 != hidden or tuple(dn_qweight.shape) != (hidden, inter // 2):
-        raise RuntimeError("mlp_fused_per_chn: gate_up [2 * inter, hidden / 2] and down [hidden, inter / 2] packed weights expected")
-    sk = ctypes.c_int(0)
-    rc = _lib.lib().omni_w4a8_per_chn_mlp_fused(
-        residual.data_ptr(), o_slab.data_ptr(), int(sk_o), o_wscales.data_ptr(), o_wsz.data_ptr(), o_ascales.data_ptr(),
-        o_asum.data_ptr(), gamma.data_ptr(), float(epsilon), gu_qweight.data_ptr(), gu_wscales.data_ptr(), gu_wsz.data_ptr(),
-        dn_qweight.data_ptr(), dn_slab.data_ptr(), dn_slab.numel() * dn_slab.element_size(), ctypes.byref(sk),
-        act_sum.data_ptr(), act_scale.data_ptr(), counters.data_ptr(), int(layers), int(phase), scratch.data_ptr(),
-        scratch.numel(), int(bool(clocks)), M, hidden, inter, _lib.current_stream())
-    _lib.check(rc, "fused_ext.mlp_fused_per_chn")
-    return sk.value
-
-
-def mlp_fused_check(counters):
-    """Raises if a bounded wait inside a mlp_fused_per_chn launch gave up since `counters` was last zeroed (a workgroup was
-    not resident: the launch's results are garbage).  Synchronises the current stream."""
-    rc = _lib.lib().omni_mlp_fused_error(counters.data_ptr(), _lib.current_stream())
-    if rc != 0:
-        raise RuntimeError("mlp_fused_per_chn: an in-kernel hand-off timed out (rc %d)" % rc)
-
-
 def gemm_partial_f16_per_group(act, amax, qweight, s2_zeros, s2_scales, slab, sum_out, scale_out):
     """The g128 form of gemm_partial_f16_per_chn (sum_out may be None: the per-group layers read no row sums)."""
     import ctypes

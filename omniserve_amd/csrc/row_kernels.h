@@ -1,4 +1,4 @@
-// Row-kernel pieces shared between elementwise.hip (the stand-alone row kernels) and mlp_fused.hip (the persistent MLP
+// Row-kernel pieces shared between elementwise.hip (the stand-alone row kernels) and tools/experiments/mlp_fused.hip (the persistent MLP
 // launch, whose norm "service" workgroups run the same row code): the split-K slab source and the general-norm row body.
 // Arithmetic, reduction geometry and rounding points are documented in elementwise.hip / row_reduce.h; nothing here changes them.
 #pragma once

@@ -152,13 +152,9 @@ class DecodeRunner:
         # leaves fp16 + row maxima, and o_proj / down_proj quantise their input on the fly (fused_ext.gemm_silu_*,
         # decode_attention_f16_amax, gemm_partial_f16_*): 7 kernels per layer instead of 9, same bits.
         # 3 is the default (fused=True) where it applies: batch <= 16, one GPU.
-        # 4 (opt-in; per-channel weights, batch <= 16, hidden 4096, one GPU with 256 CUs) = level 3 with the MLP half of every
-        # layer -- add + norm + quant, gate_up + SiLU, down -- as ONE persistent launch with in-kernel hand-offs
-        # (fused_ext.mlp_fused_per_chn, csrc/mlp_fused.hip): 5 launches per layer, same bits.  Measured SLOWER than level 3
-        # in the step (2.37 vs 2.17 ms, profiles/r04_a_*: the launch is bound by the per-CU miss rate x what 128 KiB of
-        # registers per CU can hold ahead of a hand-off, which is what the L2 prefetch of the launch-per-kernel path already
-        # buys), so it is not the default.
-        self.fused = 3 if fused is True else int(fused)
+        # (A level 4 -- the MLP half of a layer as ONE persistent launch with in-kernel hand-offs -- was built in round 4, measured
+        #  slower than level 3 (2.37 vs 2.17 ms per step) and moved out of the product: tools/experiments/mlp_fused.hip, HISTORY.md.)
+        self.fused = 3 if fused is True else min(int(fused), 3)
         # the attention-side fusions of level 2 (split merge inside the quantiser, q / k / v from the qkv projection's slabs)
         # involve no row-parallel projection, so they also apply under tensor parallelism, where the level drops to 1
         self.l2_attn = self.fused >= 2 and batch <= 128 and bool(tp_l2_attn)
@@ -171,9 +167,6 @@ class DecodeRunner:
         # without a grid-level K split, i.e. hidden <= 4096; one rider workgroup per row in a grid row of hidden / 64; the
         # rider's LDS copy of a row) and the wide attention merge's 4 heads per wave; otherwise level 2, which has no such
         # limits (a hidden = 5120 layer used to pass the old size test here and fail in its first step)
-        if self.fused >= 4 and not (cfg.group_size == -1 and self.tp_size == 1 and int(max_fused) >= 4 and
-                                    fused_ext.mlp_fused_ok(batch, cfg.hidden, self.il)):
-            self.fused = 3
         if self.fused >= 3 and not (self.hl % 4 == 0 and int(max_fused) >= 3 and
                                     _lib.lib().omni_gemm_rowfree_ok(batch, cfg.hidden, self.hl * cfg.head_dim, self.il,
                                                                     0 if cfg.group_size == -1 else 1) == 1):
@@ -272,18 +265,6 @@ class DecodeRunner:
         # row-maximum candidates of the level-3 path: [layer][0 = attention output, 1 = MLP activation][AMAX_WORDS], zeroed once
         # per step (the producers raise them with atomicMax)
         self.amax = torch.zeros((c.layers, 2, fused_ext.AMAX_WORDS), dtype=torch.int32, device=device)
-        # level 4: arrival counters / row maxima of the persistent MLP launches live BEHIND the row-maximum slots in one
-        # buffer, so that decode_step_begin zeroes both in its one launch (the counters are compared against (layer + 1) x
-        # arrivals: zeroed once per step, no memset between the layers)
-        self.mlp_counters = self.mlp_scratch = None
-        self.mlp_clocks = False
-        if self.fused >= 4:
-            import ctypes as _ct  # noqa: F401
-            nwords = int(_lib.lib().omni_mlp_fused_counter_words(c.layers))
-            self._step_zero = torch.zeros((self.amax.numel() + nwords,), dtype=torch.int32, device=device)
-            self.amax = self._step_zero[: self.amax.numel()].view(c.layers, 2, fused_ext.AMAX_WORDS)
-            self.mlp_counters = self._step_zero[self.amax.numel():]
-            _, self.mlp_scratch = fused_ext.mlp_fused_buffers(1, c.hidden, il, device)
         # level 3: the norm in front of gate_up prefetches ALL of DOWN's weights (29.6 MB fit the 32 MB of L2s) instead of
         # the head of gate_up's 58.7 MB; gate_up then streams cold with non-temporal loads (they do not displace the
         # prefetched lines) and down reads L2: 2.322-2.334 -> 2.294-2.314 ms per step on the same box (profiles/r03_g;
@@ -365,10 +346,7 @@ class DecodeRunner:
         self.steps_done += 1
 
     def check(self):
-        """Raises if an in-kernel hand-off of the last step's persistent launches gave up (level 4) or a peer wait timed out
-        (tensor parallel, tp_comm = "peer").  Synchronises."""
-        if self.mlp_counters is not None:
-            fused_ext.mlp_fused_check(self.mlp_counters)
+        """Raises if a peer wait of the last step timed out (tensor parallel, tp_comm = "peer").  Synchronises."""
         if self.comm is not None:
             self.comm.check_error()
 
@@ -431,7 +409,7 @@ class DecodeRunner:
         c = self.cfg
         if self.fused:     # one launch: embedding rows (torch's index_select takes 12.6 us for 16 rows) + lengths += 1 + the
             fused_ext.decode_step_begin(self.x, self.embed, self.tokens, self.lengths,      # step's row-maximum slots zeroed
-                                        (self._step_zero if self.fused >= 4 else self.amax) if self.fused >= 3 else None)
+                                        self.amax if self.fused >= 3 else None)
         else:
             self.lengths.add_(1)
             torch.index_select(self.embed, 0, self.tokens, out=self.x)
@@ -493,16 +471,6 @@ class DecodeRunner:
                     sk = self._partial_f16(self.attn_f16, self.amax[li, 0], L["o"], mA, sA)
                 else:
                     sk = self._partial(self._q_attn, L["o"])
-                if l3 and self.fused >= 4:
-                    # the MLP half in one persistent launch: residual += o_proj epilogue(slabs), norm + quant, gate_up + SiLU,
-                    # quant, down_proj -> slabs (self.slab is re-used: the launch reads o_proj's slabs before its first
-                    # hand-off and writes down_proj's after its second) + the activation's row sums / scales
-                    G, D = L["gate_up"], L["down"]
-                    skd = fused_ext.mlp_fused_per_chn(self.x, self.slab, sk, L["o"].s1_scales, L["o"].s1_szeros, sA, mA, L["ln2"],
-                                                      c.eps, G.qweight, G.s1_scales, G.s1_szeros, D.qweight, self.slab, mA, sA,
-                                                      self.mlp_counters, c.layers, li, self.mlp_scratch, clocks=self.mlp_clocks)
-                    pending = (skd, D)
-                    continue
                 if l3 and self.pf_down:
                     self._arm(L["down"], deferred=True)
                 else:

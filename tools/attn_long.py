@@ -1,5 +1,5 @@
 """Long-context KV4 / KV8 decode attention in isolation (B=8, T=32768, GQA 32/8) for rocprofv3 PMC passes.
-Usage: python tools/attn_long.py [kv4|kv8] [iters]"""
+Usage: python tools/attn_long.py [kv4|kv8] [iters] [B] [T]"""
 import os
 import sys
 
@@ -12,7 +12,9 @@ import omniserve_backend.fused_attention_pure_dense as pd  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "kv4"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-Hq, Hk, B, Tc = 32, 8, 8, 32768
+Hq, Hk = 32, 8
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+Tc = int(sys.argv[4]) if len(sys.argv) > 4 else 32768
 row = 128 if mode == "kv8" else 64
 pools = Pools(B, Tc // 64 + 2, Hk, row=row)
 lens = torch.full((B,), Tc + 1, dtype=torch.int32, device=dev)
