@@ -227,6 +227,11 @@ def roofline_gate_up(runner, ms_per_step=None):
            "in_step_us_per_launch": prof.get("in_step_us"), "in_step_source": prof.get("in_step_source"),
            "measured_copy_rate_GBps": HBM_ACHIEVABLE_GBS,      # context only (MI355X_MICROARCH.md: float4 copy 6.29 TB/s); `frac` is against the 8 TB/s peak
            "gemv_aggregate": aggregate}
+    sc = consts.get("stream_ceiling M=%d N=%d K=%d" % (B, N, K))
+    if sc:      # what an isolated launch that only LOADS this kernel's weight bytes costs on this chip (a measured ceiling, not a peak)
+        out["stream_ceiling"] = {"us_per_launch": sc.get("us_per_launch"), "frac": sc.get("frac_of_hbm_peak"),
+                                 "achieved_vs_ceiling": round(achieved / sc["GBps"], 4) if sc.get("GBps") else None,
+                                 "source": sc.get("source")}
     if silu:
         out["gate_up_plain_form"] = {"us_per_launch": round(ms_plain * 1e3, 2), "bytes_per_launch": alg_plain,
                                      "frac": round(alg_plain / (ms_plain * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}

@@ -8,15 +8,20 @@
 #include <cstdint>
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <bool NT, int RING>
+// COAL: lane l asks for bytes 16 l .. of a 1-KiB piece (piece j of a k-step = tiles 2 s, 2 s + 1 of tile row 2 ng + j): every lane quad
+// reads 64 ascending bytes.  !COAL: the MFMA operand's own lane map over the packed tile (what the GEMV kernels use): the lanes
+// of a quad are 64 B apart (round 5: the address unit takes one COALESCED quad per clock, a scattered one in four).
+template <bool NT, int RING, bool COAL = false>
 __global__ __launch_bounds__(256) void vgpr_kernel(const uint8_t* W, int* out, int K, int nsteps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ng = blockIdx.x;
   const int lx = (lane >> 3) & 1, lc = lane & 7, le = lane >> 4;
   const uint8_t* base = W + ((size_t)(2 * ng + lx) * (K / 32)) * 512 + (lc * 4 + le) * 16;
   const int k0 = (blockIdx.y * 4 + wave) * nsteps;
+  const uint8_t* cbase = W + (size_t)(2 * ng) * (K / 32) * 512 + lane * 16;
   auto ld = [&](int s, int j) -> v4i {
-    const v4i* p = reinterpret_cast<const v4i*>(base + (size_t)((k0 + s) * 2 + j) * 512);
+    const v4i* p = COAL ? reinterpret_cast<const v4i*>(cbase + ((size_t)j * (K / 32) + (size_t)(k0 + s) * 2) * 512)
+                        : reinterpret_cast<const v4i*>(base + (size_t)((k0 + s) * 2 + j) * 512);
     if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
   };
   v4i q[RING][2];
@@ -38,7 +43,7 @@ __global__ __launch_bounds__(256) void vgpr_kernel(const uint8_t* W, int* out, i
 }
 
 // DMA ring: PIECES 1-KiB pieces in flight per wave (two pieces = one 64-k step of the wave's two tile rows)
-template <bool NT, int PIECES>
+template <bool NT, int PIECES, bool COAL = false>
 __global__ __launch_bounds__(256) void dma_kernel(const uint8_t* W, int* out, int K, int nsteps) {
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -49,7 +54,8 @@ __global__ __launch_bounds__(256) void dma_kernel(const uint8_t* W, int* out, in
   const uint32_t ring = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)smem + wave * PIECES * 1024;
   const int npieces = nsteps * 2;
   auto issue = [&](int pc) {      // piece pc of this wave -> ring slot pc % PIECES
-    const uint8_t* src = base + (size_t)(k0 * 2 + pc) * 512;
+    const uint8_t* cb = W + (size_t)(2 * ng) * (K / 32) * 512 + lane * 16;
+    const uint8_t* src = COAL ? cb + ((size_t)(pc & 1) * (K / 32) + (size_t)(k0 + (pc >> 1)) * 2) * 512 : base + (size_t)(k0 * 2 + pc) * 512;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(ring + (uint32_t)(pc % PIECES) * 1024);
     uint32_t keep;
     if constexpr (NT)
@@ -105,12 +111,16 @@ int main() {
       float us = time_us([&](int i) { hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, W + bytes * (i % copies), out, K, nsteps); }, 36); \
       printf("sk=%d %-34s: %7.2f us  %7.1f GB/s\n", sk, name, us, bytes / us / 1e3); }
     RUN("vgpr ring 8 steps nt", (vgpr_kernel<true, 8>), 0)
+    RUN("vgpr ring 8 steps nt COALESCED", (vgpr_kernel<true, 8, true>), 0)
+    RUN("vgpr ring 8 steps COALESCED", (vgpr_kernel<false, 8, true>), 0)
     RUN("vgpr ring 8 steps", (vgpr_kernel<false, 8>), 0)
     if (sk == 1) RUN("vgpr ring 16 steps nt", (vgpr_kernel<true, 16>), 0)
     RUN("dma ring 8 pieces", (dma_kernel<false, 8>), 4 * 8 * 1024)
     RUN("dma ring 8 pieces nt", (dma_kernel<true, 8>), 4 * 8 * 1024)
     RUN("dma ring 16 pieces", (dma_kernel<false, 16>), 4 * 16 * 1024)
     RUN("dma ring 16 pieces nt", (dma_kernel<true, 16>), 4 * 16 * 1024)
+    RUN("dma ring 16 pieces nt COALESCED", (dma_kernel<true, 16, true>), 4 * 16 * 1024)
+    RUN("dma ring 8 pieces nt COALESCED", (dma_kernel<true, 8, true>), 4 * 8 * 1024)
     if (sk == 1) RUN("dma ring 32 pieces nt", (dma_kernel<true, 32>), 4 * 32 * 1024)
   }
   return 0;
