@@ -296,10 +296,13 @@ _TICKETS = {}
 
 
 def _tickets(device):
-    """Ticket words of the single-launch decode attention: zero between launches (the last arriver resets its word)."""
-    t = _TICKETS.get(device)
+    """Ticket words of the single-launch decode attention: zero between launches (the last arriver resets its word).  One buffer
+    per (device, stream) -- include/omniserve_hip.h asks for one per stream: two runners decoding concurrently on two streams
+    of one device must not share ticket words."""
+    key = (torch.device(device), int(torch.cuda.current_stream(device).cuda_stream))
+    t = _TICKETS.get(key)
     if t is None:
-        t = _TICKETS[device] = torch.zeros((4096,), dtype=torch.int32, device=device)
+        t = _TICKETS[key] = torch.zeros((4096,), dtype=torch.int32, device=device)
     return t
 
 

@@ -44,17 +44,14 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
   // at about twice the single-wave tiles' rate beyond them, so it takes the BIG matrices (measured, tools/midm_sweep.py,
   // profiles/r05_a: Llama-3-8B gate_up at M = 128 35.4 -> 23.1 us, Llama-2-70B gate_up 138 -> 71, down 106 -> 41 -- and
   // Llama-3-8B qkv 11.7 -> 19.6, which stays where it was): N x K >= 80 M weights, or >= 50 M where the caller wants the
-  // slabs anyway (the deferred forms at 65 .. 128 rows: no slab epilogue launch to pay for).  Per-group weights at <= 64 rows
-  // tie on Llama-3-8B's gate_up (21.4 vs 20.7 .. 22.5 us) and keep their plan below 200 M.
+  // slabs anyway (the deferred forms: no slab epilogue launch to pay for; Llama-3-8B down at M = 64: 11.4 -> 10.7 us, g128
+  // 13.6 -> 12.6; g128 gate_up at M = 64 21.2 -> 19.5).
   // K split: one workgroup per CU and launch (its LDS rings fill the CU) -- the largest split that keeps the grid inside one
   // round of 256 and >= 4 chunks per slice (Llama-2-70B qkv, 80 tiles: 2 slices 28.5 us, 4 slices 34.7).
   if (g_midm_mode != 0 && g_override_waves == 0 && g_override_sk == 0 && M > 32 && M <= 128 && N % 128 == 0 && K % KCHUNK == 0) {
     const long long weights = (long long)N * K;
     bool take = g_midm_mode > 0;
-    if (g_midm_mode < 0) {
-      if (M <= 64) take = weights >= (kalign == 128 ? 200000000LL : 80000000LL);
-      else take = weights >= 80000000LL || (deferred && weights >= 50000000LL);
-    }
+    if (g_midm_mode < 0) take = weights >= 80000000LL || (deferred && weights >= 50000000LL);
     if (take) {
       const int tiles = N / 128;
       int best = 1;
