@@ -120,16 +120,19 @@ __device__ __forceinline__ void vadd4_zbyte_x4(uint32_t (&u)[4], uint32_t zw, in
   }
 }
 
+// (the f32 result is made opaque before the fp16 conversion: hipcc otherwise may fold `(half)(f32 * f32)` into
+//  v_fma_mixlo_f16 -- ONE rounding where the reference rounds to f32 first; one output in ~10^4 then differs by an ulp,
+//  depending on the code around the call: seen in w4a8_gemm_exact_kernel (round 3) and in w4a8_midm_kernel's store forms)
 template <int MODE>
 __device__ __forceinline__ half_t epilogue(int acc, float sw, float sa, float sz, float asum) {
   if constexpr (MODE == MODE_CHN) {
     float t = (float)acc * sw;
     t = t * sa;
     float c = sz * asum;
-    return (half_t)(t - c);
+    return (half_t)rounded_f32(t - c);
   } else {
     float s = sw * sa;
-    return (half_t)((float)acc * s);
+    return (half_t)rounded_f32((float)acc * s);
   }
 }
 
@@ -1255,7 +1258,8 @@ template <int MODE, bool TO_SLAB>
 static void launch_midm(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
   const dim3 grid(a.N / 128, pl.sk, pl.mz), block(512);
   const bool nt = !take_prefetched_weight(a.W);
-  const GemmArgs& b = a;
+  GemmArgs b = a;
+  b.tile_linear = (!TO_SLAB && (a.out_stride % 8) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) ? 1 : 0;   // 16-B stores
   if (pl.mb == 8) {
     if (nt) hipLaunchKernelGGL((w4a8_midm_kernel<8, MODE, TO_SLAB, true>), grid, block, 0, st, b);
     else hipLaunchKernelGGL((w4a8_midm_kernel<8, MODE, TO_SLAB, false>), grid, block, 0, st, b);

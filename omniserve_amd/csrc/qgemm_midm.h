@@ -487,17 +487,17 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
     const v4i* const theirs = red + (size_t)(wave ^ 2) * HB * 4 * 64 + lane;
     if (s < 2) {
 #pragma unroll
-      for (int j = 0; j < HB; ++j) {      // (one row block at a time: sixteen reads in flight next to 128 accumulators spill)
+      for (int j = 0; j < HB; ++j) {      // (two row blocks' reads in flight: all sixteen next to 128 accumulators spill)
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab) acc[j][ab] += theirs[(j * 4 + ab) * 64];
-        __builtin_amdgcn_sched_barrier(0);
+        if (j & 1) __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < HB; ++j) {
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab) acc[HB + j][ab] += theirs[(j * 4 + ab) * 64];
-        __builtin_amdgcn_sched_barrier(0);
+        if (j & 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
@@ -518,7 +518,6 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
       for (int j = 0; j < QB; ++j) {
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab) acc[KEEP + j][ab] += theirs[(j * 4 + ab) * 64];
-        __builtin_amdgcn_sched_barrier(0);
       }
     };
     if (s == 0) park2(IntTag<QB>{});
@@ -538,6 +537,7 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
   // W4: channel = ng * 64 + (i >> 3) * 32 + ab * 8 + (i & 7) (4 consecutive channels per lane); W8: ng * 64 + ab * 16 + i.
   const int mcol = lane & 15;
   const int i0 = (lane >> 4) * 4;
+  const bool out16 = !TO_SLAB && p.tile_linear != 0;      // (host: output rows start 16-B aligned)
   auto finish = [&](auto first_tag) {
     constexpr int FIRST = decltype(first_tag)::value;
 #pragma unroll
@@ -550,26 +550,53 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
         sa = (float)__builtin_bit_cast(half_t, (uint16_t)(av & 0xFFFFu));
         as = (float)__builtin_bit_cast(half_t, (uint16_t)(av >> 16));
       }
-#pragma unroll
-      for (int ab = 0; ab < 4; ++ab) {
+      auto fp16x4 = [&](int ab) -> uint2 {      // the four channels this lane holds of operand block ab, finished to fp16
         int nl;     // channel inside the workgroup's tile
         if constexpr (MODE == MODE_W8) nl = g * 64 + ab * 16 + i0;
         else nl = g * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
-        const int n = blockIdx.x * 64 * NG + nl;
+        const uint4 w4 = *reinterpret_cast<const uint4*>(&epi_w[nl]);      // {wscale, w_sz} x 4 channels
+        const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
         const v4i a4 = acc[mb][ab];
-        if (m >= p.M) continue;
-        if constexpr (TO_SLAB) {
-          int32_t* dst = p.slab + ((size_t)blockIdx.y * p.M + m) * p.N + n;
-          *reinterpret_cast<v4i*>(dst) = a4;
-        } else {
-          const uint4 w4 = *reinterpret_cast<const uint4*>(&epi_w[nl]);      // {wscale, w_sz} x 4 channels
-          const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
-          half_t o[4];
+        half_t o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            o[r] = epilogue<MODE>(a4[r], (float)__builtin_bit_cast(half_t, (uint16_t)(wv[r] & 0xFFFFu)), sa,
-                                  (float)__builtin_bit_cast(half_t, (uint16_t)(wv[r] >> 16)), as);
-          *reinterpret_cast<uint2*>(p.out + (size_t)m * p.out_stride + n) = *reinterpret_cast<const uint2*>(o);
+        for (int r = 0; r < 4; ++r)
+          o[r] = epilogue<MODE>(a4[r], (float)__builtin_bit_cast(half_t, (uint16_t)(wv[r] & 0xFFFFu)), sa,
+                                (float)__builtin_bit_cast(half_t, (uint16_t)(wv[r] >> 16)), as);
+        return *reinterpret_cast<const uint2*>(o);
+      };
+      if constexpr (TO_SLAB) {
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+          int nl;
+          if constexpr (MODE == MODE_W8) nl = g * 64 + ab * 16 + i0;
+          else nl = g * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
+          if (m < p.M)
+            *reinterpret_cast<v4i*>(p.slab + ((size_t)blockIdx.y * p.M + m) * p.N + blockIdx.x * 64 * NG + nl) = acc[mb][ab];
+        }
+      } else if (out16) {
+        // lane pairs (l, l ^ 16) exchange halves so that every lane stores 16 B = 8 consecutive channels
+        // (w4a8_gemm_exact_kernel's write-back): 4 store instructions per wave and two row blocks instead of 8
+        const int odd = (lane >> 4) & 1;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const uint2 x = fp16x4(2 * pr), y = fp16x4(2 * pr + 1);
+          const auto lo = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+          const auto hi = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+          int n8;
+          if constexpr (MODE == MODE_W8) n8 = g * 64 + (2 * pr + odd) * 16 + (lane >> 5) * 8;
+          else n8 = g * 64 + (lane >> 5) * 32 + (2 * pr + odd) * 8;
+          if (m < p.M)
+            *reinterpret_cast<uint4*>(p.out + (size_t)m * p.out_stride + blockIdx.x * 64 * NG + n8) =
+                make_uint4((uint32_t)lo[0], (uint32_t)hi[0], (uint32_t)lo[1], (uint32_t)hi[1]);
+        }
+      } else {
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+          int nl;
+          if constexpr (MODE == MODE_W8) nl = g * 64 + ab * 16 + i0;
+          else nl = g * 64 + (i0 >> 3) * 32 + ab * 8 + (i0 & 7);
+          const uint2 o = fp16x4(ab);
+          if (m < p.M) *reinterpret_cast<uint2*>(p.out + (size_t)m * p.out_stride + blockIdx.x * 64 * NG + nl) = o;
         }
       }
     }

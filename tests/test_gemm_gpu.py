@@ -22,7 +22,10 @@ def _run_chn(M, N, K, seed=0, out_view=False):
     qw, s1h, szh = w4a8.pack_per_channel(u, z, s1)
     a, sa, asum = _acts(M, K, seed + 1)
     want = w4a8.gemm_per_chn(a, qw, s1h, sa, szh, asum)
-    if out_view:  # pre-allocated larger buffer, row-slice view (llama_w4a8_unpad.py:356-361)
+    if out_view == "cols":  # rows that start 8 bytes into a wider buffer (row stride not a multiple of 16 bytes: the 8-byte store forms)
+        buf = torch.full((M, N + 4), 7.0, dtype=torch.float16, device=dev())
+        out = buf[:, 4:]
+    elif out_view:  # pre-allocated larger buffer, row-slice view (llama_w4a8_unpad.py:356-361)
         buf = torch.full((M + 3, N), 7.0, dtype=torch.float16, device=dev())
         out = buf[1:M + 1]
     else:
@@ -30,7 +33,9 @@ def _run_chn(M, N, K, seed=0, out_view=False):
     mod.gemm_forward_cuda(to_dev(a), to_dev(qw), to_dev(s1h), to_dev(sa), to_dev(szh), to_dev(asum), out)
     torch.cuda.synchronize()
     assert_f16_equal(out, want, "per_chn M=%d N=%d K=%d" % (M, N, K))
-    if out_view:
+    if out_view == "cols":
+        assert (buf[:, :4] == 7).all()
+    elif out_view:
         assert (buf[0] == 7).all() and (buf[M + 1:] == 7).all()
 
 
@@ -300,6 +305,7 @@ def test_midm_forced_per_chn(M, N, K, sk):
     with _ForcedMidm(sk):
         _run_chn(M, N, K, seed=M + K)
         _run_chn(M, N, K, seed=M + K + 1, out_view=True)
+        _run_chn(M, N, K, seed=M + K + 2, out_view="cols")
 
 
 @pytest.mark.parametrize("wrap", [False, True])
