@@ -342,20 +342,33 @@ def drop_in_leg(cfg, args, device, steps=24, warmup=4):
     """The decode step through the reference call sequence ONLY (llama_w4a8_unpad.py:406-438: 11 mirror calls per layer
     plus the torch residual adds), launched eagerly: no fused extension entry points, no HIP graph, no L2 prefetch,
     torch.argmax -- what the unmodified reference host stack would get from the drop-in mirror (minus its own Python)."""
+    from omniserve_amd import _lib
     from omniserve_amd.runtime import DecodeRunner
     r = DecodeRunner(cfg, args.batch, args.context, steps + warmup + 4, device, seed=99, use_graph=False, fused=0)
-    for _ in range(warmup):
-        r.step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        r.step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+
+    def run(use_ext):
+        keep, _lib.USE_EXT = _lib.USE_EXT, use_ext
+        try:
+            for _ in range(warmup):
+                r.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r.step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps
+        finally:
+            _lib.USE_EXT = keep
+    have_ext = _lib.fast() is not None
+    dt_ctypes = run(False)
+    dt = run(True) if have_ext else dt_ctypes
     del r
     torch.cuda.empty_cache()
     return {"ms_per_step": round(dt * 1e3, 4), "tokens_per_s": round(args.batch / dt, 1), "hip_graph": False,
             "fused_ext_level": 0, "prefetch": False,
+            "binding": "pybind11 (omniserve_amd/csrc_ext/omni_ext.cpp) for the GEMM / norm / quant / SiLU calls, ctypes for the attention"
+                       if have_ext else "ctypes",
+            "ms_per_step_ctypes_mirror": round(dt_ctypes * 1e3, 4),
             "note": "eager launches of the reference's own call sequence; host-launch bound (~360 launches per step)"}
 
 

@@ -6,6 +6,10 @@ from .. import _lib
 
 
 def silu_and_mul(out, input):
+    if input.dtype is torch.float16 and out.dtype is torch.float16:
+        f = _lib.fast()
+        if f is not None:
+            return f.silu_and_mul_f16(out, input)
     _lib.require_cuda(out, input)
     d = input.shape[-1] // 2
     tokens = input.numel() // input.shape[-1]

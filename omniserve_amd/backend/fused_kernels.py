@@ -28,6 +28,10 @@ def invoke_quant(out, input, scale):
     a Python float (at::Half) -> static, q = rni_sat(x / scale) (fused_kernels.cu:202-216)."""
     if not torch.is_tensor(scale):
         return _quant_static(out, input, scale, "fused_kernels.invoke_quant")
+    if input.dtype is torch.float16:
+        f = _lib.fast()
+        if f is not None:
+            return f.quant_f16(out, input, scale)
     tokens, hidden = _shape(out, input)
     if tokens == 0:
         return
@@ -48,6 +52,10 @@ def invoke_quant_fuse_sum(out, input, input_sum, scale):
         return _quant_static(out, input, scale, "fused_kernels.invoke_quant_fuse_sum")
     if not torch.is_tensor(scale) or not torch.is_tensor(input_sum):
         raise TypeError("invoke_quant_fuse_sum: input_sum and scale must both be tensors or both be floats")
+    if input.dtype is torch.float16:
+        f = _lib.fast()
+        if f is not None:
+            return f.quant_fuse_sum_f16(out, input, input_sum, scale)
     tokens, hidden = _shape(out, input)
     if tokens == 0:
         return

@@ -11,6 +11,10 @@ def _shape(input):
 
 def rms_norm(out, input, weight, epsilon, use_quant=False):
     """fp16 out (layernorm_kernels.cu:335-365), or with use_quant int8 out = rni_sat((x * rstd) * w)."""
+    if not use_quant and input.dtype is torch.float16 and weight.dtype is torch.float16 and out.dtype is torch.float16:
+        f = _lib.fast()
+        if f is not None:
+            return f.rms_norm_f16(out, input, weight, float(epsilon))
     _lib.require_cuda(out, input, weight)
     tokens, hidden = _shape(input)
     fn = _lib.lib().omni_rms_norm_quant if use_quant else _lib.lib().omni_rms_norm
@@ -36,6 +40,10 @@ def rms_norm(out, input, weight, epsilon, use_quant=False):
 def rms_norm_general(out, input, weight, scaling, epsilon, use_per_token_quant=False):
     """Per token: scaling [tokens] is written (layernorm_kernels.cu:443-454); per tensor: scaling [1] is read,
     q = rni_sat(y * scaling) (:455-466)."""
+    if use_per_token_quant and input.dtype is torch.float16 and weight.dtype is torch.float16:
+        f = _lib.fast()
+        if f is not None:
+            return f.rms_norm_general_f16(out, input, weight, scaling, float(epsilon))
     _lib.require_cuda(out, input, weight, scaling)
     tokens, hidden = _shape(input)
     fn = _lib.lib().omni_rms_norm_general if use_per_token_quant else _lib.lib().omni_rms_norm_general_static
@@ -59,6 +67,10 @@ def rms_norm_general_fuse_sum(out, input, weight, input_sum, scaling, epsilon, u
     if not use_per_token_quant:
         raise AssertionError("rms_norm_general_fuse_sum: per-tensor input_sum is not implemented "
                              "(the reference asserts here too, layernorm_kernels.cu:499-501)")
+    if input.dtype is torch.float16 and weight.dtype is torch.float16:
+        f = _lib.fast()
+        if f is not None:
+            return f.rms_norm_general_fuse_sum_f16(out, input, weight, input_sum, scaling, float(epsilon))
     _lib.require_cuda(out, input, weight, input_sum, scaling)
     tokens, hidden = _shape(input)
     dt = _lib.elem_dtype(input, "generalLayerNorm_fuse_sum")

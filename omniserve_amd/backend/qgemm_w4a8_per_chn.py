@@ -6,6 +6,9 @@ from ._gemm_common import check_gemm_io, gemm_workspace
 def gemm_forward_cuda(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_feats):
     """out_feats[m,n] = fp16(acc*wscales[n]*ascales[m] - w_szs[n]*a_ssums[m]); writes in place,
     returns None (caller: w4a8_linear.py:111-120)."""
+    f = _lib.fast()
+    if f is not None:
+        return f.gemm_w4a8_per_chn(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_feats)
     M, N, K, stride = check_gemm_io(in_feats, kernel, out_feats, packed=True)
     _lib.require_cuda(wscales, ascales, w_szs, a_ssums)
     ws = gemm_workspace(M, N, K, in_feats.device)

@@ -5,6 +5,9 @@ from ._gemm_common import check_gemm_io, gemm_workspace
 
 def gemm_forward_cuda(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_feats):
     """g128 W4A8 GEMM; argument order as the reference (caller: w4a8_linear.py:126-135)."""
+    f = _lib.fast()
+    if f is not None:
+        return f.gemm_w4a8_per_group(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_feats)
     M, N, K, stride = check_gemm_io(in_feats, kernel, out_feats, packed=True)
     _lib.require_cuda(zeros, scales_i8, wscales, ascales)
     if tuple(zeros.shape) != (K // 128, N) or tuple(scales_i8.shape) != (K // 128, N):

@@ -4,6 +4,9 @@ from ._gemm_common import check_gemm_io, gemm_workspace
 
 
 def w8a8_gemm_forward_cuda(in_feats, kernel, wscales, ascales, out_feats):
+    f = _lib.fast()
+    if f is not None:
+        return f.gemm_w8a8(in_feats, kernel, wscales, ascales, out_feats)
     M, N, K, stride = check_gemm_io(in_feats, kernel, out_feats, packed=False)
     _lib.require_cuda(wscales, ascales)
     ws = gemm_workspace(M, N, K, in_feats.device)

@@ -43,12 +43,50 @@ def _deps_mtime() -> float:
     return max(m, os.path.getmtime(os.path.abspath(__file__)))
 
 
+EXT_SRC = os.path.join(HERE, "csrc_ext", "omni_ext.cpp")
+
+
+def ext_path() -> str:
+    import sysconfig
+    return os.path.join(HERE, "_omni_ext" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
 def needs_build() -> bool:
-    return not os.path.exists(LIB) or os.path.getmtime(LIB) < _deps_mtime()
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < _deps_mtime():
+        return True
+    ext = ext_path()
+    return not os.path.exists(ext) or os.path.getmtime(ext) < max(os.path.getmtime(EXT_SRC), os.path.getmtime(LIB))
+
+
+def build_ext(verbose: bool = False) -> str:
+    """The pybind11 fast path of the mirror (csrc_ext/omni_ext.cpp): host-only C++ against the installed torch's headers,
+    linked to libomniserve_hip.so next to it (rpath $ORIGIN); g++, ~25 s.  The mirror works without it (ctypes)."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    out = ext_path()
+    inc = list(ce.include_paths()) + ["/opt/rocm/include", os.path.join(os.path.dirname(HERE), "include"),
+                                      sysconfig.get_paths()["include"]]
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=_omni_ext", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ["-I" + i for i in inc]
+    tmp = out + ".tmp"
+    cmd += [EXT_SRC, "-o", tmp, "-L" + torch_lib, "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10", "-lc10_hip", "-ltorch_hip",
+            "-L" + HERE, "-l:libomniserve_hip.so", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + torch_lib]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building the pybind11 fast path failed:\n%s" % r.stderr[-4000:])
+    os.replace(tmp, out)
+    return out
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
+        return LIB
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():      # only the binding is stale
+        build_ext(verbose)
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
@@ -72,6 +110,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     os.replace(tmp, LIB)
+    build_ext(verbose)
     return LIB
 
 

@@ -160,3 +160,22 @@ def test_kv_formats_without_a_working_upstream_behaviour_are_named_in_the_error(
     _attn_common._check_cfg(128, True, True, True, 128)          # the fine_grained KV4 format
     _attn_common._check_cfg_kv8(128, True, False, False, 128)    # the per_tensor KV8 format
 
+
+
+
+def test_fast_binding_is_built_and_exports_the_routed_functions():
+    """omniserve_amd/csrc_ext/omni_ext.cpp: the pybind11 bodies of the per-step mirror functions.  It imports here (it links
+    the library), reports the library's ABI version, and is NOT used without a GPU (the mirror stays on ctypes)."""
+    import importlib
+    import os
+    from omniserve_amd import _lib, build
+    assert os.path.exists(build.ext_path()), "python -m omniserve_amd.build builds it next to the library"
+    _lib.lib()
+    e = importlib.import_module("omniserve_amd._omni_ext")
+    assert e.abi_version() == _lib.lib().omni_abi_version()
+    for name in ("gemm_w4a8_per_chn", "gemm_w4a8_per_group", "gemm_w8a8", "rms_norm_general_fuse_sum_f16", "rms_norm_general_f16",
+                 "rms_norm_f16", "quant_fuse_sum_f16", "quant_f16", "silu_and_mul_f16"):
+        assert callable(getattr(e, name))
+    import torch
+    if not torch.cuda.is_available():
+        assert _lib.fast() is None

@@ -288,12 +288,14 @@ class _ForcedMidm:
         from omniserve_amd.backend import _gemm_common
         _lib.lib().omni_gemm_set_midm_override(1, self.sk)
         _gemm_common._ws_bytes.clear()
+        self.keep_ext, _lib.USE_EXT = _lib.USE_EXT, False      # (the fast binding caches scratch sizes per shape as well)
 
     def __exit__(self, *exc):
         from omniserve_amd import _lib
         from omniserve_amd.backend import _gemm_common
         _lib.lib().omni_gemm_set_midm_override(-1, 0)
         _gemm_common._ws_bytes.clear()
+        _lib.USE_EXT = self.keep_ext
 
 
 MIDM_SMALL = [(33, 128, 256, 0), (64, 256, 512, 0), (65, 128, 1024, 0), (100, 384, 2048, 2), (128, 256, 4096, 4), (48, 128, 768, 0),

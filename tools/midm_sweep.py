@@ -15,6 +15,7 @@ if os.environ.get("OMNI_TUNE_LIB"):     # A/B against a library variant (tools/b
     _lib.LIB_PATH = os.path.abspath(os.environ["OMNI_TUNE_LIB"])
 from omniserve_amd.backend import _gemm_common, fused_ext, qgemm_w4a8_per_chn, qgemm_w4a8_per_group, qgemm_w8a8  # noqa: E402
 
+_lib.USE_EXT = False      # plan overrides change scratch sizes per shape: stay on the ctypes mirror, which this tool re-sizes
 dev = torch.device("cuda:0")
 lib = _lib.lib()
 quick = "--quick" in sys.argv or "--big" in sys.argv
