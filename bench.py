@@ -369,7 +369,9 @@ def drop_in_leg(cfg, args, device, steps=24, warmup=4):
             "binding": "pybind11 (omniserve_amd/csrc_ext/omni_ext.cpp) for the GEMM / norm / quant / SiLU calls, ctypes for the attention"
                        if have_ext else "ctypes",
             "ms_per_step_ctypes_mirror": round(dt_ctypes * 1e3, 4),
-            "note": "eager launches of the reference's own call sequence; host-launch bound (~360 launches per step)"}
+            "note": "eager launches of the reference's own call sequence (~450 launches per step incl. torch's adds / arg-max): bound by "
+                    "per-kernel dispatch without a graph, not by the binding -- the pybind11 path halves the host time per call "
+                    "(cProfile: 7 -> 3.5 us) and the step does not move (profiles/r05_d_drop_in.md)"}
 
 
 def configs2_leg(args, device, steps=32, warmup=6):

@@ -75,6 +75,19 @@ _dense_ws_bytes = {}      # (B, Hq, D, context rounded up to 1024) -> omni_kv4_d
 def decode_attention(q, k, v, kv_pointers, lengths, tokens_per_block, size_per_token, timestep,
                      rotary_embedding_dim, rotary_base, neox, int4, zeros, what):
     # (runs once per decoder layer of every eager decode step: attributes are read once, the scratch size is cached)
+    f = _lib.fast()
+    if f is not None:      # the pybind11 body (csrc_ext/omni_ext.cpp): same checks, same C-ABI call, callee-allocated result
+        B, Hq, D = q.shape
+        _check_cfg(rotary_embedding_dim, neox, int4, zeros, D)
+        max_ctx = max(int(timestep), 1)
+        device = q.device
+        table = rope_table(max_ctx + 1, D, float(rotary_base), 1.0, device)
+        key = (B, Hq, D, (max_ctx + 1023) >> 10)
+        need = _dense_ws_bytes.get(key)
+        if need is None:
+            need = _dense_ws_bytes[key] = int(_lib.lib().omni_kv4_decode_workspace_bytes(B, Hq, D, key[3] << 10))
+        return f.decode_attention_kv4(q, k, v, kv_pointers, lengths, int(tokens_per_block), int(size_per_token), max_ctx, table,
+                                      _lib.workspace(need, device, "attn"), what)
     _lib.require_cuda(q, k, v, kv_pointers, lengths)
     B, Hq, D = q.shape
     Hkv = k.shape[1]

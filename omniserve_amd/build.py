@@ -86,7 +86,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():      # only the binding is stale
-        build_ext(verbose)
+        try:
+            build_ext(verbose)
+        except Exception as exc:   # noqa: BLE001
+            print("omniserve_amd.build: the pybind11 fast path was not built (%s)" % str(exc)[-400:], file=sys.stderr)
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
@@ -110,7 +113,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     os.replace(tmp, LIB)
-    build_ext(verbose)
+    try:
+        build_ext(verbose)
+    except Exception as exc:   # noqa: BLE001  (the mirror works without it: ctypes)
+        print("omniserve_amd.build: the pybind11 fast path was not built (%s); the ctypes mirror stays in use" % str(exc)[-400:],
+              file=sys.stderr)
     return LIB
 
 

@@ -158,6 +158,28 @@ void silu_and_mul_f16(torch::Tensor out, const torch::Tensor& input) {
   fail(omni_silu_and_mul(out.data_ptr(), input.data_ptr(), tokens, (int)(d2 / 2), stream_of(input)), "activation_ops.silu_and_mul");
 }
 
+// fused_attention_pure_dense.single_query_attention (KV4 pages with zero points, neox RoPE): the callee allocates the fp16 [B,Hq,Dh]
+// result, as the reference does.  `table` / `ws`: the host-built RoPE table and the split-KV scratch the mirror caches per device.
+torch::Tensor decode_attention_kv4(const torch::Tensor& q, const torch::Tensor& k, const torch::Tensor& v, const torch::Tensor& kv_pointers,
+                                   const torch::Tensor& lengths, int64_t tokens_per_block, int64_t size_per_token, int64_t max_ctx,
+                                   const torch::Tensor& table, torch::Tensor ws, const std::string& what) {
+  const char* w = what.c_str();
+  need_cuda(q, w); need_cuda(k, w); need_cuda(v, w); need_cuda(kv_pointers, w); need_cuda(lengths, w);
+  TORCH_CHECK(q.dim() == 3 && k.dim() == 3 && v.dim() == 3, w, ": q / k / v must be [B,H,D]");
+  const int64_t B = q.size(0), Hq = q.size(1), D = q.size(2), Hkv = k.size(1);
+  TORCH_CHECK(size_per_token == Hkv * D / 2, w, ": size_per_token ", size_per_token, " != Hkv*Dh/2");
+  TORCH_CHECK(q.scalar_type() == torch::kFloat16 && q.stride(2) == 1 && q.stride(1) == D, w, ": q must be fp16 [B,H,D] with contiguous heads");
+  TORCH_CHECK(k.stride(2) == 1 && k.stride(1) == D && v.stride(2) == 1 && v.stride(1) == D, w, ": k/v heads must be contiguous");
+  TORCH_CHECK(k.stride(0) == v.stride(0), w, ": k and v must share the row stride");
+  TORCH_CHECK(lengths.scalar_type() == torch::kInt32 && kv_pointers.is_contiguous(), w, ": lengths must be int32, kv_pointers contiguous");
+  torch::Tensor out = torch::empty({B, Hq, D}, q.options());
+  fail(omni_kv4_decode_attention(out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), kv_pointers.data_ptr(),
+                                 lengths.data_ptr(), (int)B, (int)kv_pointers.size(-1), (int)Hq, (int)Hkv, (int)D, (int)tokens_per_block,
+                                 (int)max_ctx, table.data_ptr(), (int)table.size(0), ws.data_ptr(), (size_t)ws.numel(), stream_of(q)),
+       w);
+  return out;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -172,4 +194,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("quant_fuse_sum_f16", &quant_fuse_sum_f16);
   m.def("quant_f16", &quant_f16);
   m.def("silu_and_mul_f16", &silu_and_mul_f16);
+  m.def("decode_attention_kv4", &decode_attention_kv4);
 }

@@ -132,3 +132,43 @@ def test_other_element_types_keep_the_ctypes_path():
         fk.invoke_quant(q, x.half(), 0.05)
     torch.cuda.synchronize()
     assert np.isfinite(s.float().cpu().numpy()).all()
+
+
+def test_decode_attention_agrees_incl_appended_rows():
+    """fused_attention_pure_dense.single_query_attention: callee-allocated result and the appended KV rows, both bindings."""
+    import omniserve_backend.fused_attention_pure_dense as fa
+    from oracle import kv4
+    from tests.util import GpuPagedKV, to_dev
+    D, BASE, Hq, Hk = 128, 500000.0, 32, 8
+    hist = [200, 17, 130, 1000]
+    B = len(hist)
+    rng = np.random.default_rng(7)
+    pages = (max(hist) + 64) // 64 + 1
+    n_pages = B * pages
+    kc, vc = kv4.PagedKV4(n_pages, Hk, D), kv4.PagedKV4(n_pages, Hk, D)
+    for c in (kc, vc):
+        c.pool[:] = rng.integers(0, 256, c.pool.shape, dtype=np.uint8)
+        for p in range(n_pages):
+            c.scales(p)[:] = (0.05 + 0.15 * rng.random((Hk, 64))).astype(np.float16)
+            c.zeros(p)[:] = (6.0 + 3.0 * rng.random((Hk, 64))).astype(np.float16)
+    kidx = rng.permutation(n_pages).reshape(B, pages)
+    vidx = rng.permutation(n_pages).reshape(B, pages)
+    pools = [GpuPagedKV(kc, vc, kidx, vidx), GpuPagedKV(kc, vc, kidx, vidx)]
+    lens = to_dev(np.asarray(hist, np.int32) + 1)
+    qkv = to_dev(rng.standard_normal((B, (Hq + 2 * Hk) * D)).astype(np.float16))
+    q = qkv[:, : Hq * D].view(B, Hq, D)
+    k = qkv[:, Hq * D:(Hq + Hk) * D].view(B, Hk, D)
+    v = qkv[:, (Hq + Hk) * D:].view(B, Hk, D)
+    outs = []
+    for use_ext, g in zip((False, True), pools):
+        with _Path(use_ext):
+            outs.append(fa.single_query_attention(q, k, v, g.table, lens, None, 65536, 64, Hk * D // 2, max(hist) + 1, D, BASE, True, True, True))
+    torch.cuda.synchronize()
+    assert outs[1].shape == (B, Hq, D) and outs[1].is_contiguous()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert torch.equal(pools[0].kpool, pools[1].kpool) and torch.equal(pools[0].vpool, pools[1].vpool)
+    with _Path(True):
+        with pytest.raises(RuntimeError):
+            fa.single_query_attention(q, k, v, pools[1].table, lens.long(), None, 65536, 64, Hk * D // 2, max(hist) + 1, D, BASE, True, True, True)
+        with pytest.raises(NotImplementedError):      # non-neox RoPE: refused before either binding is reached
+            fa.single_query_attention(q, k, v, pools[1].table, lens, None, 65536, 64, Hk * D // 2, max(hist) + 1, D, BASE, False, True, True)
