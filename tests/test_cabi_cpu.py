@@ -5,6 +5,8 @@ import inspect
 import os
 import re
 
+import pytest
+
 from omniserve_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
