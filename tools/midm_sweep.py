@@ -11,14 +11,14 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omniserve_amd import _lib  # noqa: E402
 
-if os.environ.get("OMNI_TUNE_LIB"):     # A/B against a library variant (tools/build_variant.sh)
+if os.environ.get("OMNI_TUNE_LIB", ""):     # A/B against a library variant (tools/build_variant.sh)
     _lib.LIB_PATH = os.path.abspath(os.environ["OMNI_TUNE_LIB"])
 from omniserve_amd.backend import _gemm_common, fused_ext, qgemm_w4a8_per_chn, qgemm_w4a8_per_group, qgemm_w8a8  # noqa: E402
 
 _lib.USE_EXT = False      # plan overrides change scratch sizes per shape: stay on the ctypes mirror, which this tool re-sizes
 dev = torch.device("cuda:0")
 lib = _lib.lib()
-quick = "--quick" in sys.argv or "--big" in sys.argv
+quick = "--quick" in sys.argv or "--big" in sys.argv or "--one" in sys.argv
 SHAPES = {
     "8b": [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)],
     "70b_tp8": [(1280, 8192), (8192, 1024), (7168, 8192), (8192, 3584)],
@@ -107,6 +107,12 @@ def run(model, M, N, K, mode):
 
 
 if __name__ == "__main__":
+    if "--one" in sys.argv:
+        quick = True
+        run("8b", 128, 28672, 4096, "chn")
+        run("8b", 64, 28672, 4096, "chn")
+        run("70b_tp1", 128, 8192, 28672, "chn")
+        sys.exit(0)
     if "--big" in sys.argv:      # the shapes the mid-M kernel is for (one line per plan: legacy, mid-M at its own K split)
         quick = True
         for model, N, K in (("8b", 28672, 4096), ("8b", 4096, 14336), ("70b_tp8", 7168, 8192), ("70b_tp1", 57344, 8192),
