@@ -132,8 +132,9 @@ template <int V> struct IntTag { static constexpr int value = V; };
 
 #ifdef OMNI_DEBUG_CLOCKS
 // timeline probe (tools/midm_timeline.py): per wave of workgroups 0 and gridDim.x - 1, shader-clock stamps
-//   [0] entry, [1] prologue requests issued, then per chunk c < 24: [4 + 4c] before the DMA wait, [+1] behind it, [+2] behind the
-//   barrier, [+3] behind the chunk's last MFMA issue; [100] K loop done, [101] partials exchanged, [102] stores issued
+//   [0] entry, [1] prologue requests issued, then per chunk c < 24: [4 + 4c] top, [+1] behind the first half's MFMA issue,
+//   [+2] behind the DMA wait and the barrier, [+3] behind the second half; [100] K loop done, [101] partials exchanged,
+//   [102] stores issued
 static __device__ unsigned long long omni_dbg_midm[2 * 8 * 104];
 
 #define MIDM_STAMP(i)                                                                                              \
@@ -157,9 +158,8 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
   // ring depth: what fits 160 KiB next to the epilogue operands.  128 rows: 3 x (32 KiB tile + 8 x 2 KiB of weights) =
   // 144 KiB (W8A8 rows are twice the bytes: 2 slots); 64 rows: 4 x (16 + 16) = 128 KiB.  D = chunks in flight behind the one
   // being multiplied; vmcnt counts at most 63 operations: (NBUF - 1) x OPS <= 32.
-  constexpr int NBUF = MB == 8 ? (MODE == MODE_W8 ? 2 : 3) : (MODE == MODE_W8 ? 3 : 4);
-  constexpr int D = NBUF - 1;
-  static_assert(D * OPS < 64, "vmcnt is a 6-bit counter");
+  constexpr int NBUF = (MB == 8 && MODE == MODE_W8) ? 2 : 3;
+  static_assert(NBUF * OPS < 64, "vmcnt is a 6-bit counter");
   constexpr int HB = MB / 2, QB = MB / 4;
   constexpr int ABUF = MT * CH;                            // one activation buffer
   constexpr int WSLOT = WL * 1024 + (GP ? 512 : 0);        // one ring slot of one wave
@@ -264,116 +264,39 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) acc[mb][ab] = (v4i){0, 0, 0, 0};
 
-  // ---- prologue: the first D chunks are requested; epilogue operands -> LDS (published by the first chunk's barrier) ----
-#pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (d < nchunks) issue(d, d);
-  MIDM_STAMP(1);
-  if constexpr (!TO_SLAB) {
-    if (tid < 64 * NG) {
-      const int n = blockIdx.x * 64 * NG + tid;
-      const uint32_t sw = __builtin_bit_cast(uint16_t, p.wscales[n]);
-      uint32_t sz = 0;
-      if constexpr (MODE == MODE_CHN) sz = __builtin_bit_cast(uint16_t, p.wsz[n]);
-      epi_w[tid] = sw | (sz << 16);
-    } else if (tid - 64 * NG < MT) {
-      const int i = tid - 64 * NG;
-      const int m = (m0 + i) < p.M ? (m0 + i) : (p.M - 1);
-      const uint32_t sa = __builtin_bit_cast(uint16_t, p.ascales[m]);
-      uint32_t as = 0;
-      if constexpr (MODE == MODE_CHN) as = __builtin_bit_cast(uint16_t, p.asum[m]);
-      epi_a[i] = sa | (as << 16);
-    }
-  }
-
-  // Software pipeline across the barrier: the MFMAs of a chunk's last DEF row blocks run at the HEAD of the next chunk, behind
-  // its barrier and its first LDS reads -- there the weight reads, the lane transposition and the first masks are in flight
-  // and no MFMA of the new chunk can issue yet (both waves of the SIMD: the matrix pipe idled ~300 cycles per chunk).  Their
-  // operands stay in registers: the A operands `wa` are rewritten only by the operand stages behind them, `bfl` keeps the B
-  // operands.  Zero operands in front of the first chunk: those MFMAs add nothing.
-  constexpr int DEF = MB == 8 ? 2 : 1;
-  v4i wa[4], bfl[DEF];
-#pragma unroll
-  for (int ab = 0; ab < 4; ++ab) wa[ab] = (v4i){0, 0, 0, 0};
-#pragma unroll
-  for (int j = 0; j < DEF; ++j) bfl[j] = (v4i){0, 0, 0, 0};
-  auto deferred_rows = [&]() {
-#pragma unroll
-    for (int j = 0; j < DEF; ++j)
-#pragma unroll
-      for (int ab = 0; ab < ((OMNI_MIDM_ABLATE & 16) ? 1 : 4); ++ab)
-        acc[MB - DEF + j][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bfl[j], acc[MB - DEF + j][ab], 0, 0, 0);
-  };
-
-  // ---- one chunk: this wave's k-step of it, out of buffer / slot B (static).  STEADY: chunk c + D exists ----------------
-  auto body = [&](int c, auto buf_tag, auto steady_tag) {
-    constexpr int B = decltype(buf_tag)::value;
-    constexpr bool STEADY = decltype(steady_tag)::value;
-    // my pieces of chunk c have landed: behind them the requests of the chunks c + 1 .. min(c + D - 1, last)
-    if (c < 24) MIDM_STAMP(4 + 4 * c);
-    if constexpr (STEADY) {
-      vm_wait<(D - 1) * OPS>();
-    } else {
-      const int after = nchunks - 1 - c < D - 1 ? nchunks - 1 - c : D - 1;
-      if (after <= 0) vm_wait<0>();
-      else if (after == 1) vm_wait<1 * OPS>();
-      else vm_wait<(D > 2 ? 2 : 1) * OPS>();
-      static_assert(D <= 3, "tail waits are enumerated");
-    }
-    if (c < 24) MIDM_STAMP(5 + 4 * c);
-    if (!(OMNI_MIDM_ABLATE & 8)) __syncthreads();          // chunk c is visible in buffer B; everybody is done reading buffer (B + D) % NBUF (chunk c - 1)
-    if (c < 24) MIDM_STAMP(6 + 4 * c);
-    const bool more = (OMNI_MIDM_ABLATE & 1) ? false : (STEADY || c + D < nchunks);      // chunk c + D is requested during this chunk
-    const uint8_t* abuf = smem + B * ABUF;
-    const uint8_t* wsl = smem + wring + B * WSLOT + wrd;
-    // The chunk runs as STAGES fenced against each other (sched_barrier): a few MFMAs, the LDS reads the stage after next
-    // needs, and ONE request of chunk c + D.  Issued in a burst behind the barrier, the 48 requests of a workgroup queue up in
-    // the CU's address unit (16 clocks each) while every wave waits to get its next one accepted and the matrix pipe idles:
-    // chunks took 2450 cycles against 1024 of MFMA per SIMD (tools/midm_timeline.py, profiles/r05_a).  The first PRE row
-    // blocks go operand by operand (ab outer), so that the MFMAs of operand ab cover the unpack of operand ab + 1.
-    constexpr int PRE = MB < 3 ? MB : 3;
-    constexpr int NSTAGE = 1 + 4 + (MB - PRE - DEF);          // the deferred rows, 4 operand stages, one per further row block
-    // The two waves of a SIMD (group 0, phase s: the older one; group 1, phase s) share its matrix pipe, and at equal priority
-    // the older wave wins every arbitration: it ran its chunk in ~1050 cycles and then sat at the barrier for ~900 while the
-    // younger one finished alone, an in-order wave whose non-MFMA instructions nobody covers (tools/midm_timeline.py).  With
-    // the favoured wave alternating stage by stage (OMNI_MIDM_PRIO=1) both waves take ~1550 cycles and nobody waits -- and
-    // the chunk takes the same 2050 cycles (profiles/r05_a: same-box A/B of 15 shapes, +-3 % either way): off.
-    auto stage_prio = [&](auto st_tag) {
-#if OMNI_MIDM_PRIO
-      constexpr int st = decltype(st_tag)::value;
-      if (g == (st & 1)) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(0);
-#endif
-    };
-    // request k goes out in stage k * NSTAGE / OPS (spread evenly; several per stage where there are more requests than stages)
-    auto stage_requests = [&](auto st_tag) {
-      constexpr int st = decltype(st_tag)::value;
-      if (more) {
-        if constexpr (0 * NSTAGE / OPS == st && 0 < OPS) issue_piece(IntTag<0>{}, c + D, (B + D) % NBUF);
-        if constexpr (1 * NSTAGE / OPS == st && 1 < OPS) issue_piece(IntTag<1>{}, c + D, (B + D) % NBUF);
-        if constexpr (2 * NSTAGE / OPS == st && 2 < OPS) issue_piece(IntTag<2>{}, c + D, (B + D) % NBUF);
-        if constexpr (3 * NSTAGE / OPS == st && 3 < OPS) issue_piece(IntTag<3>{}, c + D, (B + D) % NBUF);
-        if constexpr (4 * NSTAGE / OPS == st && 4 < OPS) issue_piece(IntTag<4>{}, c + D, (B + D) % NBUF);
-        if constexpr (5 * NSTAGE / OPS == st && 5 < OPS) issue_piece(IntTag<5>{}, c + D, (B + D) % NBUF);
-        if constexpr (6 * NSTAGE / OPS == st && 6 < OPS) issue_piece(IntTag<6>{}, c + D, (B + D) % NBUF);
-        if constexpr (7 * NSTAGE / OPS == st && 7 < OPS) issue_piece(IntTag<7>{}, c + D, (B + D) % NBUF);
-      }
-    };
-    v4i bf[MB];
-    uint32_t d[2][4];
-    uint32_t sc4 = 0, zr4 = 0;
-    uint4 wraw[MODE == MODE_W8 ? 4 : 2];
+  // ---- K loop, software-pipelined around a MID-CHUNK barrier ---------------------------------------------------
+  // An in-order wave cannot multiply while it waits for its own LDS reads, lane transposition and masks, and the two
+  // waves of a SIMD pass every barrier together: with the barrier at the TOP of a chunk both did that preparation with the
+  // matrix pipe idle (chunks of 2050 cycles against 1024 of MFMA per SIMD; timing ablations: without any memory request
+  // 20.8 us, with a quarter of the MFMAs 19.5 us, against 22.1 -- a latency chain, not a resource; profiles/r05_a §2).
+  // So the barrier that publishes chunk c + 1 sits in the MIDDLE of chunk c's MFMAs:
+  //   P0 (rows 0 .. HALF - 1 of chunk c, row by row): all remaining B operands of chunk c are read (nothing of chunk c is
+  //       read behind the barrier: its buffer is recycled there) and the weight-side requests of chunk c + NBUF go out;
+  //   wait for this wave's pieces of chunk c + 1, barrier;
+  //   P1 (rows HALF .. MB - 1, operand by operand): the reads of chunk c + 1's packed weights and first B rows are issued,
+  //       and while the MFMAs of operands 0, 1 run the data arrives; operand ab of chunk c + 1 is unpacked into wa[ab] right
+  //       behind the last MFMA that reads the old wa[ab]; the activation requests of chunk c + NBUF go out (buffer c % NBUF
+  //       is free behind the barrier).
+  // Every request is issued NBUF chunks ahead and has two chunks (NBUF = 3) to land.
+  constexpr int HALF = MB / 2, PF = 2;
+  static_assert(HALF >= PF, "two prefetched B rows");
+  constexpr int WP = WL + GP;                                   // weight-side requests per chunk
+  constexpr int VM_STEADY = (NBUF - 2) * OPS + WP;              // requests issued behind chunk c + 1's by the middle of chunk c
+  v4i wa[4], bf[MB];
+  uint32_t d[2][4];
+  uint32_t sc4 = 0, zr4 = 0;
+  uint4 wraw[MODE == MODE_W8 ? 4 : 2];
+  auto read_weights = [&](int b) {       // this wave's packed k-step out of ring slot b (+ its second-level parameters)
+    const uint8_t* wsl = smem + wring + b * WSLOT + wrd;
 #pragma unroll
     for (int j = 0; j < (MODE == MODE_W8 ? 4 : 2); ++j) wraw[j] = *reinterpret_cast<const uint4*>(wsl + j * (MODE == MODE_W8 ? 1024 : 512));
     if constexpr (MODE == MODE_GRP) {
-      sc4 = *reinterpret_cast<const uint32_t*>(smem + wring + B * WSLOT + WL * 1024 + lane * 4);
-      zr4 = *reinterpret_cast<const uint32_t*>(smem + wring + B * WSLOT + WL * 1024 + 256 + lane * 4);
+      sc4 = *reinterpret_cast<const uint32_t*>(smem + wring + b * WSLOT + WL * 1024 + lane * 4);
+      zr4 = *reinterpret_cast<const uint32_t*>(smem + wring + b * WSLOT + WL * 1024 + 256 + lane * 4);
     }
-#pragma unroll
-    for (int mb = 0; mb < PRE; ++mb) bf[mb] = *reinterpret_cast<const v4i*>(abuf + boff + ((OMNI_MIDM_ABLATE & 2) ? 0 : mb) * 16 * 256);
-    stage_prio(IntTag<0>{});
-    deferred_rows();          // (chunk c - 1's last row blocks: stage 0)
-    stage_requests(IntTag<0>{});
+  };
+  auto read_b = [&](int b, int mb) -> v4i { return *reinterpret_cast<const v4i*>(smem + b * ABUF + boff + mb * 16 * 256); };
+  auto transpose = [&]() {
     if constexpr (MODE != MODE_W8) {
       // dwords of a 16-B piece: x = (k5 = 0, n2 = 0) y = (0, 1) z = (1, 0) w = (1, 1); d[n2][(tile parity, k5)]
       const uint32_t dd[2][4] = {{wraw[0].x, wraw[0].z, wraw[1].x, wraw[1].z}, {wraw[0].y, wraw[0].w, wraw[1].y, wraw[1].w}};
@@ -388,83 +311,159 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
         d[b][0] = (uint32_t)s01[0]; d[b][1] = (uint32_t)s01[1]; d[b][2] = (uint32_t)s23[0]; d[b][3] = (uint32_t)s23[1];
       }
     }
-    auto operand = [&](auto ab_tag) {      // MFMA A operand ab = a * 2 + b of this k-step
-      constexpr int ab = decltype(ab_tag)::value;
-      if constexpr (MODE == MODE_W8) {
-        wa[ab] = (v4i){(int)wraw[ab].x, (int)wraw[ab].y, (int)wraw[ab].z, (int)wraw[ab].w};
-      } else {
-        constexpr int a = ab >> 1, b = ab & 1;
-        uint32_t u[4];
+  };
+  auto operand = [&](auto ab_tag) {      // MFMA A operand ab = a * 2 + b of the k-step in `d` / `wraw`
+    constexpr int ab = decltype(ab_tag)::value;
+    if constexpr (MODE == MODE_W8) {
+      wa[ab] = (v4i){(int)wraw[ab].x, (int)wraw[ab].y, (int)wraw[ab].z, (int)wraw[ab].w};
+    } else {
+      constexpr int a = ab >> 1, b = ab & 1;
+      uint32_t u[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) u[q] = (OMNI_MIDM_ABLATE & 4) ? d[b][q] : ((d[b][q] >> (4 * a)) & 0x0F0F0F0Fu);
-        if constexpr (MODE == MODE_GRP) {
-          const uint32_t sc = (sc4 >> (8 * ab)) & 0xFFu;
+      for (int q = 0; q < 4; ++q) u[q] = (OMNI_MIDM_ABLATE & 4) ? d[b][q] : ((d[b][q] >> (4 * a)) & 0x0F0F0F0Fu);
+      if constexpr (MODE == MODE_GRP) {
+        const uint32_t sc = (sc4 >> (8 * ab)) & 0xFFu;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) u[q] = u[q] * sc;
-          vadd4_zbyte_x4(u, zr4, ab);
-        }
-        wa[ab] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
+        for (int q = 0; q < 4; ++q) u[q] = u[q] * sc;
+        vadd4_zbyte_x4(u, zr4, ab);
       }
-    };
-    auto operand_stage = [&](auto ab_tag) {
-      constexpr int ab = decltype(ab_tag)::value;
-      stage_prio(IntTag<1 + ab>{});
-      operand(ab_tag);
+      wa[ab] = (v4i){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
+    }
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------------------------
+  // Chunk 0 of every wave first, a barrier, then the other NBUF - 1 chunks: the address unit serves the oldest wave first, and
+  // with all of a wave's prologue requests in one run the last waves' chunk-0 pieces queued behind 2 x 48 KiB of the first
+  // waves' later chunks.  The epilogue operands are plain loads right behind chunk 0's requests (in-order returns: waiting
+  // for chunk 0 waits for them too, and nothing else); they stay in two registers until the K loop is over -- a use any
+  // earlier would be waited for with vmcnt(0), i.e. behind every request in flight (the compiler does not see the asm's).
+  if (nchunks > 0) issue(0, 0);
+  uint32_t epi_lo = 0, epi_hi = 0;
+  if constexpr (!TO_SLAB) {
+    if (tid < 64 * NG) {
+      const int n = blockIdx.x * 64 * NG + tid;
+      epi_lo = __builtin_bit_cast(uint16_t, p.wscales[n]);
+      if constexpr (MODE == MODE_CHN) epi_hi = __builtin_bit_cast(uint16_t, p.wsz[n]);
+    } else if (tid - 64 * NG < MT) {
+      const int i = tid - 64 * NG;
+      const int m = (m0 + i) < p.M ? (m0 + i) : (p.M - 1);
+      epi_lo = __builtin_bit_cast(uint16_t, p.ascales[m]);
+      if constexpr (MODE == MODE_CHN) epi_hi = __builtin_bit_cast(uint16_t, p.asum[m]);
+    }
+  }
+  __syncthreads();
 #pragma unroll
-      for (int mb = 0; mb < PRE; ++mb)
-        if (!(OMNI_MIDM_ABLATE & 16) || ab == 0) acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf[mb], acc[mb][ab], 0, 0, 0);
-      // B operands of the row-block stages: two stages ahead of their MFMAs
-      if constexpr (ab >= 2 && PRE + ab - 2 < MB)
-        bf[PRE + ab - 2] = (OMNI_MIDM_ABLATE & 2) ? bf[0] : *reinterpret_cast<const v4i*>(abuf + boff + (PRE + ab - 2) * 16 * 256);
-      stage_requests(IntTag<1 + ab>{});
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    __builtin_amdgcn_sched_barrier(0);
-    operand_stage(IntTag<0>{});
-    operand_stage(IntTag<1>{});
-    operand_stage(IntTag<2>{});
-    operand_stage(IntTag<3>{});
-    auto row_stage = [&](auto mb_tag) {
-      constexpr int mb = decltype(mb_tag)::value;
-      if constexpr (mb < MB - DEF) {
-        stage_prio(IntTag<5 + mb - PRE>{});
+  for (int c0 = 1; c0 < NBUF; ++c0)
+    if (c0 < nchunks) issue(c0, c0);
+  MIDM_STAMP(1);
+  // chunk 0: its pieces (behind them the other prologue chunks'), the barrier, its operands
+  if (nchunks >= NBUF) vm_wait<(NBUF - 1) * OPS>();
+  else vm_wait<0>();
+  __syncthreads();
+  read_weights(0);
 #pragma unroll
-        for (int ab = 0; ab < ((OMNI_MIDM_ABLATE & 16) ? 1 : 4); ++ab) acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf[mb], acc[mb][ab], 0, 0, 0);
-        if constexpr (mb + 2 < MB) bf[mb + 2] = (OMNI_MIDM_ABLATE & 2) ? bf[0] : *reinterpret_cast<const v4i*>(abuf + boff + (mb + 2) * 16 * 256);
-        stage_requests(IntTag<5 + mb - PRE>{});
+  for (int mb = 0; mb < PF; ++mb) bf[mb] = read_b(0, mb);
+  transpose();
+  operand(IntTag<0>{}); operand(IntTag<1>{}); operand(IntTag<2>{}); operand(IntTag<3>{});
+
+  // ---- one chunk out of buffer / slot B (static).  STEADY: the chunks c + 1 and c + NBUF exist ---------------------------
+  auto body = [&](int c, auto buf_tag, auto steady_tag) {
+    constexpr int B = decltype(buf_tag)::value;
+    constexpr int BN = (B + 1) % NBUF;                       // buffer / slot of chunk c + 1
+    constexpr bool STEADY = decltype(steady_tag)::value;
+    const bool has_next = STEADY || c + 1 < nchunks;
+    const bool req = (OMNI_MIDM_ABLATE & 1) ? false : (STEADY || c + NBUF < nchunks);
+    if (c < 24) MIDM_STAMP(4 + 4 * c);
+    // ---- P0: rows 0 .. HALF - 1, row by row; the rest of chunk c's B operands; weight-side requests of chunk c + NBUF ----
+    auto p0_stage = [&](auto i_tag) {
+      constexpr int i = decltype(i_tag)::value;
+      if constexpr (i < HALF) {
+#pragma unroll
+        for (int ab = 0; ab < ((OMNI_MIDM_ABLATE & 16) ? 1 : 4); ++ab)
+          acc[i][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf[i], acc[i][ab], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);      // (reads hoisted above the first MFMA of a loop round would be waited for at once)
+        if constexpr (PF + i < HALF) bf[PF + i] = (OMNI_MIDM_ABLATE & 2) ? bf[0] : read_b(B, PF + i);
+        bf[HALF + i] = (OMNI_MIDM_ABLATE & 2) ? bf[0] : read_b(B, HALF + i);
+        if (req) {      // weight-side request k (k = NI .. OPS - 1) goes out in stage (k - NI) * HALF / WP
+          if constexpr ((0 * HALF) / WP == i && 0 < WP) issue_piece(IntTag<NI + 0>{}, c + NBUF, B);
+          if constexpr ((1 * HALF) / WP == i && 1 < WP) issue_piece(IntTag<NI + 1>{}, c + NBUF, B);
+          if constexpr ((2 * HALF) / WP == i && 2 < WP) issue_piece(IntTag<NI + 2>{}, c + NBUF, B);
+          if constexpr ((3 * HALF) / WP == i && 3 < WP) issue_piece(IntTag<NI + 3>{}, c + NBUF, B);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    row_stage(IntTag<PRE>{});
-    row_stage(IntTag<PRE + 1>{});
-    row_stage(IntTag<PRE + 2>{});
-    row_stage(IntTag<PRE + 3>{});
-    row_stage(IntTag<PRE + 4>{});
-    static_assert(MB - PRE <= 5, "row-block stages are enumerated");
+    p0_stage(IntTag<0>{}); p0_stage(IntTag<1>{}); p0_stage(IntTag<2>{}); p0_stage(IntTag<3>{});
+    static_assert(HALF <= 4 && WP <= 4, "stages / requests are enumerated");
+    if (c < 24) MIDM_STAMP(5 + 4 * c);
+    // ---- my pieces of chunk c + 1 have landed; barrier: chunk c + 1 is visible, nobody reads chunk c's buffer any more ----
+    if (has_next) {
+      // requests issued behind chunk c + 1's: all of chunk c + 2 .. c + NBUF - 1, the weight side of chunk c + NBUF
+      if (STEADY || c + NBUF < nchunks) vm_wait<VM_STEADY>();
+      else if (NBUF == 3 && c + 2 < nchunks) vm_wait<(NBUF - 2) * OPS>();
+      else vm_wait<0>();
+      if (!(OMNI_MIDM_ABLATE & 8)) __syncthreads();
+    }
+    if (c < 24) MIDM_STAMP(6 + 4 * c);
+    // ---- P1: rows HALF .. MB - 1, operand by operand; chunk c + 1's operands; activation requests of chunk c + NBUF ----
+    v4i nbf[PF];
+    if (has_next) {
+      read_weights(BN);
 #pragma unroll
-    for (int j = 0; j < DEF; ++j) bfl[j] = bf[MB - DEF + j];      // (read two stages ahead like every other row block)
-#ifdef OMNI_DEBUG_CLOCKS
+      for (int mb = 0; mb < PF; ++mb) nbf[mb] = read_b(BN, mb);
+    }
+    auto p1_mfma = [&](auto ab_tag) {
+      constexpr int ab = decltype(ab_tag)::value;
+      if (!(OMNI_MIDM_ABLATE & 16) || ab == 0) {
+#pragma unroll
+        for (int mb = HALF; mb < MB; ++mb) acc[mb][ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf[mb], acc[mb][ab], 0, 0, 0);
+      }
+    };
+    auto p1_requests = [&](auto st_tag) {      // activation request k (k < NI) goes out in stage k * 4 / NI
+      constexpr int st = decltype(st_tag)::value;
+      if (req) {
+        if constexpr ((0 * 4) / NI == st && 0 < NI) issue_piece(IntTag<0>{}, c + NBUF, B);
+        if constexpr ((1 * 4) / NI == st && 1 < NI) issue_piece(IntTag<1>{}, c + NBUF, B);
+        if constexpr ((2 * 4) / NI == st && 2 < NI) issue_piece(IntTag<2>{}, c + NBUF, B);
+        if constexpr ((3 * 4) / NI == st && 3 < NI) issue_piece(IntTag<3>{}, c + NBUF, B);
+      }
+    };
+    static_assert(NI <= 4, "activation requests are enumerated");
+    __builtin_amdgcn_sched_barrier(0);
+    p1_mfma(IntTag<0>{}); p1_requests(IntTag<0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    p1_mfma(IntTag<1>{}); p1_requests(IntTag<1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) transpose();                 // (the packed weights of chunk c + 1 have had two MFMA groups to arrive)
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) operand(IntTag<0>{});        // wa[0], wa[1] are free: their last MFMAs of chunk c are issued
+    p1_mfma(IntTag<2>{}); p1_requests(IntTag<2>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) operand(IntTag<1>{});
+    p1_mfma(IntTag<3>{}); p1_requests(IntTag<3>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) {
+      operand(IntTag<2>{}); operand(IntTag<3>{});
+#pragma unroll
+      for (int mb = 0; mb < PF; ++mb) bf[mb] = nbf[mb];
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (c < 24) MIDM_STAMP(7 + 4 * c);
-#endif
   };
   {
     int c = 0;
-    for (; c + (NBUF - 1) + D < nchunks; c += NBUF) {      // whole ring rounds whose every chunk has a chunk c + D behind it
+    for (; c + (NBUF - 1) + NBUF < nchunks; c += NBUF) {      // whole ring rounds whose every chunk has a chunk c + NBUF behind it
       body(c, IntTag<0>{}, BoolTag<true>{});
       body(c + 1, IntTag<1 % NBUF>{}, BoolTag<true>{});
       if constexpr (NBUF > 2) body(c + 2, IntTag<2 % NBUF>{}, BoolTag<true>{});
-      if constexpr (NBUF > 3) body(c + 3, IntTag<3 % NBUF>{}, BoolTag<true>{});
-      static_assert(NBUF >= 2 && NBUF <= 4, "ring rounds are unrolled by hand");
+      static_assert(NBUF == 2 || NBUF == 3, "ring rounds are unrolled by hand");
     }
-    for (; c < nchunks; c += NBUF) {                        // the last chunks: conditions on workgroup-uniform values
+    for (; c < nchunks; c += NBUF) {                          // the last chunks: conditions on workgroup-uniform values
       body(c, IntTag<0>{}, BoolTag<false>{});
       if (c + 1 < nchunks) body(c + 1, IntTag<1 % NBUF>{}, BoolTag<false>{});
       if (NBUF > 2 && c + 2 < nchunks) body(c + 2, IntTag<2 % NBUF>{}, BoolTag<false>{});
-      if (NBUF > 3 && c + 3 < nchunks) body(c + 3, IntTag<3 % NBUF>{}, BoolTag<false>{});
     }
   }
-  deferred_rows();            // the last chunk's
   __builtin_amdgcn_sched_barrier(0);
   MIDM_STAMP(100);
 
@@ -472,6 +471,11 @@ __global__ __launch_bounds__(512, 2) void w4a8_midm_kernel(GemmArgs p) {
   // round 1: phases {0,1} keep the low half of the row blocks and park the high half, phases {2,3} the other way round;
   //          partner = phase ^ 2.  round 2: inside {0,1} and {2,3} the same with quarters; partner = phase ^ 1.
   // Afterwards wave (g, s) holds the finished accumulators of row blocks s * QB .. s * QB + QB - 1.
+  asm volatile("" : "+v"(epi_lo), "+v"(epi_hi));      // (first use of the two loads: here, not in the prologue)
+  if constexpr (!TO_SLAB) {   // epilogue operands -> LDS (their region is outside the buffers; published by the barriers below)
+    if (tid < 64 * NG) epi_w[tid] = epi_lo | (epi_hi << 16);
+    else if (tid - 64 * NG < MT) epi_a[tid - 64 * NG] = epi_lo | (epi_hi << 16);
+  }
   __syncthreads();            // the activation buffers are free
   v4i* const red = reinterpret_cast<v4i*>(smem);
   {
