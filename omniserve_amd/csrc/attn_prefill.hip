@@ -48,9 +48,6 @@ constexpr int PVROW = 256;            // bytes per key row of the V tile (swizzl
 constexpr int PKTILE = PKT * PKROW, PVTILE = PKT * PVROW;
 typedef __fp16 pv4hp __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-template <int V>
-struct IntTag { static constexpr int value = V; };
-
 __device__ __forceinline__ int xor_nohoist(int a, int uniform_b) {
   int r;
   asm volatile("v_xor_b32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(uniform_b));

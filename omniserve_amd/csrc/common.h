@@ -6,6 +6,8 @@
 
 namespace omni {
 
+template <int V> struct IntTag { static constexpr int value = V; };      // static index handed to a generic lambda
+
 typedef _Float16 half_t;
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));

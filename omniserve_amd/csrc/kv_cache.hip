@@ -368,9 +368,26 @@ constexpr int FVTILE = 32 * FVROW;
 // group), and the LAST arriver merges the splits (row_kernels.h: SrcAttnMerge, the merge kernels' own arithmetic), stores
 // the fp16 output and raises its row maxima: the attention is ONE launch (it also carries the armed L2 prefetch on extra
 // z slices of its grid, as the merge kernel did).
+#ifdef OMNI_DEBUG_CLOCKS
+// timeline probe (tools/flash_timeline.py): shader-clock stamps of every wave of three workgroups -- the first, the middle
+// and the last of the grid in dispatch order: [0] entry, [1] page window visible, [2] q in LDS (first batch requested),
+// [3 + i] tile i of the wave done (i < 24), [28] sweep done, [29] combined / stored, [30] exit
+static __device__ unsigned long long omni_dbg_flash[3 * DEC_WAVES * 32];
+#define FLASH_STAMP(i)                                                                                              \
+  do {                                                                                                              \
+    if (fdbg >= 0 && (threadIdx.x & 63) == 0) omni_dbg_flash[(fdbg * DEC_WAVES + (threadIdx.x >> 6)) * 32 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define FLASH_STAMP(i) do {} while (0)
+#endif
 template <int G, bool DIRECT, bool FG = false, bool KV8 = false, bool LASTM = false>
 __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode_flash_kernel(DecodeArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifdef OMNI_DEBUG_CLOCKS
+  const unsigned flin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), fall = gridDim.x * gridDim.y * gridDim.z;
+  const int fdbg = flin == 0 ? 0 : (flin == fall / 2 ? 1 : (flin == fall - 1 ? 2 : -1));
+  FLASH_STAMP(0);
+#endif
   // One batch of scalar loads for the kernel arguments of trip 1 (and the rider test): hipcc otherwise requests them where
   // they are first used -- three dependent kernarg round trips (rider test, geometry, pointers) in front of the first vector
   // load of a kernel that is a chain of memory round trips (ISA of round 4, profiles/r04_e).
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   float* mlbuf = xbuf + DEC_WAVES * G * DH;                   // [4 waves][G][2]  (max, sum) of each wave
   uint8_t* vtile = reinterpret_cast<uint8_t*>(mlbuf + DEC_WAVES * G * 2);   // [4 waves][32][FVROW]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x;
   const int group = p.num_heads / p.num_kv_heads;
   const int qg = group / G;
@@ -590,6 +607,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   }
   OMNI_CLK(17);
   __syncthreads();   // pages[] visible
+  FLASH_STAMP(1);
 
   const int vtok = lane >> 2, vpiece = lane & 3;          // coalesced V loads: 4 lanes per token
   const size_t vhead_off = (size_t)hrank * lay.tpb * RB + vpiece * 16 * NQ;
@@ -600,11 +618,71 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   // (fine-grained instantiations keep two tiles per batch: at batch 1 / 256 K tokens the launch has few workgroups and
   //  lives on loads in flight per wave -- 93 vs 98 us for the dense 4 + 4 head mix; sparse decode times the same)
   constexpr int FB = FG ? 2 : OMNI_FLASH_FB;
-  uint4 kraw[FB][2][NQ], vraw[FB][2][NQ];
-  half_t ksc[FB][2], kze[FB][2], vsc[FB][2], vze[FB][2];   // KV4 only
+  // two register sets: the batch being consumed and the batch in flight (static indices: the sweep is unrolled by two
+  // batches -- copying the arrived batch into a second set cost 24 v_mov per tile)
+  uint4 kraw[2][FB][2][NQ], vraw[2][FB][2][NQ];
+  half_t ksc[2][FB][2], kze[2][FB][2], vsc[2][FB][2], vze[2][FB][2];   // KV4 only
   // safe token of an out-of-range lane: the split's first token, or (empty split) slot 0 of window entry 0
   const int tsafe = nt > 0 ? t0 : ((FG && streaming) ? 0 : (page0 << lay.tpb_log2));
-  auto load_batch = [&](int i0) {   // branch-free; page pointers of the whole batch first, then every load
+  // Dense instantiations: a 16-token group never straddles a page (splits start at multiples of 16 tokens, pages hold a
+  // multiple of 16), so its page pointer, first slot and every base address are WAVE-UNIFORM: the page window sits in two
+  // VGPR pairs (lane i = window entry i, read with v_readlane), the bases are scalar arithmetic, and the loads take
+  // (scalar base, 32-bit lane offset).  The per-lane pointer arithmetic this replaces was 117 of the tile loop's 406 VALU
+  // instructions -- in a sweep that is VALU-issue bound (profiles/r05_b).  Lanes past the split's end re-read its last
+  // token (finite values; their scores are masked), a group wholly past it reads the safe token.
+  // Requests run TWO tiles ahead without a third register set: a tile's K registers are dead once its K operands are
+  // unpacked and its V registers once the V tile is in LDS, so the K / V requests of tile i + 2 go out right there, into the
+  // set tile i is leaving.  With one tile ahead a wave's period was the memory latency (2.2 us at this load; three waves per
+  // SIMD need 3 x 0.55 us of VALU per round): 73 us at 256 x 1 K tokens against 49 us for the same requests without the
+  // arithmetic (profiles/r05_b).
+  int64_t kwin = 0, vwin = 0;
+  if constexpr (!FG) {
+    kwin = pages[lane < 40 ? lane : 0];
+    vwin = pages[40 + (lane < 40 ? lane : 0)];
+  }
+  auto window_page = [&](int64_t win, int pidx) -> const uint8_t* {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)win, pidx);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)win >> 32), pidx);
+    return reinterpret_cast<const uint8_t*>(((uint64_t)hi << 32) | lo);
+  };
+  // dense: the K half / V half of one tile's requests (tile u of the batch that starts at tile index i0 of this wave)
+  auto load_dense = [&](auto set_tag, auto which_tag, int u, int i0) {
+    constexpr int S = decltype(set_tag)::value;
+    constexpr int WHICH = decltype(which_tag)::value;      // 0: K bytes + K scales / zeros, 1: V
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int g0 = (wave + DEC_WAVES * (i0 + u)) * 32 + h * 16;      // first token of the group inside the split
+      const bool live = g0 < nt;
+      const int vt_base = live ? t0 + g0 : tsafe;
+      const int lim = live ? min(15, nt - g0 - 1) : 0;                  // last lane token that exists
+      const int pidx = (vt_base >> lay.tpb_log2) - page0;
+      const size_t row0 = ((size_t)hrank * lay.tpb + (size_t)(vt_base & (lay.tpb - 1))) * RB;
+      const size_t tail0 = (size_t)tail_off + 2 * (size_t)(vt_base & (lay.tpb - 1));
+      const uint8_t* page = window_page(WHICH == 0 ? kwin : vwin, pidx);
+      const uint32_t tok = min((uint32_t)(WHICH == 0 ? l15 : vtok), (uint32_t)lim);
+      const uint32_t off = __umul24(tok, (uint32_t)RB) + (uint32_t)((WHICH == 0 ? l4 : vpiece) * 16 * NQ);
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) {
+        if constexpr (WHICH == 0) kraw[S][u][h][n] = gload<uint4>(page + row0 + off + 16 * n);
+        else vraw[S][u][h][n] = gload<uint4>(page + row0 + off + 16 * n);
+      }
+      if constexpr (!KV8) {
+        const half_t sc = gload<half_t>(page + tail0 + 2 * tok), ze = gload<half_t>(page + tail0 + zero_off + 2 * tok);
+        if constexpr (WHICH == 0) { ksc[S][u][h] = sc; kze[S][u][h] = ze; }
+        else { vsc[S][u][h] = sc; vze[S][u][h] = ze; }
+      }
+    }
+  };
+  auto load_batch = [&](auto set_tag, int i0) {   // branch-free; page pointers of the whole batch first, then every load
+    constexpr int S = decltype(set_tag)::value;
+    if constexpr (!FG) {
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        load_dense(set_tag, IntTag<0>{}, u, i0);
+        load_dense(set_tag, IntTag<1>{}, u, i0);
+      }
+      return;
+    }
     const uint8_t* kp[FB][2];
     const uint8_t* vp[FB][2];
     int ks_[FB][2], vs_[FB][2];
@@ -627,21 +705,21 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int n = 0; n < NQ; ++n)
-          kraw[u][h][n] = gload<uint4>(kp[u][h] + khead_off + (size_t)ks_[u][h] * RB + 16 * n);
+          kraw[S][u][h][n] = gload<uint4>(kp[u][h] + khead_off + (size_t)ks_[u][h] * RB + 16 * n);
 #pragma unroll
         for (int n = 0; n < NQ; ++n)
-          vraw[u][h][n] = gload<uint4>(vp[u][h] + vhead_off + (size_t)vs_[u][h] * RB + 16 * n);
+          vraw[S][u][h][n] = gload<uint4>(vp[u][h] + vhead_off + (size_t)vs_[u][h] * RB + 16 * n);
         if constexpr (!KV8) {
           const uint8_t* kt = kp[u][h] + tail_off + 2 * ks_[u][h];
-          ksc[u][h] = gload<half_t>(kt);
-          kze[u][h] = gload<half_t>(kt + zero_off);
+          ksc[S][u][h] = gload<half_t>(kt);
+          kze[S][u][h] = gload<half_t>(kt + zero_off);
           const uint8_t* vt_ = vp[u][h] + tail_off + 2 * vs_[u][h];
-          vsc[u][h] = gload<half_t>(vt_);
-          vze[u][h] = gload<half_t>(vt_ + zero_off);
+          vsc[S][u][h] = gload<half_t>(vt_);
+          vze[S][u][h] = gload<half_t>(vt_ + zero_off);
         }
       }
   };
-  load_batch(0);
+  load_batch(IntTag<0>{}, 0);
 
   // RoPE(q) (and k of the current token) into LDS while the cache bytes are in flight
 #pragma unroll
@@ -666,6 +744,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   __syncthreads();
 
   OMNI_CLK(18);
+  FLASH_STAMP(2);
   float scur[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) scur[g] = 0.0f;
@@ -692,37 +771,45 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   // pieces) of a ds_write_b128 group hit 8 different 4-bank groups.  PMC before: 40 % of the LDS cycles were conflicts.
   const int tr_off = (4 * l4 + (l15 >> 2)) * FVROW + (l15 & 3) * 8;
   const int my_tiles = ntiles > wave ? (ntiles - wave + DEC_WAVES - 1) / DEC_WAVES : 0;
-  for (int i0 = 0; i0 < my_tiles; i0 += FB) {
-    uint4 kr[FB][2][NQ], vr[FB][2][NQ];
-    half_t ks[FB][2], kz[FB][2], vs[FB][2], vz[FB][2];
-#pragma unroll
-    for (int u = 0; u < FB; ++u)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) { kr[u][h][n] = kraw[u][h][n]; vr[u][h][n] = vraw[u][h][n]; }
-        if constexpr (!KV8) {
-          ks[u][h] = ksc[u][h]; kz[u][h] = kze[u][h];
-          vs[u][h] = vsc[u][h]; vz[u][h] = vze[u][h];
-        }
-      }
-    if (i0 + FB < my_tiles) load_batch(i0 + FB);   // next batch in flight while this one is consumed
+  auto consume = [&](auto set_tag, int i0) {
+    constexpr int S = decltype(set_tag)::value;
 #pragma unroll
     for (int u = 0; u < FB; ++u) {
       const int tbase = (wave + DEC_WAVES * (i0 + u)) * 32;
-      if (tbase >= nt) continue;  // wave-uniform
+      const bool on = tbase < nt;   // wave-uniform: the tile exists.  Its arithmetic is conditional, the REQUESTS below are not:
+                                    // vmcnt counts in order, and the compiler sizes every wait for the path with the fewest
+                                    // requests behind the one it needs -- a conditional prefetch turns each counted wait into
+                                    // (nearly) vmcnt(0), i.e. a wait for the request just issued (ISA of round 5: vmcnt(5 .. 0)
+                                    // in front of the V unpack where 17 .. 12 are in flight).  A tile past the end re-reads the
+                                    // safe token: two wasted batches per wave.
+#ifdef OMNI_FLASH_ABLATE     // timing experiment (wrong results): the sweep's loads without its arithmetic -- what the launch
+      {                      // geometry (pages, workgroups, one batch in flight per wave) can stream at all
+        uint32_t acc_x = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          acc_x ^= kraw[S][u][h][0].x ^ kraw[S][u][h][0].y ^ kraw[S][u][h][0].z ^ kraw[S][u][h][0].w;
+          acc_x ^= vraw[S][u][h][0].x ^ vraw[S][u][h][0].y ^ vraw[S][u][h][0].z ^ vraw[S][u][h][0].w;
+          if constexpr (!KV8) acc_x ^= (uint32_t)__builtin_bit_cast(uint16_t, ksc[S][u][h]) ^ (uint32_t)__builtin_bit_cast(uint16_t, kze[S][u][h]) ^
+                                       (uint32_t)__builtin_bit_cast(uint16_t, vsc[S][u][h]) ^ (uint32_t)__builtin_bit_cast(uint16_t, vze[S][u][h]);
+        }
+        if (on) oacc[0][0] += (float)(acc_x & 1u);
+        if constexpr (!FG) { load_dense(set_tag, IntTag<0>{}, u, i0 + 2 * FB); load_dense(set_tag, IntTag<1>{}, u, i0 + 2 * FB); }
+        continue;
+      }
+#endif
       // ---- scores of 32 tokens: two 16-token groups ----
       float x[8];
       float tmax = -1e30f;
+      if (on) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         v2h kd[16];
         if constexpr (KV8) {
-          kv8_dequant16(kr[u][h][0], k_qo, kd);
-          kv8_dequant16(kr[u][h][NQ - 1], k_qo, kd + 8);
+          kv8_dequant16(kraw[S][u][h][0], k_qo, kd);
+          kv8_dequant16(kraw[S][u][h][NQ - 1], k_qo, kd + 8);
         } else {
-          const half_t ch = (half_t)(-(float)ks[u][h] * (float)kz[u][h]);
-          kv4_dequant16(kr[u][h][0], (v2h){ks[u][h], ks[u][h]}, (v2h){ch, ch}, kd);
+          const half_t ch = (half_t)(-(float)ksc[S][u][h] * (float)kze[S][u][h]);
+          kv4_dequant16(kraw[S][u][h][0], (v2h){ksc[S][u][h], ksc[S][u][h]}, (v2h){ch, ch}, kd);
         }
         v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -735,6 +822,10 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
         for (int r = 0; r < 4; ++r)     // acc[r] = q[head l15] . K[token tbase + 16h + 4*l4 + r]; scores in the exp2 domain
           x[4 * h + r] = acc[r] * sm_scale2;
       }
+      }
+      if constexpr (!FG) load_dense(set_tag, IntTag<0>{}, u, i0 + 2 * FB);      // this tile's K registers are free: tile + 2's K
+      v8h pb;   // k-slots of the P.V step: tokens 4*l4+r of group 0, then of group 1 (as the V^T operand below)
+      if (on) {
       if (tbase + 32 > nt) {   // wave-uniform: only the last tile of a split has token slots to mask (118 -> ~50 softmax VALU per
 #pragma unroll                 //  full tile: the sweep is VALU-issue bound at every batch size, profiles/r03_h)
         for (int e = 0; e < 8; ++e) {
@@ -748,7 +839,6 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       const float m_new = __builtin_fmaxf(m_run, tmax);      // (a tile holds >= 1 real token: m_new is a real score)
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.0f;
-      v8h pb;   // k-slots of the P.V step: tokens 4*l4+r of group 0, then of group 1 (as the V^T operand below)
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
         // masked slots: exp2(-1e30 - m_new) = 0.  The row sum takes the unrounded exponentials (as upstream sums them);
@@ -770,11 +860,11 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       for (int h = 0; h < 2; ++h) {
         v2h vd[16];
         if constexpr (KV8) {
-          kv8_dequant16(vr[u][h][0], v_qo, vd);
-          kv8_dequant16(vr[u][h][NQ - 1], v_qo, vd + 8);
+          kv8_dequant16(vraw[S][u][h][0], v_qo, vd);
+          kv8_dequant16(vraw[S][u][h][NQ - 1], v_qo, vd + 8);
         } else {
-          const half_t ch = (half_t)(-(float)vs[u][h] * (float)vz[u][h]);
-          kv4_dequant16(vr[u][h][0], (v2h){vs[u][h], vs[u][h]}, (v2h){ch, ch}, vd);
+          const half_t ch = (half_t)(-(float)vsc[S][u][h] * (float)vze[S][u][h]);
+          kv4_dequant16(vraw[S][u][h][0], (v2h){vsc[S][u][h], vsc[S][u][h]}, (v2h){ch, ch}, vd);
         }
         uint8_t* dst = vt + (h * 16 + vtok) * FVROW + vpiece * 64;   // 32 values in dequant order
         const int wsw = vpiece >> 1;
@@ -785,6 +875,9 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
           *reinterpret_cast<v8h*>(dst + (w ^ wsw) * 16) = t;
         }
       }
+      }
+      if constexpr (!FG) load_dense(set_tag, IntTag<1>{}, u, i0 + 2 * FB);      // ... and its V registers
+      if (on) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const uint8_t* src = vt + (c < 4 ? tr_off : (tr_off ^ 16)) + c * 32;   // pieces 2, 3: swapped unit pairs
@@ -796,9 +889,18 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
                        (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
         oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb, oacc[c], 0, 0, 0);
       }
+      }
     }
+    if constexpr (FG) load_batch(set_tag, i0 + 2 * FB);      // fine-grained instantiations: the whole next-but-one batch
+    if (i0 < 24) FLASH_STAMP(3 + i0);
+  };
+  load_batch(IntTag<1>{}, FB);      // (batch 0 went out with trip 2)
+  for (int i0 = 0; i0 < my_tiles; i0 += 2 * FB) {       // consume() requests batch i0 + 2 FB into the set it empties
+    consume(IntTag<0>{}, i0);
+    consume(IntTag<1>{}, i0 + FB);
   }
   OMNI_CLK(19);
+  FLASH_STAMP(28);
   // ---- combine the four waves' (max, sum, O); add the current token; normalise / emit partials ----------------
   l_run = rows4_sum(l_run);
   if (l15 < G) {
@@ -884,6 +986,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   }
 
   OMNI_CLK(22);
+  FLASH_STAMP(29);
   // ---- append the current token (quantised) to the cache ------------------------------------------
   if (owns_cur && sub == 0 && wave < 2) {
     const half_t* src = wave == 0 ? kcur : vcur;
@@ -1490,6 +1593,11 @@ extern "C" int omni_kv_decode_attention_fine_grained_partial(
 }
 
 OMNI_CLK_READER(omni_debug_clocks_kv)
+#ifdef OMNI_DEBUG_CLOCKS
+extern "C" int omni_debug_timeline_flash(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(omni::omni_dbg_flash), sizeof(unsigned long long) * 3 * omni::DEC_WAVES * 32) == hipSuccess ? 0 : -5;
+}
+#endif
 
 extern "C" int omni_kv4_decode_attention_fine_grained(
     void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16, int64_t q_stride, int64_t kv_stride,

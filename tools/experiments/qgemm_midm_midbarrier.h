@@ -128,7 +128,6 @@ __device__ __forceinline__ void lds_dma_piece(const void* sbase, uint32_t v0, ui
 template <int N>
 __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int V> struct IntTag { static constexpr int value = V; };
 
 #ifdef OMNI_DEBUG_CLOCKS
 // timeline probe (tools/midm_timeline.py): per wave of workgroups 0 and gridDim.x - 1, shader-clock stamps
