@@ -5,8 +5,11 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from block_sparse_attn import flash_attn_varlen_func, token_streaming_attn_func  # noqa: E402
 from omniserve_amd import _lib  # noqa: E402
+
+if os.environ.get("OMNI_TUNE_LIB"):     # A/B against a library variant (tools/build_variant.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["OMNI_TUNE_LIB"])
+from block_sparse_attn import flash_attn_varlen_func, token_streaming_attn_func  # noqa: E402
 
 dev = torch.device("cuda:0")
 Hq, Hk, D = 32, 8, 128
