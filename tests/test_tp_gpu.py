@@ -223,6 +223,37 @@ def _peer_allreduce_rank(rank, world, port, shapes, ret):
         dist.destroy_process_group()
 
 
+def _peer_stale_rank(rank, world, port, n, iters, ret):
+    """Every round: fresh values into the slot the peer read LAST time with ordinary cached loads (a torch reduction over
+    the peer's mapped buffer = lines of the old contents planted in this process' caches), then the collective."""
+    import torch.distributed as dist
+    from omniserve_amd import tp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        comm = tp.PeerComm(rank, world, n, dev)
+        peer = torch.as_tensor(tp.PeerComm._Blob(comm._mapped[0], comm.data_bytes), device=dev).view(torch.int16)   # both slots
+        out = torch.empty((n,), dtype=torch.float16, device=dev)
+        outs, planted = [], []
+        for it in range(iters):
+            comm.slot(n).fill_(float(2 * it + rank + 1))
+            torch.cuda.synchronize()
+            dist.barrier()                                   # both slots of this round are written
+            comm.all_reduce(out)
+            torch.cuda.synchronize()
+            outs.append(out.cpu().numpy().copy())
+            planted.append(int(peer.long().sum().item()))    # plain loads over the peer's two slots: their lines are cached here now
+            dist.barrier()
+        comm.check_error()
+        ret[rank] = (outs, planted)
+        dist.barrier()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def _peer_add_norm_rank(rank, world, port, cases, ret):
     """PeerComm.add_rms_norm (the all-reduce folded into add + norm + quant) against all_reduce + the reference sequence, for row
     widths that take one, two and four vectors per thread (tp_add_norm_v2_kernel<512, 1 | 2 | 4>)."""
@@ -300,6 +331,22 @@ def test_peer_allreduce_two_ranks_one_gpu():
         want = np.full((shapes[0],), 2.0 * (3 + 2 * it), np.float16)
         for rk in range(2):
             assert np.array_equal(ret[rk][len(shapes) * 2 + it], want), (it, rk)
+
+
+def test_peer_allreduce_reads_fresh_slots_behind_planted_stale_lines():
+    """VERDICT r4 item 3 for the peer collective: between two uses of a slot the OTHER process reads it with ordinary cached
+    loads (so any cache level that could keep a non-coherent copy of it holds the old contents), the owner then overwrites
+    it and the collective must return the new sum.  24 rounds x 64 K elements, two processes on the one test GPU (different
+    processes' kernels land on different XCDs: the L2s are not shared).  The buffers are fine-grained allocations and the
+    kernels acquire at system scope behind the flag wait (csrc/tp_comm.h); a plain allocation or a missing acquire fails here."""
+    n, iters = 65536, 24
+    ret = _spawn2(_peer_stale_rank, (n, iters))
+    for rk in range(2):
+        outs, planted = ret[rk]
+        for it in range(iters):
+            want = np.full((n,), float(4 * it + 3), np.float16)
+            assert np.array_equal(outs[it], want), "round %d rank %d: %s ... instead of %s" % (it, rk, outs[it][:4], want[:1])
+        assert all(p != 0 for p in planted)      # (the planting reads really happened)
 
 
 @pytest.mark.parametrize("group_size,graph", [(-1, False), (128, False), (-1, True)])
