@@ -235,8 +235,14 @@ __device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t mask, uint32_t m
   return r;
 }
 
+template <bool CHEAP = false>
 __device__ __forceinline__ void kv4_dequant16(const uint4 raw, v2h scale2, v2h c2, v2h out[16]) {
   const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+  if constexpr (CHEAP) {      // (timing experiments only: 16 instead of 52 operations, no dependent chains)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[i] = __builtin_bit_cast(v2h, w[i & 3]) * scale2;
+    return;
+  }
   const v2h k1024 = {(half_t)1024.0f, (half_t)1024.0f};
   const v2h k16th = {(half_t)0.0625f, (half_t)0.0625f};
   const v2h k64 = {(half_t)64.0f, (half_t)64.0f};
@@ -359,6 +365,9 @@ constexpr int FVTILE = 32 * FVROW;
                                // (15 / 25 / 88 us at 16 x 1 K, 64 x 1 K, 8 x 32 K); inside the decode step 1 is 1-2 % faster per
                                // STEP at bs = 16 and bs = 64 (2.31 -> 2.26-2.29 ms, 3.59 -> 3.53-3.54 ms, profiles/r03_h)
 #endif
+#ifndef OMNI_FLASH_ABLATE
+#define OMNI_FLASH_ABLATE 0    // timing experiments (WRONG results), bits: 1 loads only, 2 no P.V part (V unpack, LDS round trip, MFMAs),
+#endif                         // 4 V unpack without its arithmetic, 8 K unpack without its arithmetic, 16 no exponentials (profiles/r05_b)
 #ifndef OMNI_FLASH_SLOTS
 #define OMNI_FLASH_SLOTS 512   // workgroups the chip holds at a time (256 CUs x workgroups per CU): the split planner's round size
 #endif
@@ -782,7 +791,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
                                     // (nearly) vmcnt(0), i.e. a wait for the request just issued (ISA of round 5: vmcnt(5 .. 0)
                                     // in front of the V unpack where 17 .. 12 are in flight).  A tile past the end re-reads the
                                     // safe token: two wasted batches per wave.
-#ifdef OMNI_FLASH_ABLATE     // timing experiment (wrong results): the sweep's loads without its arithmetic -- what the launch
+#if (OMNI_FLASH_ABLATE & 1)  // timing experiment (wrong results): the sweep's loads without its arithmetic -- what the launch
       {                      // geometry (pages, workgroups, one batch in flight per wave) can stream at all
         uint32_t acc_x = 0;
 #pragma unroll
@@ -809,7 +818,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
           kv8_dequant16(kraw[S][u][h][NQ - 1], k_qo, kd + 8);
         } else {
           const half_t ch = (half_t)(-(float)ksc[S][u][h] * (float)kze[S][u][h]);
-          kv4_dequant16(kraw[S][u][h][0], (v2h){ksc[S][u][h], ksc[S][u][h]}, (v2h){ch, ch}, kd);
+          kv4_dequant16<(OMNI_FLASH_ABLATE & 8) != 0>(kraw[S][u][h][0], (v2h){ksc[S][u][h], ksc[S][u][h]}, (v2h){ch, ch}, kd);
         }
         v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -843,7 +852,8 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       for (int e = 0; e < 8; e += 2) {
         // masked slots: exp2(-1e30 - m_new) = 0.  The row sum takes the unrounded exponentials (as upstream sums them);
         // the P.V operand is their fp16 rounding
-        const v2f pp = {__builtin_amdgcn_exp2f(x[e] - m_new), __builtin_amdgcn_exp2f(x[e + 1] - m_new)};
+        const v2f pp = (OMNI_FLASH_ABLATE & 16) ? (v2f){x[e] - m_new, x[e + 1] - m_new}
+                                              : (v2f){__builtin_amdgcn_exp2f(x[e] - m_new), __builtin_amdgcn_exp2f(x[e + 1] - m_new)};
         psum += pp[0] + pp[1];
         const v2h ph = __builtin_convertvector(pp, v2h);
         pb[e] = ph[0];
@@ -856,6 +866,10 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       }
       m_run = m_new;
       // ---- O^T += V^T . P^T : dequantised V tile through LDS, transposed reads ----
+      if constexpr ((OMNI_FLASH_ABLATE & 2) != 0) {      // (timing experiment: the V bytes are consumed, nothing else)
+        oacc[0][0] += (float)((vraw[S][u][0][0].x ^ vraw[S][u][1][0].y ^ (uint32_t)__builtin_bit_cast(uint16_t, vsc[S][u][0]) ^
+                               (uint32_t)__builtin_bit_cast(uint16_t, vze[S][u][1]) ^ (uint32_t)pb[0]) & 1u);
+      } else {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         v2h vd[16];
@@ -864,7 +878,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
           kv8_dequant16(vraw[S][u][h][NQ - 1], v_qo, vd + 8);
         } else {
           const half_t ch = (half_t)(-(float)vsc[S][u][h] * (float)vze[S][u][h]);
-          kv4_dequant16(vraw[S][u][h][0], (v2h){vsc[S][u][h], vsc[S][u][h]}, (v2h){ch, ch}, vd);
+          kv4_dequant16<(OMNI_FLASH_ABLATE & 4) != 0>(vraw[S][u][h][0], (v2h){vsc[S][u][h], vsc[S][u][h]}, (v2h){ch, ch}, vd);
         }
         uint8_t* dst = vt + (h * 16 + vtok) * FVROW + vpiece * 64;   // 32 values in dequant order
         const int wsw = vpiece >> 1;
@@ -876,8 +890,9 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
         }
       }
       }
+      }
       if constexpr (!FG) load_dense(set_tag, IntTag<1>{}, u, i0 + 2 * FB);      // ... and its V registers
-      if (on) {
+      if (on && !(OMNI_FLASH_ABLATE & 2)) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const uint8_t* src = vt + (c < 4 ? tr_off : (tr_off ^ 16)) + c * 32;   // pieces 2, 3: swapped unit pairs
