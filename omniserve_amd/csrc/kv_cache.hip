@@ -389,7 +389,8 @@ static __device__ unsigned long long omni_dbg_flash[3 * DEC_WAVES * 32];
 #else
 #define FLASH_STAMP(i) do {} while (0)
 #endif
-template <int G, bool DIRECT, bool FG = false, bool KV8 = false, bool LASTM = false>
+// PIPE (dense instantiations; the host picks it when a wave sweeps six or more tiles): requests two tiles ahead, see below.
+template <int G, bool DIRECT, bool FG = false, bool KV8 = false, bool LASTM = false, bool PIPE = true>
 __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode_flash_kernel(DecodeArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #ifdef OMNI_DEBUG_CLOCKS
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   // SIMD need 3 x 0.55 us of VALU per round): 73 us at 256 x 1 K tokens against 49 us for the same requests without the
   // arithmetic (profiles/r05_b).
   int64_t kwin = 0, vwin = 0;
-  if constexpr (!FG) {
+  if constexpr (!FG && PIPE) {
     kwin = pages[lane < 40 ? lane : 0];
     vwin = pages[40 + (lane < 40 ? lane : 0)];
   }
@@ -684,8 +685,8 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   };
   auto load_batch = [&](auto set_tag, int i0) {   // branch-free; page pointers of the whole batch first, then every load
     constexpr int S = decltype(set_tag)::value;
-    if constexpr (!FG) {
-#pragma unroll
+    if constexpr (!FG && PIPE) {      // (short sweeps keep the per-lane addressing: its page lookups do not queue behind one another
+#pragma unroll                        //  on the scalar unit in front of a wave's only two batches -- 1 % of the bs = 16 step)
       for (int u = 0; u < FB; ++u) {
         load_dense(set_tag, IntTag<0>{}, u, i0);
         load_dense(set_tag, IntTag<1>{}, u, i0);
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
         }
       }
   };
-  load_batch(IntTag<0>{}, 0);
+  load_batch(IntTag<(FG || PIPE) ? 0 : 1>{}, 0);      // (short-sweep form: set 1 is the one in flight, set 0 the one consumed)
 
   // RoPE(q) (and k of the current token) into LDS while the cache bytes are in flight
 #pragma unroll
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
                                        (uint32_t)__builtin_bit_cast(uint16_t, vsc[S][u][h]) ^ (uint32_t)__builtin_bit_cast(uint16_t, vze[S][u][h]);
         }
         if (on) oacc[0][0] += (float)(acc_x & 1u);
-        if constexpr (!FG) { load_dense(set_tag, IntTag<0>{}, u, i0 + 2 * FB); load_dense(set_tag, IntTag<1>{}, u, i0 + 2 * FB); }
+        if constexpr (!FG && PIPE) { load_dense(set_tag, IntTag<0>{}, u, i0 + 2 * FB); load_dense(set_tag, IntTag<1>{}, u, i0 + 2 * FB); }
         continue;
       }
 #endif
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
           x[4 * h + r] = acc[r] * sm_scale2;
       }
       }
-      if constexpr (!FG) load_dense(set_tag, IntTag<0>{}, u, i0 + 2 * FB);      // this tile's K registers are free: tile + 2's K
+      if constexpr (!FG && PIPE) load_dense(set_tag, IntTag<0>{}, u, i0 + 2 * FB);      // this tile's K registers are free: tile + 2's K
       v8h pb;   // k-slots of the P.V step: tokens 4*l4+r of group 0, then of group 1 (as the V^T operand below)
       if (on) {
       if (tbase + 32 > nt) {   // wave-uniform: only the last tile of a split has token slots to mask (118 -> ~50 softmax VALU per
@@ -891,7 +892,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       }
       }
       }
-      if constexpr (!FG) load_dense(set_tag, IntTag<1>{}, u, i0 + 2 * FB);      // ... and its V registers
+      if constexpr (!FG && PIPE) load_dense(set_tag, IntTag<1>{}, u, i0 + 2 * FB);      // ... and its V registers
       if (on && !(OMNI_FLASH_ABLATE & 2)) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -909,10 +910,31 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
     if constexpr (FG) load_batch(set_tag, i0 + 2 * FB);      // fine-grained instantiations: the whole next-but-one batch
     if (i0 < 24) FLASH_STAMP(3 + i0);
   };
-  load_batch(IntTag<1>{}, FB);      // (batch 0 went out with trip 2)
-  for (int i0 = 0; i0 < my_tiles; i0 += 2 * FB) {       // consume() requests batch i0 + 2 FB into the set it empties
-    consume(IntTag<0>{}, i0);
-    consume(IntTag<1>{}, i0 + FB);
+  if constexpr (FG || PIPE) {
+    load_batch(IntTag<1>{}, FB);      // (batch 0 went out with trip 2)
+    for (int i0 = 0; i0 < my_tiles; i0 += 2 * FB) {       // consume() requests batch i0 + 2 FB into the set it empties
+      consume(IntTag<0>{}, i0);
+      consume(IntTag<1>{}, i0 + FB);
+    }
+  } else {
+    // Short sweeps (bs = 16 at 1 K tokens runs four KV splits: two or three tiles per wave) have little to request two ahead,
+    // and the unconditional requests would be two tiles of real loads for nothing, waited for behind the sweep where their
+    // registers are reused: +1.4 % on the bs = 16 decode step (same-box A/B).  One tile ahead, conditionally, per-lane addresses.
+    for (int i0 = 0; i0 < my_tiles; i0 += FB) {      // one loop body: the arrived batch is copied out of the set in flight
+#pragma unroll
+      for (int u = 0; u < FB; ++u)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int n = 0; n < NQ; ++n) { kraw[0][u][h][n] = kraw[1][u][h][n]; vraw[0][u][h][n] = vraw[1][u][h][n]; }
+          if constexpr (!KV8) {
+            ksc[0][u][h] = ksc[1][u][h]; kze[0][u][h] = kze[1][u][h];
+            vsc[0][u][h] = vsc[1][u][h]; vze[0][u][h] = vze[1][u][h];
+          }
+        }
+      if (i0 + FB < my_tiles) load_batch(IntTag<1>{}, i0 + FB);   // next batch in flight while this one is consumed
+      consume(IntTag<0>{}, i0);
+    }
   }
   OMNI_CLK(19);
   FLASH_STAMP(28);
@@ -1369,8 +1391,13 @@ static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, co
   dim3 grid(pl.nsplit, num_kv_heads * (group / pl.g), batch);
   hipStream_t st = (hipStream_t)stream;
   if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;
-#define OMNI_LAUNCH_DEC(G_, D_) \
-  hipLaunchKernelGGL((kv4_decode_flash_kernel<G_, D_>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a)
+  const bool pipe = pl.split_tokens > 5 * 32 * DEC_WAVES;      // a wave sweeps six or more 32-token tiles (the two batches the
+                                                               // pipelined form requests past the end are real loads: see the kernel)
+#define OMNI_LAUNCH_DEC(G_, D_)                                                                                          \
+  do {                                                                                                                   \
+    if (pipe) hipLaunchKernelGGL((kv4_decode_flash_kernel<G_, D_>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a);       \
+    else hipLaunchKernelGGL((kv4_decode_flash_kernel<G_, D_, false, false, false, false>), grid, dim3(DEC_THREADS), pl.lds_bytes, st, a); \
+  } while (0)
   if (pl.nsplit == 1 && !partials_only) {
     switch (pl.g) {
       case 1: OMNI_LAUNCH_DEC(1, true); break;
@@ -1465,8 +1492,12 @@ extern "C" int omni_kv4_decode_attention_f16_amax(void* out_f16, void* amax_slot
   }
   if (pl.lds_bytes > 160 * 1024) return OMNI_EINVAL;
   dim3 grid(pl.nsplit, gy, batch + rider_slices);
-  hipLaunchKernelGGL((kv4_decode_flash_kernel<4, false, false, false, true>), grid, dim3(DEC_THREADS), pl.lds_bytes,
-                     (hipStream_t)stream, a);
+  if (pl.split_tokens > 5 * 32 * DEC_WAVES)
+    hipLaunchKernelGGL((kv4_decode_flash_kernel<4, false, false, false, true>), grid, dim3(DEC_THREADS), pl.lds_bytes,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((kv4_decode_flash_kernel<4, false, false, false, true, false>), grid, dim3(DEC_THREADS), pl.lds_bytes,
+                       (hipStream_t)stream, a);
   return omni_launch_status();
 }
 

@@ -34,5 +34,8 @@ else:
     fn = lambda: pd.single_query_attention(q, k, v, pools.table, lens, None, 1 << 20, 64, Hk * D // 2, Tc + 1, D,
                                            500000.0, True, True, True)
     nbytes = 1088 * Tc * B
+if os.environ.get("OMNI_NSPLIT"):      # planner override (tuning): KV splits per (sequence, head group)
+    from omniserve_amd import _lib as _l
+    _l.lib().omni_kv4_decode_set_split_override(int(os.environ["OMNI_NSPLIT"]))
 us = timed(fn, iters=iters)
 print("%s decode attention B=%d T=%d: %.1f us, %.0f GB/s" % (mode, B, Tc, us, nbytes / us / 1e3))
