@@ -786,6 +786,9 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
 #pragma unroll
     for (int u = 0; u < FB; ++u) {
       const int tbase = (wave + DEC_WAVES * (i0 + u)) * 32;
+      if constexpr (!FG && !PIPE) {
+        if (tbase >= nt) continue;   // (short-sweep form: no request rides on a tile that does not exist)
+      }
       const bool on = tbase < nt;   // wave-uniform: the tile exists.  Its arithmetic is conditional, the REQUESTS below are not:
                                     // vmcnt counts in order, and the compiler sizes every wait for the path with the fewest
                                     // requests behind the one it needs -- a conditional prefetch turns each counted wait into
