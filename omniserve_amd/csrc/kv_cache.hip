@@ -417,9 +417,18 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   half_t* vcur = kcur_p + DH;                                 // [128]
   float* red = reinterpret_cast<float*>(vcur + DH);           // [64]
   int64_t* pages = reinterpret_cast<int64_t*>(red + 64);      // [2][40]
-  float* xbuf = reinterpret_cast<float*>(pages + 80);         // [4 waves][G][128]
-  float* mlbuf = xbuf + DEC_WAVES * G * DH;                   // [4 waves][G][2]  (max, sum) of each wave
+  // G = 8 (head groups of 8 q heads per kv head: Llama-2/3-70B; the MFMAs' 16 head columns hold them at no extra cost, and K / V
+  // are fetched and unpacked once for all eight instead of once per four): the waves' O accumulators for the combine would be
+  // 16 KiB -- each wave parks them in its OWN V tile instead (it writes them when its sweep is over; nobody else touches that
+  // tile), so the workgroup stays at 40 KiB of LDS.  G <= 4 keeps the separate [4 waves][G][128] array.
+  constexpr bool XOVER = G > 4;
+  float* xbuf = reinterpret_cast<float*>(pages + 80);         // [4 waves][G][128] (G <= 4)
+  float* mlbuf = XOVER ? xbuf : xbuf + DEC_WAVES * G * DH;    // [4 waves][G][2]  (max, sum) of each wave
   uint8_t* vtile = reinterpret_cast<uint8_t*>(mlbuf + DEC_WAVES * G * 2);   // [4 waves][32][FVROW]
+  static_assert(G <= 16 && G * DH * 4 <= FVTILE, "head columns of the MFMA; accumulators fit the wave's V tile");
+  auto xrow = [&](int w, int g) -> float* {
+    return XOVER ? reinterpret_cast<float*>(vtile + w * FVTILE) + g * DH : xbuf + ((size_t)w * G + g) * DH;
+  };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x;
@@ -946,7 +955,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   if (l15 < G) {
 #pragma unroll
     for (int c = 0; c < 8; ++c)
-      *reinterpret_cast<v4f*>(xbuf + ((size_t)wave * G + l15) * DH + c * 16 + 4 * l4) = oacc[c];
+      *reinterpret_cast<v4f*>(xrow(wave, l15) + c * 16 + 4 * l4) = oacc[c];
     if (l4 == 0) {
       mlbuf[(wave * G + l15) * 2 + 0] = m_run * 0.6931471805599453f;    // back to natural units for the combine / merge
       mlbuf[(wave * G + l15) * 2 + 1] = l_run;
@@ -963,7 +972,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
 #pragma unroll
     for (int w = 0; w < DEC_WAVES; ++w) {
       const float wgt = __expf(mlbuf[(w * G + g) * 2] - M);
-      acc += wgt * xbuf[((size_t)w * G + g) * DH + qpos];
+      acc += wgt * xrow(w, g)[qpos];
       L += wgt * mlbuf[(w * G + g) * 2 + 1];
     }
     if (owns_cur) {
@@ -1134,10 +1143,11 @@ struct DecodePlan {
 static thread_local int g_override_nsplit = 0;   // tuning hook, see omni_kv4_decode_set_split_override
 
 static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int max_context, int tokens_per_block,
-                              bool per_q_head = false) {
+                              bool per_q_head = false, bool allow_g8 = false) {
   DecodePlan pl;
   const int group = num_heads / num_kv_heads;
   pl.g = group >= 4 ? 4 : group;  // group in {1,2,4,8,...}
+  if (allow_g8 && group % 8 == 0) pl.g = 8;      // (the dense two-launch forms: one workgroup serves eight q heads)
   if (per_q_head) pl.g = 1;       // every q head walks its own page list
   const int wgs_per_split = batch * num_kv_heads * (group / pl.g);
   // LDS bound of the two-pass kernel's score buffer; the kernels keep a window of 40 page pointers per split
@@ -1172,7 +1182,7 @@ static DecodePlan plan_decode(int batch, int num_heads, int num_kv_heads, int ma
   if (st > st_cap) st = st_cap;   // caller rejects: max_context > 1024 * st_cap
   pl.nsplit = s;
   pl.split_tokens = st;
-  pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (size_t)DEC_WAVES * pl.g * DH * 4 +
+  pl.lds_bytes = (size_t)(pl.g + 3) * DH * 2 + 64 * 4 + 80 * 8 + (pl.g > 4 ? 0 : (size_t)DEC_WAVES * pl.g * DH * 4) +
                  (size_t)DEC_WAVES * pl.g * 2 * 4 + (size_t)DEC_WAVES * FVTILE;
   return pl;
 }
@@ -1371,7 +1381,7 @@ static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, co
     return OMNI_EINVAL;
   const int group = num_heads / num_kv_heads;
   if (group != 1 && group != 2 && group % 4 != 0) return OMNI_EINVAL;
-  const DecodePlan pl = plan_decode(batch, num_heads, num_kv_heads, max_context, tokens_per_block);
+  const DecodePlan pl = plan_decode(batch, num_heads, num_kv_heads, max_context, tokens_per_block, false, true);
   if ((long long)pl.nsplit * pl.split_tokens < max_context) return OMNI_EINVAL;
   const size_t need = (size_t)batch * num_heads * pl.nsplit * (DH + 2) * sizeof(float);
   if (workspace_bytes < need) return OMNI_ENOMEM;
@@ -1405,12 +1415,14 @@ static int decode_common(void* out_f16, const void* q_f16, const void* k_f16, co
     switch (pl.g) {
       case 1: OMNI_LAUNCH_DEC(1, true); break;
       case 2: OMNI_LAUNCH_DEC(2, true); break;
+      case 8: OMNI_LAUNCH_DEC(8, true); break;
       default: OMNI_LAUNCH_DEC(4, true); break;
     }
   } else {
     switch (pl.g) {
       case 1: OMNI_LAUNCH_DEC(1, false); break;
       case 2: OMNI_LAUNCH_DEC(2, false); break;
+      case 8: OMNI_LAUNCH_DEC(8, false); break;
       default: OMNI_LAUNCH_DEC(4, false); break;
     }
     if (!partials_only)

@@ -94,6 +94,15 @@ def test_decode_attention(hist_lens, Hq, Hk):
     _decode_case(hist_lens, Hq, Hk, seed=sum(hist_lens) + Hq)
 
 
+@pytest.mark.parametrize("hist_lens,Hq,Hk,steps", [([70, 5, 129], 16, 2, 2), ([300, 64], 64, 8, 1), ([1400, 1030, 1], 8, 1, 1),
+                                                    ([2100], 16, 2, 1), ([33], 24, 3, 1)])
+def test_decode_attention_eight_q_heads_per_kv_head(hist_lens, Hq, Hk, steps):
+    """Head groups of 8 (Llama-2/3-70B: 64 / 8, one TP = 8 rank: 8 / 1) run as ONE workgroup per (split, kv head, sequence) with
+    eight head columns (kv4_decode_flash_kernel<8, ...>): short and long sweeps (both loop forms), one split and several (the
+    merge launch), the append crossing a page; 24 / 3 stays on the four-column form."""
+    _decode_case(hist_lens, Hq, Hk, seed=sum(hist_lens) + Hq, steps=steps)
+
+
 def test_decode_attention_multi_step_crossing_page():
     _decode_case([62, 127], 8, 2, seed=3, steps=4)
 
