@@ -789,8 +789,30 @@ extern "C" int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, vo
       return omni_launch_status();
     }
   }
+  // Rows of 16384 < d <= 32768 (Llama-2/3-70B's intermediate size at TP = 1: 28672): the <512, 8> geometry, 112 KiB of LDS for
+  // the f32 row copy (one workgroup per CU; a decode batch has fewer rows than the chip has CUs).  The one-thread-per-32-columns
+  // kernel below took 13.6 us per layer at bs = 128 (128 workgroups, a serial loop of 56 vectors per thread; profiles/r05_f).
+  {
+    const int nv = norm_block(d, false);
+    if (d > 512 * 4 * VT && d <= 512 * 8 * VT && d % 8 == 0 && nv % 32 == 0 && nv <= 1024) {
+      const PrefetchArgs pf = take_prefetch(tokens);
+      const size_t lds = (size_t)d * sizeof(float);
+      auto launch = [&](auto kern, half_t* sum) {
+        static bool raised = false;      // (dynamic LDS beyond 64 KiB is an opt-in per kernel)
+        if (!raised) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+          raised = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(tokens + pf.blocks), dim3(512), lds, (hipStream_t)stream, (int8_t*)out_i8,
+                           SrcSilu{(const half_t*)in_f16, d}, sum, (half_t*)scale_f16, d, nv, pf);
+      };
+      if (sum_f16) launch(quant_v2_kernel<512, 8, true, SrcSilu>, (half_t*)sum_f16);
+      else launch(quant_v2_kernel<512, 8, false, SrcSilu>, (half_t*)nullptr);
+      return omni_launch_status();
+    }
+  }
   (void)take_armed_prefetch();
-  // row lengths outside the v2 geometry (d > 16384: Llama-2-70B / Yi-34B intermediate sizes at TP = 1)
+  // row lengths outside every v2 geometry
   if (sum_f16)
     hipLaunchKernelGGL(silu_mul_quant_kernel<true>, dim3(tokens), dim3(norm_block(d, false)), 0, (hipStream_t)stream,
                        (int8_t*)out_i8, (const half_t*)in_f16, (half_t*)sum_f16, (half_t*)scale_f16, d);

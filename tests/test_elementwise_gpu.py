@@ -104,9 +104,11 @@ def test_fused_add_norm_matches_the_two_reference_calls(tokens, hidden):
     assert_f16_equal(ssum, sm, "sum")
 
 
-@pytest.mark.parametrize("tokens,d", [(16, 14336), (3, 28672), (5, 128), (1030, 14336)])
+@pytest.mark.parametrize("tokens,d", [(16, 14336), (3, 28672), (5, 128), (1030, 14336), (128, 28672), (5, 32768), (2, 16416),
+                                      (3, 32800)])
 def test_fused_silu_mul_quant_matches_the_two_kernels(tokens, d):
-    """Compared against the HIP silu_and_mul + quant pair (both go through the same device expf)."""
+    """Compared against the HIP silu_and_mul + quant pair (both go through the same device expf).  Rows of 16384 < d <= 32768
+    (Llama-2-70B's 28672) take the <512, 8> geometry with 112 - 128 KiB of LDS, wider ones the one-kernel-per-row fallback."""
     import omniserve_backend.activation_ops as act
     import omniserve_backend.fused_kernels as fk
     from omniserve_amd.backend import fused_ext
