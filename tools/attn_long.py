@@ -12,7 +12,7 @@ import omniserve_backend.fused_attention_pure_dense as pd  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "kv4"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-Hq, Hk = 32, 8
+Hq, Hk = int(os.environ.get("OMNI_HQ", 32)), int(os.environ.get("OMNI_HK", 8))      # (one TP = 8 rank of Llama-2-70B: 8 / 1)
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 Tc = int(sys.argv[4]) if len(sys.argv) > 4 else 32768
 row = 128 if mode == "kv8" else 64
