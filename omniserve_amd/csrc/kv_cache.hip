@@ -637,23 +637,22 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   // (fine-grained instantiations keep two tiles per batch: at batch 1 / 256 K tokens the launch has few workgroups and
   //  lives on loads in flight per wave -- 93 vs 98 us for the dense 4 + 4 head mix; sparse decode times the same)
   constexpr int FB = FG ? 2 : OMNI_FLASH_FB;
-  // two register sets: the batch being consumed and the batch in flight (static indices: the sweep is unrolled by two
-  // batches -- copying the arrived batch into a second set cost 24 v_mov per tile)
+  // two register sets: the batch being consumed and the batch in flight (PIPE / fine-grained: static indices, the sweep is
+  // unrolled by two batches; the short-sweep form copies the arrived batch from set 1 to set 0 and has one loop body)
   uint4 kraw[2][FB][2][NQ], vraw[2][FB][2][NQ];
   half_t ksc[2][FB][2], kze[2][FB][2], vsc[2][FB][2], vze[2][FB][2];   // KV4 only
   // safe token of an out-of-range lane: the split's first token, or (empty split) slot 0 of window entry 0
   const int tsafe = nt > 0 ? t0 : ((FG && streaming) ? 0 : (page0 << lay.tpb_log2));
-  // Dense instantiations: a 16-token group never straddles a page (splits start at multiples of 16 tokens, pages hold a
-  // multiple of 16), so its page pointer, first slot and every base address are WAVE-UNIFORM: the page window sits in two
-  // VGPR pairs (lane i = window entry i, read with v_readlane), the bases are scalar arithmetic, and the loads take
-  // (scalar base, 32-bit lane offset).  The per-lane pointer arithmetic this replaces was 117 of the tile loop's 406 VALU
-  // instructions -- in a sweep that is VALU-issue bound (profiles/r05_b).  Lanes past the split's end re-read its last
-  // token (finite values; their scores are masked), a group wholly past it reads the safe token.
-  // Requests run TWO tiles ahead without a third register set: a tile's K registers are dead once its K operands are
-  // unpacked and its V registers once the V tile is in LDS, so the K / V requests of tile i + 2 go out right there, into the
-  // set tile i is leaving.  With one tile ahead a wave's period was the memory latency (2.2 us at this load; three waves per
-  // SIMD need 3 x 0.55 us of VALU per round): 73 us at 256 x 1 K tokens against 49 us for the same requests without the
-  // arithmetic (profiles/r05_b).
+  // Dense instantiations, long sweeps (PIPE: the host picks it where a wave has six or more tiles): a 16-token group never
+  // straddles a page (splits start at multiples of 16 tokens, pages hold a multiple of 16), so its page pointer, first slot and
+  // every base address are WAVE-UNIFORM: the page window sits in two VGPR pairs (lane i = window entry i, read with v_readlane),
+  // the bases are scalar arithmetic, and the loads take (scalar base, 32-bit lane offset) -- 41 VALU instructions per tile less.
+  // Lanes past the split's end re-read its last token (finite values; their scores are masked), a group wholly past it reads
+  // the safe token.  Requests run TWO tiles ahead without a third register set: a tile's K registers are dead once its K
+  // operands are unpacked and its V registers once the V tile is in LDS, so the K / V requests of tile i + 2 go out right there,
+  // into the set tile i is leaving (issued unconditionally: see consume()).  What these bought and what they did not:
+  // profiles/r05_b (256 x 2 K tokens 171.7 -> 160 us, 8 x 32 K 88 -> 79; 256 x 1 K unchanged -- the sweep is bound by the
+  // unpack arithmetic the reference's per-element fp16 rounding dictates).
   int64_t kwin = 0, vwin = 0;
   if constexpr (!FG && PIPE) {
     kwin = pages[lane < 40 ? lane : 0];
@@ -803,7 +802,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
                                     // requests behind the one it needs -- a conditional prefetch turns each counted wait into
                                     // (nearly) vmcnt(0), i.e. a wait for the request just issued (ISA of round 5: vmcnt(5 .. 0)
                                     // in front of the V unpack where 17 .. 12 are in flight).  A tile past the end re-reads the
-                                    // safe token: two wasted batches per wave.
+                                    // safe token: two wasted batches per wave, which is why short sweeps do not run this form.
 #if (OMNI_FLASH_ABLATE & 1)  // timing experiment (wrong results): the sweep's loads without its arithmetic -- what the launch
       {                      // geometry (pages, workgroups, one batch in flight per wave) can stream at all
         uint32_t acc_x = 0;
