@@ -10,6 +10,9 @@ from omniserve_amd.runtime import DecodeRunner, LlamaConfig  # noqa: E402
 
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 dev = torch.device("cuda:0")
+if os.environ.get("OMNI_MIDM"):      # planner override of the mid-M kernel (-1 heuristic, 0 never, 1 wherever legal); plans are taken at capture
+    from omniserve_amd import _lib
+    _lib.lib().omni_gemm_set_midm_override(int(os.environ["OMNI_MIDM"]), 0)
 r = DecodeRunner(LlamaConfig.llama2_70b(-1), bs, 1024, 40, dev, seed=3, fused=int(os.environ.get("OMNI_FUSED", "3")), tp_rank=0, tp_size=8)
 for _ in range(4):
     r.step()
