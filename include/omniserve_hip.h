@@ -498,6 +498,34 @@ int omni_tp_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, cons
 int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, int mode, int deferred, int64_t budget_bytes,
                            int blocks);
 
+/* Fused extension (round 6): a (residual add + rms_norm_general[_fuse_sum]) -> (decode-shape W4A8 GEMM) pair as ONE launch with
+ * heterogeneous workgroups (csrc/norm_gemv_fused.h): the reference's input_layernorm -> qkv_proj and post_attention_layernorm ->
+ * gate_up_proj (+ silu_and_mul) edges (omniserve/modeling/models/llama_w4a8_unpad.py:410-432).  Workgroups [0, M) are the rows
+ * (the row kernels' own body); the others are the GEMM's 64-channel tiles, which request their WHOLE weight part first and then
+ * wait for the rows on sync_u32[0] (agent-scope polls, bounded: a give-up stores NaN outputs and sets *err_u32 = 1).
+ * Bit-identical to omni_splitk_[w8_]add_rms_norm_general_fuse_sum / omni_add_rms_norm_general_fuse_sum /
+ * omni_rms_norm_general[_fuse_sum] followed by omni_w4a8_per_*_gemm / omni_w4a8_per_*_gemm_silu.
+ *   rows' source: slab_i32 != NULL: residual += h(epilogue(sum of sk slabs)) (p_* = the producing GEMM's scales / zero terms and
+ *     its input's scales / sums); else delta_f16 != NULL: residual += delta; else the residual as it is.
+ *   amax_slots_u32 != NULL: the gate_up form (out_f16 = act [M, N/2], raises the row-maximum slots); NULL: out_f16 [M, N].
+ *   sync_u32: 32 words the CALLER ZEROES before every launch (e.g. omni_decode_step_begin's zero list); err_u32: sticky.
+ *   clk_u64: NULL, or [grid][8] wall-clock marks (timeline probe).  M <= 16, K % 256 == 0, K <= 4096, N % 64 (128) == 0.
+ * omni_norm_gemm_fused_ok: 1 when the shape is accepted AND every workgroup of its grid is resident at once on this device
+ * (the hand-off cannot deadlock whatever the dispatch order); 0: use the two launches. */
+int omni_norm_gemm_fused_ok(int M, int N, int K, int mode, int silu);
+int omni_w4a8_per_chn_norm_gemm_fused(void* codes_i8, void* residual_f16, const void* slab_i32, int sk, const void* delta_f16,
+                                      const void* p_wscales_f16, const void* p_ascales_f16, const void* p_wszs_f16,
+                                      const void* p_asums_f16, const void* gamma_f16, void* sum_f16, void* scale_f16, float eps,
+                                      const void* qweight, const void* wscales_f16, const void* w_szs_f16, void* out_f16,
+                                      long long out_row_stride, void* amax_slots_u32, void* sync_u32, void* err_u32, int M, int N,
+                                      int K, void* clk_u64, void* stream);
+int omni_w4a8_per_group_norm_gemm_fused(void* codes_i8, void* residual_f16, const void* slab_i32, int sk, const void* delta_f16,
+                                        const void* p_wscales_f16, const void* p_ascales_f16, const void* gamma_f16,
+                                        void* sum_f16, void* scale_f16, float eps, const void* qweight, const void* zeros_i8,
+                                        const void* scales_i8, const void* wscales_f16, void* out_f16, long long out_row_stride,
+                                        void* amax_slots_u32, void* sync_u32, void* err_u32, int M, int N, int K, void* clk_u64,
+                                        void* stream);
+
 /* Fused extension (round 4): omni_kv4_decode_attention_partial + omni_attn_merge_f16_amax as ONE launch.  Every split
  * workgroup writes its partial through, takes a ticket of its (sequence, head group), and the last arriver merges the splits
  * (the merge kernels' arithmetic), stores the fp16 [B, Hq * 128] output and raises the row maxima; an armed L2 prefetch rides

@@ -96,6 +96,11 @@ PROTOTYPES = {
     "omni_kv4_decode_attention_fine_grained": (_i, [_vp, _vp, _vp, _vp, _i64, _i64] + [_vp] * 6 + [_i] * 16 + [_vp, _i, _vp, _sz, _vp]),
     "omni_kv8_prefill_write_per_tensor": (_i, [_vp] * 8 + [_i] * 15 + [_vp, _i, _i, _vp]),
     "omni_kv8_decode_attention_per_tensor": (_i, [_vp, _vp, _vp, _vp, _i64, _i64] + [_vp] * 8 + [_i] * 16 + [_vp, _i, _vp, _sz, _vp]),
+    "omni_norm_gemm_fused_ok": (_i, [_i, _i, _i, _i, _i]),
+    "omni_w4a8_per_chn_norm_gemm_fused": (_i, [_vp, _vp, _vp, _i] + [_vp] * 8 + [_f] + [_vp] * 4 + [_c.c_longlong, _vp, _vp, _vp,
+                                                _i, _i, _i, _vp, _vp]),
+    "omni_w4a8_per_group_norm_gemm_fused": (_i, [_vp, _vp, _vp, _i] + [_vp] * 6 + [_f] + [_vp] * 5 + [_c.c_longlong, _vp, _vp, _vp,
+                                                  _i, _i, _i, _vp, _vp]),
     "omni_kv4_decode_attention": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp] + [_i] * 7 + [_vp, _i, _vp, _sz, _vp]),
 }
 

@@ -447,3 +447,43 @@ def select_topk_pages(out, scores, subs_per_page, total_pages, k):
     rc = _lib.lib().omni_select_topk_pages(out.data_ptr(), scores.data_ptr(), scores.stride(1), B * H,
                                            int(subs_per_page), int(total_pages), int(k), _lib.current_stream())
     _lib.check(rc, "fused_ext.select_topk_pages")
+
+
+# ---- round 6: (norm -> GEMV) pairs as one launch (csrc/norm_gemv_fused.h) -------------------------------------------
+NGF_SYNC_WORDS = 32     # per call site: arrival counter + the rows' {scale, sum} pairs; zeroed by the caller before every launch
+
+
+def norm_gemm_fused_ok(M, N, K, group_size=-1, silu=False):
+    """True when omni_w4a8_per_*_norm_gemm_fused takes the shape and its whole grid is resident on this device."""
+    return _lib.lib().omni_norm_gemm_fused_ok(int(M), int(N), int(K), 0 if group_size == -1 else 1, 1 if silu else 0) == 1
+
+
+def norm_gemm_fused(codes, residual, gamma, input_sum, scaling, epsilon, lin, out, sync, err, slab=None, sk=0, delta=None,
+                    producer=None, p_ascales=None, p_asums=None, amax=None, clk=None):
+    """rows: residual (+= epilogue(sum of `sk` split-K slabs of `producer`) | += delta | as is) -> rms_norm_general[_fuse_sum] ->
+    codes / scaling / input_sum; tiles: out = lin(codes) (amax given: out = silu_and_mul(lin(codes)) [M, N/2], row maxima
+    raised) -- ONE launch, bit-identical to the two (three) reference calls.  `lin` / `producer`: objects with qweight,
+    s1_scales and s1_szeros (per-channel) or s2_zeros / s2_scales (per-group).  `sync`: NGF_SYNC_WORDS zeroed uint32 words."""
+    _lib.require_cuda(codes, residual, gamma, input_sum, scaling, out, sync, err, slab, delta, amax, clk)
+    M, K = residual.shape
+    N = lin.qweight.shape[0]
+    per_chn = getattr(lin, "group", -1) == -1
+    st = _lib.current_stream()
+    if slab is not None:
+        p_ws = producer.s1_scales.data_ptr()
+        p_wsz = producer.s1_szeros.data_ptr() if per_chn else None
+    else:
+        p_ws = p_wsz = None
+    if per_chn:
+        rc = _lib.lib().omni_w4a8_per_chn_norm_gemm_fused(
+            codes.data_ptr(), residual.data_ptr(), _ptr(slab), int(sk), _ptr(delta), p_ws, _ptr(p_ascales), p_wsz,
+            _ptr(p_asums), gamma.data_ptr(), _ptr(input_sum), scaling.data_ptr(), float(epsilon), lin.qweight.data_ptr(),
+            lin.s1_scales.data_ptr(), lin.s1_szeros.data_ptr(), out.data_ptr(), out.stride(0), _ptr(amax), sync.data_ptr(),
+            err.data_ptr(), M, N, K, _ptr(clk), st)
+    else:
+        rc = _lib.lib().omni_w4a8_per_group_norm_gemm_fused(
+            codes.data_ptr(), residual.data_ptr(), _ptr(slab), int(sk), _ptr(delta), p_ws, _ptr(p_ascales), gamma.data_ptr(),
+            _ptr(input_sum), scaling.data_ptr(), float(epsilon), lin.qweight.data_ptr(), lin.s2_zeros.data_ptr(),
+            lin.s2_scales.data_ptr(), lin.s1_scales.data_ptr(), out.data_ptr(), out.stride(0), _ptr(amax), sync.data_ptr(),
+            err.data_ptr(), M, N, K, _ptr(clk), st)
+    _lib.check(rc, "fused_ext.norm_gemm_fused")

@@ -20,7 +20,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libomniserve_hip.so")
 ARCH = "gfx950"
 SOURCES = ["qgemm_plan.hip", "qgemm_chn.hip", "qgemm_grp.hip", "qgemm_w8.hip",
-           "elementwise.hip", "offpath.hip", "kv_cache.hip", "attn_prefill.hip", "sparse_utils.hip", "tp_comm.hip", "row_dtypes.hip"]
+           "elementwise.hip", "offpath.hip", "kv_cache.hip", "attn_prefill.hip", "sparse_utils.hip", "tp_comm.hip", "row_dtypes.hip", "norm_gemv_fused.hip"]
 # -ffp-contract=off: the fp32 epilogues / quantisers must round exactly like oracle/ (explicit
 # fma where wanted).  No -ffast-math anywhere.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

@@ -154,7 +154,12 @@ class DecodeRunner:
         # 3 is the default (fused=True) where it applies: batch <= 16, one GPU.
         # (A level 4 -- the MLP half of a layer as ONE persistent launch with in-kernel hand-offs -- was built in round 4, measured
         #  slower than level 3 (2.37 vs 2.17 ms per step) and moved out of the product: tools/experiments/mlp_fused.hip, HISTORY.md.)
-        self.fused = 3 if fused is True else min(int(fused), 3)
+        # 4 (round 6) = 3 with the two 1 -> N edges of the layer as single launches: (add + norm + quant) -> qkv and
+        # (add + norm + quant) -> gate_up + SiLU (fused_ext.norm_gemm_fused, csrc/norm_gemv_fused.h: the rows and the GEMV's tiles in
+        # one grid, the tiles request their whole weight part and then wait for the rows): 5 launches per layer, same bits.
+        self.fused = 4 if fused is True else min(int(fused), 4)
+        want_pairs = self.fused >= 4
+        self.fused = min(self.fused, 3)
         # the attention-side fusions of level 2 (split merge inside the quantiser, q / k / v from the qkv projection's slabs)
         # involve no row-parallel projection, so they also apply under tensor parallelism, where the level drops to 1
         self.l2_attn = self.fused >= 2 and batch <= 128 and bool(tp_l2_attn)
@@ -176,6 +181,10 @@ class DecodeRunner:
         # whether the GEMV on a prefetched tensor then uses plain instead of non-temporal weight loads (per call: the arm
         # names the tensor, omni_prefetch_arm_gemm; un-armed projections always stream non-temporally).  Defaults: on with the fused
         # entry points (prefetch_mb / prefetch_blocks / weight_policy arguments for sweeps).
+        # level 4 where level 3 applies and both pair forms take the shapes (M <= 16, hidden <= 4096, grids resident at once)
+        self.pairs = (want_pairs and self.fused >= 3 and int(max_fused) >= 4 and
+                      fused_ext.norm_gemm_fused_ok(batch, (self.hl + 2 * self.kl) * cfg.head_dim, cfg.hidden, cfg.group_size, False) and
+                      fused_ext.norm_gemm_fused_ok(batch, 2 * self.il, cfg.hidden, cfg.group_size, True))
         if prefetch_mb is None:
             # measured (profiles/r02_*): +6-7 % at bs = 16 with 28-40 MiB per row kernel (the L2s hold 32 MiB; the
             # excess lands in MALL), nothing at bs = 128, -4 % at bs = 64 where the row kernels are no longer idle
@@ -264,7 +273,13 @@ class DecodeRunner:
         self.attn_f16 = torch.empty((B, hl * c.head_dim), dtype=f16, device=device)
         # row-maximum candidates of the level-3 path: [layer][0 = attention output, 1 = MLP activation][AMAX_WORDS], zeroed once
         # per step (the producers raise them with atomicMax)
-        self.amax = torch.zeros((c.layers, 2, fused_ext.AMAX_WORDS), dtype=torch.int32, device=device)
+        # (one buffer with the level-4 hand-off words behind them: [layer][0 = norm -> qkv, 1 = norm -> gate_up][NGF_SYNC_WORDS]
+        #  arrival counters + row pairs -- the step's first kernel zeroes all of it)
+        n_amax = c.layers * 2 * fused_ext.AMAX_WORDS
+        self._step_words = torch.zeros((n_amax + c.layers * 2 * fused_ext.NGF_SYNC_WORDS,), dtype=torch.int32, device=device)
+        self.amax = self._step_words[:n_amax].view(c.layers, 2, fused_ext.AMAX_WORDS)
+        self.ngf_sync = self._step_words[n_amax:].view(c.layers, 2, fused_ext.NGF_SYNC_WORDS)
+        self.ngf_err = torch.zeros((4,), dtype=torch.int32, device=device)      # sticky: a hand-off wait gave up (check())
         # level 3: the norm in front of gate_up prefetches ALL of DOWN's weights (29.6 MB fit the 32 MB of L2s) instead of
         # the head of gate_up's 58.7 MB; gate_up then streams cold with non-temporal loads (they do not displace the
         # prefetched lines) and down reads L2: 2.322-2.334 -> 2.294-2.314 ms per step on the same box (profiles/r03_g;
@@ -349,6 +364,9 @@ class DecodeRunner:
         """Raises if a peer wait of the last step timed out (tensor parallel, tp_comm = "peer").  Synchronises."""
         if self.comm is not None:
             self.comm.check_error()
+        if self.pairs and int(self.ngf_err[0].item()) != 0:
+            raise RuntimeError("DecodeRunner: a (norm -> GEMV) hand-off wait gave up (rows never arrived); the step's outputs "
+                               "are NaN")
 
     def read_tokens(self):
         """The tokens of the last step on the host (synchronises).  Under tensor parallelism with the library's own
@@ -409,7 +427,7 @@ class DecodeRunner:
         c = self.cfg
         if self.fused:     # one launch: embedding rows (torch's index_select takes 12.6 us for 16 rows) + lengths += 1 + the
             fused_ext.decode_step_begin(self.x, self.embed, self.tokens, self.lengths,      # step's row-maximum slots zeroed
-                                        self.amax if self.fused >= 3 else None)
+                                        self._step_words if self.fused >= 3 else None)
         else:
             self.lengths.add_(1)
             torch.index_select(self.embed, 0, self.tokens, out=self.x)
@@ -425,9 +443,22 @@ class DecodeRunner:
         for li, L in enumerate(self.layers):
             qa_h, qa_i = self._q_hidden, self._q_inter
             l3 = self.fused >= 3 and (li < nl - 1 or self.last_l3)     # row-kernel-free MLP half in this layer
-            if self.arm_qkv:
+            if self.pairs and l3:
+                # level 4: (add + norm + quant) -> qkv as one launch (rows from the previous layer's down_proj slabs; first
+                # layer: the embedding rows as they are)
+                if pending is not None:
+                    sk, lin = pending
+                    fused_ext.norm_gemm_fused(qa_h, self.x, L["ln1"], mB, sB, c.eps, L["qkv"], self.qkv_buf, self.ngf_sync[li, 0],
+                                              self.ngf_err, slab=self.slab, sk=sk, producer=lin, p_ascales=sA, p_asums=mA)
+                    pending = None
+                else:
+                    fused_ext.norm_gemm_fused(qa_h, self.x, L["ln1"], mB, sB, c.eps, L["qkv"], self.qkv_buf, self.ngf_sync[li, 0],
+                                              self.ngf_err)
+            elif self.arm_qkv:
                 self._arm(L["qkv"], deferred=self.qkv_slabs)
-            if pending is not None:     # residual += down_proj(prev layer) [deferred epilogue], norm + quant
+            if self.pairs and l3:
+                pass
+            elif pending is not None:     # residual += down_proj(prev layer) [deferred epilogue], norm + quant
                 sk, lin = pending
                 self._consume(qa_h, sk, lin, sA, mA, L["ln1"], mB, sB)
                 pending = None
@@ -439,7 +470,9 @@ class DecodeRunner:
                 layernorm_ops.rms_norm_general_fuse_sum(qa_h, self.x, L["ln1"], mB, sB, c.eps, True)
             else:
                 layernorm_ops.rms_norm_general(qa_h, self.x, L["ln1"], sB, c.eps, True)
-            if self.qkv_slabs:      # slabs only; the attention kernel reads q / k / v from them (qkv_buf: shapes only)
+            if self.pairs and l3:
+                pass
+            elif self.qkv_slabs:      # slabs only; the attention kernel reads q / k / v from them (qkv_buf: shapes only)
                 lin = L["qkv"]
                 fused_ext.decode_arm_qkv_slabs(self.slab, self._partial(qa_h, lin), B, lin.n, 0, hq * d, (hq + hk) * d,
                                                lin.s1_scales, sB, lin.s1_szeros if per_chn else None,
@@ -471,6 +504,14 @@ class DecodeRunner:
                     sk = self._partial_f16(self.attn_f16, self.amax[li, 0], L["o"], mA, sA)
                 else:
                     sk = self._partial(self._q_attn, L["o"])
+                if self.pairs and l3:
+                    # level 4: (add + norm + quant) -> gate_up + SiLU as one launch; down_proj quantises on the fly
+                    G = L["gate_up"]
+                    fused_ext.norm_gemm_fused(qa_h, self.x, L["ln2"], mB, sB, c.eps, G, self.mlp_act, self.ngf_sync[li, 1],
+                                              self.ngf_err, slab=self.slab, sk=sk, producer=L["o"], p_ascales=sA, p_asums=mA,
+                                              amax=self.amax[li, 1])
+                    pending = (self._partial_f16(self.mlp_act, self.amax[li, 1], L["down"], mA, sA), L["down"])
+                    continue
                 if l3 and self.pf_down:
                     self._arm(L["down"], deferred=True)
                 else:
