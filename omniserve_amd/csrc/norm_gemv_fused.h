@@ -69,12 +69,11 @@ struct NormGemvArgs {
 __device__ __forceinline__ uint32_t ngf_ld_agent(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// 16 bytes with two agent-scope (sc1) 8-byte loads: bypasses this CU's L1 (the producer stored write-through)
-__device__ __forceinline__ uint4 ngf_ld16_agent(const void* p) {
-  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+// 16 bytes with ONE agent-scope load (buffer_load_dwordx4 ... sc1: bypasses this CU's L1; the producer stored write-through).
+// A raw buffer load, because hipcc has no 16-byte atomic load and counts the builtin like any other load (aux 16 = sc1).
+__device__ __forceinline__ uint4 ngf_ld16_agent(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+  const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16);
+  return make_uint4((uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
 }
 
 // sink of the row body: codes written through (8-byte agent-scope stores), scale / sum kept for the pair word
@@ -114,8 +113,12 @@ __global__ __launch_bounds__(NGF_THREADS, 2) void norm_gemv_fused_kernel(NormGem
     const int row = blockIdx.x;
     const Src src = src0.at_row(row);
     SinkHandoff sink{a.codes + (size_t)row * a.K, a.sum_out, a.scale_out, row, 0u, 0u};
-    general_norm_v2_row<NGF_THREADS, RV, FUSE_SUM, Src, SinkHandoff>(src, a.gamma, sink, a.eps, a.K, a.nv,
-                                                                     reinterpret_cast<float*>(&lds_all[0][0][0]), red);
+    struct Hook {
+      const NormGemvArgs& a;
+      __device__ __forceinline__ void loaded() const { NGF_CLK(5); }
+    };
+    general_norm_v2_row<NGF_THREADS, RV, FUSE_SUM, Src, SinkHandoff, Hook>(src, a.gamma, sink, a.eps, a.K, a.nv,
+                                                                           reinterpret_cast<float*>(&lds_all[0][0][0]), red, Hook{a});
     NGF_CLK(1);
     if (threadIdx.x == 0)
       __hip_atomic_store(a.sync + 16 + row, sink.scale_bits | (sink.sum_bits << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -188,33 +191,35 @@ __global__ __launch_bounds__(NGF_THREADS, 2) void norm_gemv_fused_kernel(NormGem
   NGF_CLK(2);
   const uint32_t pairw = ngf_ld_agent(a.sync + 16 + (mcol < a.M ? mcol : a.M - 1));
 
-  // ---- activation rounds: codes (sc1 loads) -> LDS in the weights' k order (w4a8_gemv_kernel's image) -----------
-  uint4 areg[APT];
+  // ---- activation rounds: codes (sc1 loads) -> LDS in the weights' k order (w4a8_gemv_kernel's image).  BOTH rounds are
+  //      requested at once (each one after the other cost a second exposed round trip behind the gate: timeline r06_b) ----
+  const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(a.codes, 0, a.M * a.K, 0x00020000);
+  uint4 areg[2][APT];
   auto piece = [&](int j, int& m, int& kk) {
     m = 4 * (j / CPR) + (lane >> 4);
     kk = (lane & 15) + 16 * (j % CPR);
   };
-  auto load_a = [&](int kr) {
+  auto load_a = [&](int r, int kr) {
 #pragma unroll
     for (int j = 0; j < APT; ++j) {
       int m, kk;
       piece(j, m, kk);
       const int mc = m < a.M ? m : a.M - 1;               // rows >= M re-read the last row (never stored)
       const int k = kr + kk * 16;
-      areg[j] = ngf_ld16_agent(a.codes + (size_t)mc * a.K + (k < a.K ? k : 0));
+      areg[r][j] = ngf_ld16_agent(crsrc, (uint32_t)(mc * a.K + (k < a.K ? k : 0)));
     }
   };
-  auto store_a = [&](int buf) {
+  auto store_a = [&](int r) {
 #pragma unroll
     for (int j = 0; j < APT; ++j) {
       int m, kk;
       piece(j, m, kk);
       const int kp = kk >> 2, tp = (kk >> 1) & 1, d = kk & 1;
-      uint8_t* dst = &lds[buf][(kp * MT + m) * 64 + tp * 8 + d * 4];
-      *reinterpret_cast<uint32_t*>(dst + ((0 + kp) & 3) * 16) = areg[j].x;
-      *reinterpret_cast<uint32_t*>(dst + ((1 + kp) & 3) * 16) = areg[j].y;
-      *reinterpret_cast<uint32_t*>(dst + ((2 + kp) & 3) * 16) = areg[j].z;
-      *reinterpret_cast<uint32_t*>(dst + ((3 + kp) & 3) * 16) = areg[j].w;
+      uint8_t* dst = &lds[r][(kp * MT + m) * 64 + tp * 8 + d * 4];
+      *reinterpret_cast<uint32_t*>(dst + ((0 + kp) & 3) * 16) = areg[r][j].x;
+      *reinterpret_cast<uint32_t*>(dst + ((1 + kp) & 3) * 16) = areg[r][j].y;
+      *reinterpret_cast<uint32_t*>(dst + ((2 + kp) & 3) * 16) = areg[r][j].z;
+      *reinterpret_cast<uint32_t*>(dst + ((3 + kp) & 3) * 16) = areg[r][j].w;
     }
   };
   v4i acc[4];
@@ -245,14 +250,14 @@ __global__ __launch_bounds__(NGF_THREADS, 2) void norm_gemv_fused_kernel(NormGem
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab) acc[ab] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[ab], bf, acc[ab], 0, 0, 0);
   };
-  load_a(k_begin);
+  load_a(0, k_begin);
+  if (nsteps > AR) load_a(1, k_begin + RK);
   store_a(0);
-  if (nsteps > AR) load_a(k_begin + RK);                  // the second round's codes fly under the first round's MFMAs
+  if (nsteps > AR) store_a(1);
 #pragma unroll
   for (int s = 0; s < AR; ++s)
     if (s < nsteps) step(s, lds[0]);
   if (nsteps > AR) {
-    store_a(1);
 #pragma unroll
     for (int s = AR; s < RING; ++s)
       if (s < nsteps) step(s, lds[1]);

@@ -75,7 +75,7 @@ int launch_one(const NormGemvArgs& a, const Src& src, int grid, hipStream_t st) 
 template <int MODE, bool FUSE_SUM, typename Src>
 int launch_src(const NormGemvArgs& a, const Src& src, hipStream_t st) {
   const bool silu = a.amax != nullptr;
-  const int grid = a.M + (silu ? a.N / 128 : a.N / 64);
+  const int grid = a.M + a.N / 64;      // (SiLU form: tile = tile row g of the gate half + tile row g of the up half)
   const bool rv2 = a.K > NGF_THREADS * VT;
   if (silu) return rv2 ? launch_one<MODE, 1, 2, FUSE_SUM, Src>(a, src, grid, st) : launch_one<MODE, 1, 1, FUSE_SUM, Src>(a, src, grid, st);
   return rv2 ? launch_one<MODE, 0, 2, FUSE_SUM, Src>(a, src, grid, st) : launch_one<MODE, 0, 1, FUSE_SUM, Src>(a, src, grid, st);
@@ -97,7 +97,7 @@ bool shape_ok(int M, int N, int K, int mode, bool silu) {
 extern "C" int omni_norm_gemm_fused_ok(int M, int N, int K, int mode, int silu) {
   if (mode != MODE_CHN && mode != MODE_GRP) return 0;
   if (!shape_ok(M, N, K, mode, silu != 0)) return 0;
-  const int grid = M + (silu ? N / 128 : N / 64);
+  const int grid = M + N / 64;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
   return 2LL * cus >= grid ? 1 : 0;

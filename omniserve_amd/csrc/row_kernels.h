@@ -202,9 +202,11 @@ typedef SrcAttnMergeT<false> SrcAttnMerge;
 
 // `src`: the row's source (already at_row()); `sink`: where the row's int8 codes / fp16 scale / fp16 sum go (SinkGlobal:
 // the row kernels' own outputs; the fused MLP launch parks the codes in LDS and publishes them in MFMA operand order).
-template <int RT, int RV, bool FUSE_SUM, typename Src, typename Sink>
+struct NoRowHook { __device__ __forceinline__ void loaded() const {} };   // Hook::loaded(): the row's inputs are in (LDS copy written)
+template <int RT, int RV, bool FUSE_SUM, typename Src, typename Sink, typename Hook = NoRowHook>
 __device__ __forceinline__ void general_norm_v2_row(const Src& src, const half_t* __restrict__ gamma, Sink& sink,
-                                                    float eps, int hidden, int nv, float* xs, float* red) {
+                                                    float eps, int hidden, int nv, float* xs, float* red,
+                                                    const Hook& hook = Hook()) {
   const int p = threadIdx.x;
   OMNI_CLK(0);
   float x[RV][VT];
@@ -233,6 +235,7 @@ __device__ __forceinline__ void general_norm_v2_row(const Src& src, const half_t
     }
   }
   OMNI_CLK(1);
+  hook.loaded();
   __syncthreads();
   float st[2][VT], tv[2];
   ordered_partials<2>(xs, p, nv, hidden, st, [](float (&v)[2][VT], int e, float val) {

@@ -157,9 +157,11 @@ class DecodeRunner:
         # 4 (round 6) = 3 with the two 1 -> N edges of the layer as single launches: (add + norm + quant) -> qkv and
         # (add + norm + quant) -> gate_up + SiLU (fused_ext.norm_gemm_fused, csrc/norm_gemv_fused.h: the rows and the GEMV's tiles in
         # one grid, the tiles request their whole weight part and then wait for the rows): 5 launches per layer, same bits.
-        self.fused = 4 if fused is True else min(int(fused), 4)
-        want_pairs = self.fused >= 4
-        self.fused = min(self.fused, 3)
+        # Opt-in (fused=4): measured SLOWER than level 3 on the MI355X (2.24 vs 2.11 ms per step; profiles/r06_a: the hand-off --
+        # write-through publish + a poll behind the tile CUs' own weight requests + the activation round trip -- costs what the
+        # kernel boundary costs, and the rows run 1.5-3 us slower beside the stream), so fused=True still means level 3.
+        want_pairs = fused is not True and int(fused) >= 4
+        self.fused = 3 if fused is True else min(int(fused), 3)
         # the attention-side fusions of level 2 (split merge inside the quantiser, q / k / v from the qkv projection's slabs)
         # involve no row-parallel projection, so they also apply under tensor parallelism, where the level drops to 1
         self.l2_attn = self.fused >= 2 and batch <= 128 and bool(tp_l2_attn)
@@ -280,6 +282,7 @@ class DecodeRunner:
         self.amax = self._step_words[:n_amax].view(c.layers, 2, fused_ext.AMAX_WORDS)
         self.ngf_sync = self._step_words[n_amax:].view(c.layers, 2, fused_ext.NGF_SYNC_WORDS)
         self.ngf_err = torch.zeros((4,), dtype=torch.int32, device=device)      # sticky: a hand-off wait gave up (check())
+        self.ngf_clk = {}     # timeline probe (tools/pairs_ab.py): {(layer, site): int64 [grid, 8]} handed to that launch
         # level 3: the norm in front of gate_up prefetches ALL of DOWN's weights (29.6 MB fit the 32 MB of L2s) instead of
         # the head of gate_up's 58.7 MB; gate_up then streams cold with non-temporal loads (they do not displace the
         # prefetched lines) and down reads L2: 2.322-2.334 -> 2.294-2.314 ms per step on the same box (profiles/r03_g;
@@ -449,7 +452,8 @@ class DecodeRunner:
                 if pending is not None:
                     sk, lin = pending
                     fused_ext.norm_gemm_fused(qa_h, self.x, L["ln1"], mB, sB, c.eps, L["qkv"], self.qkv_buf, self.ngf_sync[li, 0],
-                                              self.ngf_err, slab=self.slab, sk=sk, producer=lin, p_ascales=sA, p_asums=mA)
+                                              self.ngf_err, slab=self.slab, sk=sk, producer=lin, p_ascales=sA, p_asums=mA,
+                                              clk=self.ngf_clk.get((li, 0)))
                     pending = None
                 else:
                     fused_ext.norm_gemm_fused(qa_h, self.x, L["ln1"], mB, sB, c.eps, L["qkv"], self.qkv_buf, self.ngf_sync[li, 0],
@@ -509,7 +513,7 @@ class DecodeRunner:
                     G = L["gate_up"]
                     fused_ext.norm_gemm_fused(qa_h, self.x, L["ln2"], mB, sB, c.eps, G, self.mlp_act, self.ngf_sync[li, 1],
                                               self.ngf_err, slab=self.slab, sk=sk, producer=L["o"], p_ascales=sA, p_asums=mA,
-                                              amax=self.amax[li, 1])
+                                              amax=self.amax[li, 1], clk=self.ngf_clk.get((li, 1)))
                     pending = (self._partial_f16(self.mlp_act, self.amax[li, 1], L["down"], mA, sA), L["down"])
                     continue
                 if l3 and self.pf_down:

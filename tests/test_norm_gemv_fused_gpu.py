@@ -188,7 +188,7 @@ def test_norm_gemm_fused_refuses_what_it_does_not_cover():
     assert not fused_ext.norm_gemm_fused_ok(17, 6144, 4096)          # more than 16 rows
     assert not fused_ext.norm_gemm_fused_ok(16, 6144, 8192)          # a K part beyond the register ring
     assert not fused_ext.norm_gemm_fused_ok(16, 6144, 4096 + 64)     # K parts of whole k-steps
-    assert not fused_ext.norm_gemm_fused_ok(16, 64 * 1024, 4096)     # the grid would not be resident at once
+    assert not fused_ext.norm_gemm_fused_ok(16, 64 * 1024, 4096)     # the grid (1040 workgroups) would not be resident at once
     assert not fused_ext.norm_gemm_fused_ok(16, 6144 + 64, 4096, -1, True)
 
 

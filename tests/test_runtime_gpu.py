@@ -13,7 +13,8 @@ def _run(fused, graph, steps=3, group_size=-1, batch=5):
     cfg = LlamaConfig.tiny()
     cfg.group_size = group_size
     r = DecodeRunner(cfg, batch=batch, context=70, max_new=8, device=dev, seed=7, use_graph=graph, fused=fused)
-    assert r.fused == (int(fused) if batch <= 16 else min(int(fused), 2))     # level 3 needs the 16-row GEMV tile
+    assert r.fused == (min(int(fused), 3) if batch <= 16 else min(int(fused), 2))     # level 3 needs the 16-row GEMV tile
+    assert r.pairs == (int(fused) >= 4 and batch <= 16)     # level 4 = level 3 + the (norm -> GEMV) pairs as single launches
     toks = []
     for _ in range(steps):
         r.step()
@@ -26,9 +27,10 @@ def _run(fused, graph, steps=3, group_size=-1, batch=5):
 def test_fusion_levels_and_graph_agree_bitwise(group_size, batch):
     """(g128 at level 2 = the per-group partial GEMM + the slab-consuming norm; batch 40 = the 64-row GEMV tile; level 3 =
     no quantiser row kernels: SiLU in the gate_up epilogue, o / down quantising on the fly -- it falls back to 2 at batch 40;
-    batch 130 / 160 = the 128 x 256 tile with K slices over grid.y: slab-only form for o / down, split + slab epilogue elsewhere)"""
+    batch 130 / 160 = the 128 x 256 tile with K slices over grid.y: slab-only form for o / down, split + slab epilogue elsewhere;
+    level 4 = level 3 with (add + norm + quant) -> qkv and -> gate_up as single launches, csrc/norm_gemv_fused.h)"""
     ref_t, ref_x, ref_p = _run(0, False, group_size=group_size, batch=batch)
-    for fused, graph in [(1, False), (2, False), (2, True), (3, False), (3, True)]:
+    for fused, graph in [(1, False), (2, False), (2, True), (3, False), (3, True), (4, False), (4, True)]:
         t, x, pools = _run(fused, graph, group_size=group_size, batch=batch)
         assert torch.equal(t, ref_t), (fused, graph)
         assert torch.equal(x.view(torch.int16), ref_x.view(torch.int16)), (fused, graph)

@@ -132,7 +132,7 @@ def isolated(args, dev):
 def timeline(args, dev):
     for name, N, silu, copies in (("gate_up", 28672, True, 12), ("qkv", 6144, False, 40)):
         p = Pair(dev, args.batch, N, 4096, silu, copies)
-        grid = args.batch + (N // 128 if silu else N // 64)
+        grid = args.batch + N // 64
         clk = torch.zeros((grid, 8), dtype=torch.int64, device=dev)
         for i in range(copies):
             p.fused(i)       # rotate through the copies so that the probed launch streams from HBM
@@ -145,11 +145,35 @@ def timeline(args, dev):
         rows, tiles = c[:args.batch] - t0, c[args.batch:] - t0
         q = lambda v: "%6.2f /%6.2f /%6.2f" % (v.min(), np.median(v), v.max())  # noqa: E731
         print("%s  (grid %d; us after the first workgroup's start; min / median / max)" % (name, grid))
-        for k, what in ((0, "rows  start"), (1, "rows  body done"), (2, "rows  published")):
+        for k, what in ((0, "rows  start"), (5, "rows  inputs loaded"), (1, "rows  body done"), (2, "rows  published")):
             print("   %-22s %s" % (what, q(rows[:, k])))
         for k, what in ((0, "tiles start"), (1, "tiles ring requested"), (2, "tiles gate passed"), (3, "tiles K loop done"), (4, "tiles end")):
             print("   %-22s %s" % (what, q(tiles[:, k])))
         sys.stdout.flush()
+
+
+def step_timeline(args, dev):
+    """The same marks from INSIDE the captured decode step (layer 5's two pair launches)."""
+    cfg = LlamaConfig.llama3_8b(args.group_size)
+    r = DecodeRunner(cfg, args.batch, args.context, 64, dev, seed=1234, fused=4)
+    qkv_n = (cfg.heads + 2 * cfg.kv_heads) * cfg.head_dim
+    r.ngf_clk = {(5, 0): torch.zeros((args.batch + qkv_n // 64, 8), dtype=torch.int64, device=dev),
+                 (5, 1): torch.zeros((args.batch + 2 * cfg.inter // 64, 8), dtype=torch.int64, device=dev)}
+    for _ in range(8):
+        r.step()
+    torch.cuda.synchronize()
+    r.check()
+    for (li, site), clk in sorted(r.ngf_clk.items()):
+        c = clk.cpu().numpy().astype(np.float64) / 100.0
+        t0 = c[:, 0].min()
+        rows, tiles = c[:args.batch] - t0, c[args.batch:] - t0
+        q = lambda v: "%6.2f /%6.2f /%6.2f" % (v.min(), np.median(v), v.max())  # noqa: E731
+        print("in-step layer %d %s (grid %d)" % (li, "norm -> gate_up" if site else "norm -> qkv", c.shape[0]))
+        for k, what in ((0, "rows  start"), (5, "rows  inputs loaded"), (1, "rows  body done"), (2, "rows  published")):
+            print("   %-22s %s" % (what, q(rows[:, k])))
+        for k, what in ((0, "tiles start"), (1, "tiles ring requested"), (2, "tiles gate passed"), (3, "tiles K loop done"), (4, "tiles end")):
+            print("   %-22s %s" % (what, q(tiles[:, k])))
+    sys.stdout.flush()
 
 
 def main():
@@ -166,6 +190,7 @@ def main():
     dev = torch.device("cuda:0")
     if args.timeline:
         timeline(args, dev)
+        step_timeline(args, dev)
     if args.isolated:
         isolated(args, dev)
     if not args.no_step:
