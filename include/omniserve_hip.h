@@ -31,12 +31,15 @@ int omni_abi_version(void);
  * W4A8 / W8A8 GEMM         out[m,n] = fp16( epilogue( sum_k A[m,k] * W[n,k] ) )
  * -------------------------------------------------------------------------------------------- */
 
-/* Bytes of int32 split-K scratch the GEMM entry points may need for an (M,N,K) problem -- the plain entry points (which
- * return OMNI_ENOMEM when their plan splits K and the scratch is missing or smaller) AND the slab-only forms
- * (omni_*_gemm_partial, M <= 512: at least one M x N int32 slab even when K stays whole).  Callers keep one scratch buffer
- * per device/stream of at least this size (it is not persistent state: contents are dead after the call).
- * ABI 3 (omni_abi_version): before, M > 128 returned 0 for plans without a K split, which under-sized the slab-only forms. */
+/* Bytes of int32 split-K scratch for an (M,N,K) problem.  omni_gemm_workspace_bytes: the plain entry points (which return
+ * OMNI_ENOMEM when their plan splits K and the scratch is missing or smaller; 0 when no plan splits K).
+ * omni_gemm_partial_workspace_bytes: the slab-only forms (omni_*_gemm_partial[_f16], M <= 512: at least one M x N int32 slab
+ * even when K stays whole).  Both are the maximum over the three GEMM flavours and over every setting of
+ * omni_gemm_set_midm_override (mode and forced split), so a buffer sized once stays large enough.  Callers keep one scratch
+ * buffer per device/stream of at least this size (not persistent state: contents are dead after the call).
+ * ABI 4 (omni_abi_version): ABI 3 had one query for both (which pinned an M x N slab for plain calls at M = 129..512). */
 size_t omni_gemm_workspace_bytes(int M, int N, int K);
+size_t omni_gemm_partial_workspace_bytes(int M, int N, int K);
 
 /* Tuning / introspection hooks (tests and bench sweeps; not used by the serving path):
  * override the decode-shape plan (waves per workgroup: 1 or 4; K splits), 0/0 restores the

@@ -22,6 +22,7 @@ _vp, _i, _i64, _sz, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t, _c.c_fl
 PROTOTYPES = {
     "omni_abi_version": (_i, []),
     "omni_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "omni_gemm_partial_workspace_bytes": (_sz, [_i, _i, _i]),
     "omni_gemm_set_plan_override": (None, [_i, _i]),
     "omni_gemm_set_midm_override": (None, [_i, _i]),
     "omni_prefetch_arm_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i64, _i]),

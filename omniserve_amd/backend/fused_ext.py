@@ -295,19 +295,29 @@ def gemm_partial_f16_w8a8(act, amax, weight, slab, scale_out):
 _TICKETS = {}
 
 
+TICKET_WORDS = 4096
+
+
+def new_tickets(device):
+    """Ticket words of the single-launch decode attention: zero between launches (the last arriver resets its word).
+    include/omniserve_hip.h asks for one buffer per stream: a runner OWNS one (allocated once, before any capture) and hands it
+    to decode_attention_f16_amax -- two runners decoding concurrently on two streams then never share words, and a captured
+    graph holds no allocation made during capture (the per-(device, stream) cache below missed on torch's capture
+    stream and allocated + zero-filled inside the graph)."""
+    return torch.zeros((TICKET_WORDS,), dtype=torch.int32, device=device)
+
+
 def _tickets(device):
-    """Ticket words of the single-launch decode attention: zero between launches (the last arriver resets its word).  One buffer
-    per (device, stream) -- include/omniserve_hip.h asks for one per stream: two runners decoding concurrently on two streams
-    of one device must not share ticket words."""
-    key = (torch.device(device), int(torch.cuda.current_stream(device).cuda_stream))
+    """Fallback for callers that pass no buffer (tests, one-off calls): one buffer per (device, stream)."""
+    key = (torch.device(device), int(_lib.current_stream()))
     t = _TICKETS.get(key)
     if t is None:
-        t = _TICKETS[key] = torch.zeros((4096,), dtype=torch.int32, device=device)
+        t = _TICKETS[key] = new_tickets(device)
     return t
 
 
 def decode_attention_f16_amax(out_f16, amax, q, k, v, kv_pointers, lengths, tokens_per_block, timestep, rotary_base,
-                              single_launch=True):
+                              single_launch=True, tickets=None):
     """single_query_attention (KV4 + zeros, neox RoPE) writing the fp16 [B, Hq*Dh] output (the values
     single_query_attention returns) into out_f16 and raising the row maxima of |out| in `amax` -- the input pair of
     gemm_partial_f16_*.  single_launch: the last-arriving split workgroup of every (sequence, head group) merges the splits
@@ -323,7 +333,7 @@ def decode_attention_f16_amax(out_f16, amax, q, k, v, kv_pointers, lengths, toke
     need = _lib.lib().omni_kv4_decode_workspace_bytes(B, Hq, D, max_ctx)
     ws = _lib.workspace(need, q.device, "attn")
     if single_launch:
-        tk = _tickets(q.device)
+        tk = tickets if tickets is not None else _tickets(q.device)
         rc = _lib.lib().omni_kv4_decode_attention_f16_amax(
             out_f16.data_ptr(), amax.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0),
             kv_pointers.data_ptr(), lengths.data_ptr(), B, kv_pointers.shape[-1], Hq, Hkv, D, int(tokens_per_block), max_ctx,

@@ -24,7 +24,10 @@ SOURCES = ["qgemm_plan.hip", "qgemm_chn.hip", "qgemm_grp.hip", "qgemm_w8.hip",
 # -ffp-contract=off: the fp32 epilogues / quantisers must round exactly like oracle/ (explicit
 # fma where wanted).  No -ffast-math anywhere.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-function", "-I" + CSRC, "-I" + os.path.join(os.path.dirname(HERE), "include")]
+         "-Wall", "-Wno-unused-function",
+         # qgemm_midm.h's LDS-DMA statements name M0 as clobbered ("reserved register" warning, 1 240 of them per build): the M0
+         # discipline of those kernels is asserted on the disassembly instead (tests/test_code_objects_cpu.py)
+         "-Wno-inline-asm", "-I" + CSRC, "-I" + os.path.join(os.path.dirname(HERE), "include")]
 
 
 def _hipcc() -> str:

@@ -794,21 +794,25 @@ extern "C" int omni_silu_mul_quant_fuse_sum(void* out_i8, const void* in_f16, vo
   // kernel below took 13.6 us per layer at bs = 128 (128 workgroups, a serial loop of 56 vectors per thread; profiles/r05_f).
   {
     const int nv = norm_block(d, false);
-    if (d > 512 * 4 * VT && d <= 512 * 8 * VT && d % 8 == 0 && nv % 32 == 0 && nv <= 1024) {
+    // decode-size launches only (measured there; a many-row launch would run ONE 512-thread workgroup per CU at 112 - 128 KiB
+    // of LDS: those keep the kernel below -- ADVICE r5)
+    if (tokens < ROWS_MANY && d > 512 * 4 * VT && d <= 512 * 8 * VT && d % 8 == 0 && nv % 32 == 0 && nv <= 1024) {
       const PrefetchArgs pf = take_prefetch(tokens);
       const size_t lds = (size_t)d * sizeof(float);
+      bool raised_ok = true;
       auto launch = [&](auto kern, half_t* sum) {
-        static bool raised = false;      // (dynamic LDS beyond 64 KiB is an opt-in per kernel)
-        if (!raised) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-          raised = true;
+        // (dynamic LDS beyond 64 KiB is an opt-in per kernel AND per device: set on every call, like sparse_utils.hip does --
+        //  a process-wide flag missed the second device and raced between threads)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) {
+          raised_ok = false;
+          return;
         }
         hipLaunchKernelGGL(kern, dim3(tokens + pf.blocks), dim3(512), lds, (hipStream_t)stream, (int8_t*)out_i8,
                            SrcSilu{(const half_t*)in_f16, d}, sum, (half_t*)scale_f16, d, nv, pf);
       };
       if (sum_f16) launch(quant_v2_kernel<512, 8, true, SrcSilu>, (half_t*)sum_f16);
       else launch(quant_v2_kernel<512, 8, false, SrcSilu>, (half_t*)nullptr);
-      return omni_launch_status();
+      return raised_ok ? omni_launch_status() : OMNI_ELAUNCH;
     }
   }
   (void)take_armed_prefetch();

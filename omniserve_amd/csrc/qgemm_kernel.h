@@ -244,7 +244,9 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   constexpr int WL = (MODE == MODE_W8) ? 4 : 2;  // weight loads per lane per k-step
   // weight prefetch ring: a whole chunk (4 steps) ahead for the int4 modes (32 VGPRs); W8A8 rows are twice the bytes
   // (64 VGPRs for a chunk pushed the kernel over 256 VGPRs: 100 B/lane of scratch), so it runs two steps ahead
-  constexpr int WRING = MODE == MODE_CHN ? OMNI_GEMM_RING_CHN : OMNI_GEMM_RING_OTHER;
+  // (W8A8 on the 128-row tile: one step ahead -- with two the instantiation spilled 3 - 7 VGPRs to scratch; no product kernel may
+  //  spill, tests/test_code_objects_cpu.py.  This is the ragged-shape fallback: the models' shapes run w4a8_gemm_exact_kernel)
+  constexpr int WRING = MODE == MODE_CHN ? OMNI_GEMM_RING_CHN : ((MODE == MODE_W8 && MB == 8) ? 1 : OMNI_GEMM_RING_OTHER);
   uint4 wq[WRING][WL];
 
   // ---- activation staging --------------------------------------------------------------
@@ -826,6 +828,41 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
   };
   uint2 swv[ABW], szv[ABW];
   half_t sav[MB], asv[MB];
+  // 64-row tiles with the in-kernel epilogue: the operands (2 ABW + MB dwords per lane) are parked in LDS across the K loop --
+  // held in registers they pushed these instantiations to 4 - 10 spilled VGPRs (scratch traffic inside the loop); the park
+  // happens where the prologue waits for its first activation round anyway (loads return in order)
+  constexpr bool EPI_PARK = MB == 4 && !TO_SLAB && KW == 4;
+  constexpr int EPI_WORDS = 8;
+  static_assert(!EPI_PARK || (4 * ABW + MB <= EPI_WORDS), "parked epilogue operands");
+  __shared__ __attribute__((aligned(16))) uint32_t epi_park[EPI_PARK ? KW * MZ * 64 * EPI_WORDS : 4];
+  uint32_t* const my_park = epi_park + (EPI_PARK ? (threadIdx.x * EPI_WORDS) : 0);
+  auto park_epi = [&]() {
+    if constexpr (EPI_PARK) {
+      uint32_t w[EPI_WORDS] = {swv[0].x, swv[0].y, 0u, 0u, 0u, 0u, 0u, 0u};
+      if constexpr (MODE == MODE_CHN) { w[2] = szv[0].x; w[3] = szv[0].y; }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        uint32_t v = __builtin_bit_cast(uint16_t, sav[mb]);
+        if constexpr (MODE == MODE_CHN) v |= (uint32_t)__builtin_bit_cast(uint16_t, asv[mb]) << 16;
+        w[4 + mb] = v;
+      }
+      *reinterpret_cast<uint4*>(my_park) = make_uint4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<uint4*>(my_park + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  };
+  auto unpark_epi = [&]() {
+    if constexpr (EPI_PARK) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(my_park), hi = *reinterpret_cast<const uint4*>(my_park + 4);
+      swv[0] = make_uint2(lo.x, lo.y);
+      if constexpr (MODE == MODE_CHN) szv[0] = make_uint2(lo.z, lo.w);
+      const uint32_t h[4] = {hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        sav[mb] = __builtin_bit_cast(half_t, (uint16_t)(h[mb] & 0xFFFFu));
+        if constexpr (MODE == MODE_CHN) asv[mb] = __builtin_bit_cast(half_t, (uint16_t)(h[mb] >> 16));
+      }
+    }
+  };
   if constexpr (!TO_SLAB) {
 #pragma unroll
     for (int j = 0; j < ABW; ++j) {
@@ -906,6 +943,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
       compute_q();
     }
     store_a(0);
+    park_epi();
     if constexpr (WAVES > 1) __syncthreads();
     // ---- steady state ---------------------------------------------------------------------------
     for (int r = 0; r + 1 < rounds; ++r) {
@@ -967,6 +1005,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
   if constexpr (A16) {
     if (rounds == 0) compute_q();
   }
+  if (rounds == 0) park_epi();
   for (int st = rounds * RING; st < nsteps; ++st) {
     const int kn = k_begin + st * KSTEP;
     if constexpr (WAVES > 1) __syncthreads();
@@ -1018,6 +1057,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
       for (int ab = 0; ab < 4; ++ab) mine[(mb * 4 + ab) * 64 + lane] = acc[mb][ab];
     __syncthreads();
   }
+  unpark_epi();
   float rowmax[MB];     // EPI = 1: max |act| of row (mb, lane & 15) over the channels this lane finished
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) rowmax[mb] = 0.0f;
@@ -1172,10 +1212,15 @@ static void launch_variant(const GemmArgs& a, const GemmPlan& pl, hipStream_t st
   const bool out16 = (a.out_stride % 8) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
   if (MB == 8 && WAVES == 4 && exact_mode != 0 && a.M % 128 == 0 && a.N % 256 == 0 && a.K % KCHUNK == 0 && b.kslice >= a.K &&
       (size_t)a.M * a.K < ((size_t)1 << 32) && out16) {
-    if (OMNI_GEMM_EXACT_DMA && exact_mode != 2)
-      hipLaunchKernelGGL((w4a8_gemm_exact_kernel<MODE, true>), grid, dim3(256), 0, st, b);
-    else
+    // (the form that stages activations through registers -- OMNI_GEMM_EXACT=2, A/B -- exists in tuning builds only: the release
+    //  library launches the LDS-DMA form alone, and the register form's g128 / W8A8 instantiations spill)
+#if defined(OMNI_TUNING) || !OMNI_GEMM_EXACT_DMA
+    if (!(OMNI_GEMM_EXACT_DMA && exact_mode != 2)) {
       hipLaunchKernelGGL((w4a8_gemm_exact_kernel<MODE, false>), grid, dim3(256), 0, st, b);
+      return;
+    }
+#endif
+    hipLaunchKernelGGL((w4a8_gemm_exact_kernel<MODE, true>), grid, dim3(256), 0, st, b);
     return;
   }
   if (pl.sk > 1) {      // few tiles (decode at batch 129..512): K slices over grid.y -> int32 slabs -> the slab epilogue

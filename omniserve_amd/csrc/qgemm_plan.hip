@@ -48,7 +48,10 @@ GemmPlan plan_gemm(int M, int N, int K, int kalign, bool deferred, bool w8) {
   // 13.6 -> 12.6; g128 gate_up at M = 64 21.2 -> 19.5).
   // K split: one workgroup per CU and launch (its LDS rings fill the CU) -- the largest split that keeps the grid inside one
   // round of 256 and >= 4 chunks per slice (Llama-2-70B qkv, 80 tiles: 2 slices 28.5 us, 4 slices 34.7).
-  if (g_midm_mode != 0 && g_override_waves == 0 && g_override_sk == 0 && M > 32 && M <= 128 && N % 128 == 0 && K % KCHUNK == 0) {
+  // (the kernel addresses weights and activations with 32-bit lane offsets: matrices of 4 GiB and more keep the other tiles)
+  const bool midm_fits = (unsigned long long)N * K * (w8 ? 2 : 1) < (2ull << 32) && (unsigned long long)M * K < (1ull << 32);
+  if (g_midm_mode != 0 && g_override_waves == 0 && g_override_sk == 0 && M > 32 && M <= 128 && N % 128 == 0 && K % KCHUNK == 0 &&
+      midm_fits) {
     const long long weights = (long long)N * K;
     bool take = g_midm_mode > 0;
     if (g_midm_mode < 0) take = weights >= 80000000LL || (deferred && weights >= 50000000LL);
@@ -225,29 +228,45 @@ extern "C" int omni_gemm_rowfree_ok(int M, int hidden, int attn_dim, int inter, 
   return 1;
 }
 
-extern "C" size_t omni_gemm_workspace_bytes(int M, int N, int K) {
-  if (M < 1 || N < 64 || K < 64) return 0;
-  // Sized from the very plans the launches use: the maximum over the K alignments of the three GEMM flavours (64; 128 for
-  // per-group), over the plain / deferred (slab-only) variants and over the mid-M kernel on / off (so that a buffer sized
-  // once stays large enough under omni_gemm_set_midm_override).  Up to 512 rows the slab-only entry points
-  // (omni_*_gemm_partial) write their accumulators even when the plan keeps K whole: at least one slab.
+// Largest K split any plan of an (M, N, K) problem can take: the maximum over the K alignments of the three GEMM flavours (64;
+// 128 for per-group), over W4 / W8 rows and over the mid-M kernel off / forced on WITH every legal forced split (so that a
+// buffer sized once stays large enough under omni_gemm_set_midm_override(1, sk), whatever the mode was when it was sized;
+// the loop used to skip forced mode 1 and the forced sk).  `deferred`: the slab-only forms' plans.
+static int max_plan_sk(int M, int N, int K, bool deferred) {
   using namespace omni;
-  int sk = M <= 512 ? 1 : 0;
-  const int keep_mode = g_midm_mode;
+  int sk = 1;
+  const int keep_mode = g_midm_mode, keep_sk = g_midm_sk;
   for (int midm = 0; midm < 2; ++midm) {
-    g_midm_mode = midm ? (keep_mode == 0 ? 1 : keep_mode) : 0;
-    for (int kalign = 64; kalign <= 128; kalign *= 2) {
-      if (K % kalign != 0) continue;
-      for (int deferred = 0; deferred < 2; ++deferred) {
+    g_midm_mode = midm;
+    for (int force = midm ? 16 : 0; force >= 0; force = (force > 2 ? force - 1 : (force == 2 ? 0 : -1))) {
+      g_midm_sk = force;      // 0: the heuristic split; 2 .. 16: omni_gemm_set_midm_override(1, force)
+      for (int kalign = 64; kalign <= 128; kalign *= 2) {
+        if (K % kalign != 0) continue;
         for (int w8 = 0; w8 < 2; ++w8) {
-          const GemmPlan pl = plan_gemm(M, N, K, kalign, deferred != 0, w8 != 0);
-          if (pl.sk > 1 && pl.sk > sk) sk = pl.sk;
+          const GemmPlan pl = plan_gemm(M, N, K, kalign, deferred, w8 != 0);
+          if (pl.sk > sk) sk = pl.sk;
         }
       }
     }
   }
   g_midm_mode = keep_mode;
-  return (size_t)sk * M * N * sizeof(int32_t);
+  g_midm_sk = keep_sk;
+  return sk;
+}
+
+// plain entry points (omni_*_gemm): scratch only where a plan splits K (0 otherwise -- ADVICE r5: M = 129 .. 512 used to pin one
+// M x N slab here for the sake of the slab-only forms, which now have their own query)
+extern "C" size_t omni_gemm_workspace_bytes(int M, int N, int K) {
+  if (M < 1 || N < 64 || K < 64) return 0;
+  const int sk = max_plan_sk(M, N, K, false);
+  return sk > 1 ? (size_t)sk * M * N * sizeof(int32_t) : 0;
+}
+
+// slab-only forms (omni_*_gemm_partial[_f16], M <= 512): they write their int32 accumulators even when the plan keeps K whole
+extern "C" size_t omni_gemm_partial_workspace_bytes(int M, int N, int K) {
+  if (M < 1 || M > 512 || N < 64 || K < 64) return 0;
+  const int a = max_plan_sk(M, N, K, true), b = max_plan_sk(M, N, K, false);
+  return (size_t)(a > b ? a : b) * M * N * sizeof(int32_t);
 }
 
 // ---- fused extension: L2 weight prefetch riding on the next row kernel (common.h: PrefetchArgs) -------------------
@@ -315,4 +334,7 @@ extern "C" int omni_prefetch_arm_gemm(const void* weight, int M, int N, int K, i
 
 // 3: omni_gemm_set_weight_policy removed (the load policy is per call: omni_prefetch_arm_gemm mode bit 0x20);
 //    omni_gemm_workspace_bytes covers the slab-only forms (>= one slab up to 512 rows); omni_gemm_set_midm_override added.
-extern "C" int omni_abi_version(void) { return 3; }
+// 4: the slab-only forms have their own query (omni_gemm_partial_workspace_bytes) and omni_gemm_workspace_bytes is the plain
+//    entry points' again (0 without a K split); both cover every legal omni_gemm_set_midm_override; the (norm -> GEMV) pair
+//    entry points (omni_w4a8_per_*_norm_gemm_fused, omni_norm_gemm_fused_ok) added.
+extern "C" int omni_abi_version(void) { return 4; }

@@ -265,8 +265,9 @@ class DecodeRunner:
         self.act_sum = torch.empty((B,), dtype=f16, device=device)
         self.act_scale2 = torch.empty((B,), dtype=f16, device=device)  # written by quant kernels
         self.act_sum2 = torch.empty((B,), dtype=f16, device=device)
-        need = max(int(_lib.lib().omni_gemm_workspace_bytes(B, c.hidden, k)) for k in (hl * c.head_dim, il))
-        need = max(need, int(_lib.lib().omni_gemm_workspace_bytes(B, qkv_n, c.hidden)))     # (qkv slabs, see qkv_slabs)
+        pws = _lib.lib().omni_gemm_partial_workspace_bytes     # (slab-only forms: at least one M x N slab up to 512 rows)
+        need = max(int(pws(B, c.hidden, k)) for k in (hl * c.head_dim, il))
+        need = max(need, int(pws(B, qkv_n, c.hidden)))     # (qkv slabs, see qkv_slabs)
         self.slab = torch.empty((max(need, 1 << 20),), dtype=torch.uint8, device=device)  # deferred split-K partial sums
         self.qkv_buf = torch.empty((B, qkv_n), dtype=f16, device=device)
         self.proj_buf = torch.empty((B, c.hidden), dtype=f16, device=device)
@@ -282,6 +283,7 @@ class DecodeRunner:
         self.amax = self._step_words[:n_amax].view(c.layers, 2, fused_ext.AMAX_WORDS)
         self.ngf_sync = self._step_words[n_amax:].view(c.layers, 2, fused_ext.NGF_SYNC_WORDS)
         self.ngf_err = torch.zeros((4,), dtype=torch.int32, device=device)      # sticky: a hand-off wait gave up (check())
+        self.tickets = fused_ext.new_tickets(device)      # ticket words of the single-launch attention (this runner's stream)
         self.ngf_clk = {}     # timeline probe (tools/pairs_ab.py): {(layer, site): int64 [grid, 8]} handed to that launch
         # level 3: the norm in front of gate_up prefetches ALL of DOWN's weights (29.6 MB fit the 32 MB of L2s) instead of
         # the head of gate_up's 58.7 MB; gate_up then streams cold with non-temporal loads (they do not displace the
@@ -491,7 +493,7 @@ class DecodeRunner:
             if self.fused >= 3:     # merge as a wide kernel (fp16 + row maxima); o_proj quantises on the fly
                 fused_ext.decode_attention_f16_amax(self.attn_f16, self.amax[li, 0], q, k, v, self.block_tables[li],
                                                     self.lengths, self.tpb, self.max_context, c.rope_theta,
-                                                    single_launch=self.attn_single)
+                                                    single_launch=self.attn_single, tickets=self.tickets)
             elif self.fused >= 2 or self.l2_attn:   # attention with its split merge fused into the activation quant
                 fused_ext.decode_attention_quant_fuse_sum(self._q_attn, q, k, v, self.block_tables[li], self.lengths,
                                                           self.tpb, self.max_context, c.rope_theta, mA, sA)

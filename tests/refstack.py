@@ -128,9 +128,12 @@ class OracleLib:
 
     # ---- introspection / sizing ------------------------------------------------------------------------------
     def omni_abi_version(self):
-        return 3
+        return 4
 
     def omni_gemm_workspace_bytes(self, M, N, K):
+        return 1 << 16
+
+    def omni_gemm_partial_workspace_bytes(self, M, N, K):
         return 1 << 16
 
     def omni_kv4_decode_workspace_bytes(self, B, H, D, ctx):

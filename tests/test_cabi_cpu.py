@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(h, s), "library does not export %s" % s
     assert syms == set(_lib.PROTOTYPES), "ctypes prototypes out of sync with the header"
-    assert h.omni_abi_version() == 3
+    assert h.omni_abi_version() == 4
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():
@@ -123,8 +123,24 @@ def test_gemm_plans_of_the_baseline_decode_shapes():
     assert plan(128, 1280, 8192, 64)[2] > 1                 # 70B TP = 8 shard's qkv at bs = 128
     assert plan(4096, 4096, 4096, 64) == (8, 4, 1)          # prefill regime: 128 x 256 tiles, no split
     for (M, N, K) in ((16, 4096, 14336), (64, 4096, 14336), (128, 8192, 3584), (1, 6144, 4096), (16, 6144, 4096)):
-        assert lib.omni_gemm_workspace_bytes(M, N, K) >= M * N * 4
+        assert lib.omni_gemm_partial_workspace_bytes(M, N, K) >= M * N * 4
     assert lib.omni_gemm_workspace_bytes(4096, 4096, 4096) == 0
+    # ABI 4: the plain entry points pin nothing where no plan splits K (gate_up at bs = 256: 224 tiles, K whole), the slab-only
+    # forms always get their slab; both sizes hold under every forced mid-M plan
+    assert lib.omni_gemm_workspace_bytes(256, 28672, 4096) == 0
+    assert lib.omni_gemm_partial_workspace_bytes(256, 28672, 4096) >= 256 * 28672 * 4
+    assert lib.omni_gemm_partial_workspace_bytes(513, 4096, 4096) == 0
+    for (M, N, K) in ((128, 28672, 4096), (64, 4096, 14336), (96, 8192, 8192)):
+        plain, part = lib.omni_gemm_workspace_bytes(M, N, K), lib.omni_gemm_partial_workspace_bytes(M, N, K)
+        for forced in (2, 4, 7, 8, 14, 16):
+            lib.omni_gemm_set_midm_override(1, forced)
+            try:
+                for kalign in (64, 128):
+                    sk = plan(M, N, K, kalign)[2]
+                    assert plain >= (sk * M * N * 4 if sk > 1 else 0), (M, N, K, forced)
+                    assert part >= sk * M * N * 4, (M, N, K, forced)
+            finally:
+                lib.omni_gemm_set_midm_override(-1, 0)
     # fusion level 3's gate (the runners ask before their first step; ADVICE r3: a hidden = 5120 layer passed the old size
     # test and then failed in gemm_silu because its gate_up plan splits K across workgroups)
     assert lib.omni_gemm_rowfree_ok(16, 4096, 4096, 14336, 0) == 1 and lib.omni_gemm_rowfree_ok(16, 4096, 4096, 14336, 1) == 1

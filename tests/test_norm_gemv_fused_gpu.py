@@ -50,7 +50,7 @@ def _producer_slabs(M, H, Kp, seed):
     qw, s1h, szh = w4a8.pack_per_channel(u, z, s1)
     a, sa, asum = oe.quant_per_token(_x(M, Kp, seed + 1, 1.0), True)
     qw_d, s1_d, sz_d, a_d, sa_d, as_d = map(to_dev, (qw, s1h, szh, a, sa, asum))
-    need = int(_lib.lib().omni_gemm_workspace_bytes(M, H, Kp))
+    need = int(_lib.lib().omni_gemm_partial_workspace_bytes(M, H, Kp))
     slab = torch.empty((max(need, 1 << 20),), dtype=torch.uint8, device=dev())
     sk = fused_ext.gemm_partial_per_chn(a_d, qw_d, slab)
     return _Lin(qw_d, s1_d, sz_d), slab, sk, sa_d, as_d
@@ -151,7 +151,7 @@ def test_norm_gemm_fused_per_group(M, N, H, silu):
     pqw, ps1h, ps2s, ps2z = map(to_dev, w4a8.pack_per_group(pu, pz, ps2, ps1))
     pa, psa, _ = oe.quant_per_token(_x(M, Kp, 12, 1.0), False)
     pa_d, psa_d = to_dev(pa), to_dev(psa)
-    slab = torch.empty((max(int(_lib.lib().omni_gemm_workspace_bytes(M, H, Kp)), 1 << 20),), dtype=torch.uint8, device=dev())
+    slab = torch.empty((max(int(_lib.lib().omni_gemm_partial_workspace_bytes(M, H, Kp)), 1 << 20),), dtype=torch.uint8, device=dev())
     sk = fused_ext.gemm_partial_per_group(pa_d, pqw, ps2z, ps2s, slab)
     prod = _Lin(pqw, ps1h, None, ps2z, ps2s)
     u, z, s2, s1 = w4a8.synth_per_group(N, H, seed=M + 2)

@@ -55,7 +55,7 @@ class Pair:
         self.lins = [W4A8Linear(N, H, -1, gen, dev) for _ in range(copies)]
         self.prod = W4A8Linear(H, H, -1, gen, dev)
         a = torch.randint(-127, 128, (M, H), dtype=torch.int8, device=dev, generator=gen)
-        self.slab = torch.empty((max(int(_lib.lib().omni_gemm_workspace_bytes(M, H, H)), 1 << 20),), dtype=torch.uint8, device=dev)
+        self.slab = torch.empty((max(int(_lib.lib().omni_gemm_partial_workspace_bytes(M, H, H)), 1 << 20),), dtype=torch.uint8, device=dev)
         self.sk = fused_ext.gemm_partial_per_chn(a, self.prod.qweight, self.slab)
         f16 = torch.float16
         self.p_sa = (torch.rand((M,), device=dev, generator=gen) * 0.01 + 0.001).to(f16)
