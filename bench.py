@@ -259,6 +259,14 @@ def roofline_gate_up(runner, ms_per_step=None):
     return out
 
 
+def _step_roofline(cfg, weight_bytes, kv_bytes, ms_per_step, tp=1):
+    """roofline.step of a secondary leg: W4A8 weights + KV4 pages + fp16 lm_head of ONE decode step over its measured time,
+    as a fraction of the HBM peak (every leg prints its own step fraction)."""
+    sb = int(weight_bytes) + int(kv_bytes) + 2 * cfg.vocab * cfg.hidden
+    return {"bytes": sb, "achieved_GBps": round(sb / (ms_per_step * 1e-3) / 1e9, 1),
+            "step_frac": round(sb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "peak_GBps": HBM_PEAK_GBS}
+
+
 def mid_m_leg(device):
     """The decode GEMM between the GEMV and the prefill regime: Llama-3-8B gate_up [28672, 4096] per-channel at
     M = 64 / 128 (w4a8_midm_kernel, csrc/qgemm_midm.h) and 256 (the 128 x 256 prefill tile), weights rotated over 6 copies
@@ -329,6 +337,9 @@ def protocol_leg(cfg, args, device, batch=None, fused=None):
                "tokens_per_s": round(B * gen / (t2 - t0), 1),
                "note": "B*512 / wall clock of (1 prefill + 511 decode graph replays, context 1024 -> 1535), second of "
                        "two rounds; the reference's published A100 figure (3005 tok/s, batch 256) follows the same protocol"}
+    # decode steps of the protocol: mean context (prompt + gen / 2) for the KV bytes
+    out["roofline_decode_step"] = _step_roofline(cfg, r.gemm_weight_bytes_per_step(), r.kv_bytes_per_step(args.context + gen // 2),
+                                                 out["decode_ms_per_step_mean"])
     if int(r.lengths[0]) != args.context + gen - 1:
         raise RuntimeError("protocol leg: unexpected final length %d" % int(r.lengths[0]))
     if not torch.isfinite(r.x.float()).all():
@@ -393,6 +404,7 @@ def configs2_leg(args, device, steps=32, warmup=6):
            "decode_tokens_per_s": round(64 / dt, 1), "fused_ext_level": r.fused,
            "gemm_weight_bytes_per_step": r.gemm_weight_bytes_per_step(),
            "kv_bytes_per_step": r.kv_bytes_per_step(args.context)}
+    out["roofline_step"] = _step_roofline(cfg, out["gemm_weight_bytes_per_step"], out["kv_bytes_per_step"], dt * 1e3)
     del r
     torch.cuda.empty_cache()
     out["protocol"] = protocol_leg(cfg, args, device, batch=64, fused=1)
@@ -474,12 +486,12 @@ def tp_rank_leg(device, tp=8, batch=128, context=1024, steps=16, warmup=4):
             raise RuntimeError("non-finite activations in the TP-shard decode step")
         if r.comm is not None:
             r.comm.check_error()
-        wb = r.gemm_weight_bytes_per_step()
+        wb = (r.gemm_weight_bytes_per_step(), r.kv_bytes_per_step(context))
         del r
         torch.cuda.empty_cache()
         return dt, wb
 
-    dt, wbytes = run(None)
+    dt, (wbytes, kvbytes) = run(None)
     # the same step with the library's own collective kernels in place (all-reduce folded into add + norm + quant), every
     # "peer" slot aliased to this rank's own buffer: what the collectives cost on the compute side, with no fabric traffic
     dt_loop, _ = run("loopback")
@@ -494,7 +506,8 @@ def tp_rank_leg(device, tp=8, batch=128, context=1024, steps=16, warmup=4):
                 tp, batch, context),
             "ms_per_step_compute_only": round(dt * 1e3, 3), "tokens_per_s_if_collectives_were_free": round(batch / dt, 1),
             "ms_per_step_with_peer_collective_kernels_loopback": round(dt_loop * 1e3, 3),
-            "gemm_weight_bytes_per_step": r.gemm_weight_bytes_per_step(),
+            "gemm_weight_bytes_per_step": r.gemm_weight_bytes_per_step(), "kv_bytes_per_step": kvbytes,
+            "roofline_step_compute_only": _step_roofline(cfg, wbytes, kvbytes, dt * 1e3),
             "all_reduce_calls_per_step": 2 * cfg.layers, "all_reduce_payload_bytes_per_step": ar_bytes}
 
 
@@ -517,6 +530,7 @@ def tp1_leg(device, batch=128, context=1024, steps=8, warmup=3):
     out = {"config": "Llama-2-70B W4A8KV4 per-channel, TP=1, bs=%d, context=%d" % (batch, context),
            "ms_per_step": round(dt * 1e3, 3), "tokens_per_s": round(batch / dt, 1), "fused_ext_level": r.fused,
            "gemm_weight_bytes_per_step": r.gemm_weight_bytes_per_step(), "kv_bytes_per_step": r.kv_bytes_per_step(context)}
+    out["roofline_step"] = _step_roofline(cfg, out["gemm_weight_bytes_per_step"], out["kv_bytes_per_step"], dt * 1e3)
     del r
     torch.cuda.empty_cache()
     return out
@@ -584,7 +598,7 @@ def cpu_baseline(cfg, batch):
         reps += 1
     dt = (time.perf_counter() - t0) / reps
     step_s = dt * cfg.layers
-    return {"value": round(batch / step_s, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
+    return {"value": round(batch / step_s, 2), "unit": "tokens/s", "cores": cores, "kind": "port (GEMMs only)",
             "gemm_4096": cpu_gemm_4096(),
             "sample": "oracle port (torch._int_mm int8 + fp32 epilogue) of the 4 per-channel W4A8 GEMMs of one "
                       "Llama-3-8B decoder layer at M=%d (rows padded to %d) on %d host threads, %d reps in %.1f s, "

@@ -463,7 +463,7 @@ int omni_kv4_prefill_write_fine_grained(
  * BASELINE configs[4] shards the row-parallel projections (o_proj, down_proj) over the GPUs of a node and sums their fp16
  * [tokens, hidden] outputs after each.  Besides torch.distributed's all-reduce (RCCL) the library has its own collective
  * over peer-mapped memory (csrc/tp_comm.h): every rank allocates ONE fine-grained buffer (omni_tp_alloc: two data slots
- * followed by 64 flag words, zeroed), exports it (omni_tp_ipc_handle, 64 bytes, exchanged by the host over any
+ * [+ a gather region for the two-shot form] followed by 64 flag words, zeroed), exports it (omni_tp_ipc_handle, 64 bytes, exchanged by the host over any
  * bootstrap channel) and maps the peers' (omni_tp_ipc_open).  A rank writes its partial projection into its own slot
  * (the projection's output pointer IS the slot), then one consumer launch both synchronises with the peers (flag words,
  * epochs in device memory: HIP-graph capturable, no host involvement) and reads their slots directly over xGMI:
@@ -472,18 +472,24 @@ int omni_kv4_prefill_write_fine_grained(
  *                                              no row sum) -- all-reduce + residual add + norm + quant in one launch.
  * peer_data / peer_flags: HOST arrays of `world` device pointers (rank p's data / flag words as mapped into this
  * process; entry `rank` is the caller's own buffer).  slot_offset_elems: fp16 offset of the slot of THIS call; slots must
- * alternate from call to call (tp_comm.h explains why two are enough).  Every rank issues the same sequence of calls. */
+ * alternate from call to call (tp_comm.h explains why two are enough).  Every rank issues the same sequence of calls.
+ * Two forms, bit-identical (same rank-order f32 sums, one rounding): ONE SHOT -- every rank reads every peer's whole slot,
+ * (world - 1) x payload per rank over the fabric: right for small payloads; TWO SHOTS (ABI 4) -- rank r reduces chunk r
+ * (1 / world of the vector; whole rows for the fused norm) into its GATHER region (gather_offset_elems: fp16 offset inside the
+ * rank's data buffer, room for ceil(count / world) elements rounded up to 8 (to whole rows); < 0 = there is none), the ranks
+ * meet a second time, then everyone reads the reduced chunks from their owners: 2 (world - 1) / world x payload per rank.
+ * algo: 0 = two shots from 512 KiB of payload on more than two ranks, 1 = one shot, 2 = two shots. */
 int omni_tp_alloc(size_t bytes, void** ptr_out);
 int omni_tp_free(void* ptr);
 int omni_tp_ipc_handle(void* ptr, void* handle64);
 int omni_tp_ipc_open(const void* handle64, void** ptr_out);
 int omni_tp_ipc_close(void* ptr);
 int omni_tp_allreduce_f16(void* out_f16, const void* const* peer_data, void* const* peer_flags, int rank, int world,
-                          long long slot_offset_elems, long long count, void* stream);
+                          long long slot_offset_elems, long long count, long long gather_offset_elems, int algo, void* stream);
 int omni_tp_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const void* const* peer_data,
                                           void* const* peer_flags, int rank, int world, long long slot_offset_elems,
                                           const void* weight_f16, void* sum_f16, void* scale_f16, float eps, int tokens,
-                                          int hidden, void* stream);
+                                          int hidden, long long gather_offset_elems, int algo, void* stream);
 
 /* ---- fused extension (nothing upstream): L2 weight prefetch --------------------------
  * The decode step alternates bandwidth-bound GEMVs with latency-bound row kernels (norm / quant, one workgroup per

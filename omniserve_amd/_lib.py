@@ -73,9 +73,10 @@ PROTOTYPES = {
     "omni_tp_ipc_handle": (_i, [_vp, _vp]),
     "omni_tp_ipc_open": (_i, [_vp, _c.POINTER(_vp)]),
     "omni_tp_ipc_close": (_i, [_vp]),
-    "omni_tp_allreduce_f16": (_i, [_vp, _c.POINTER(_vp), _c.POINTER(_vp), _i, _i, _c.c_longlong, _c.c_longlong, _vp]),
+    "omni_tp_allreduce_f16": (_i, [_vp, _c.POINTER(_vp), _c.POINTER(_vp), _i, _i, _c.c_longlong, _c.c_longlong, _c.c_longlong,
+                                   _i, _vp]),
     "omni_tp_add_rms_norm_general_fuse_sum": (_i, [_vp, _vp, _c.POINTER(_vp), _c.POINTER(_vp), _i, _i, _c.c_longlong, _vp, _vp,
-                                                   _vp, _f, _i, _i, _vp]),
+                                                   _vp, _f, _i, _i, _c.c_longlong, _i, _vp]),
     "omni_compute_padding_offsets": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "omni_kv4_prefill_write": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _i, _i, _vp]),
     "omni_kv4_decode_set_split_override": (None, [_i]),

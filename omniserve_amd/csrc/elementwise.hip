@@ -439,10 +439,31 @@ __global__ __launch_bounds__(RT) void tp_add_norm_v2_kernel(int8_t* __restrict__
                                                              float eps, int hidden, int nv) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   __shared__ float red[96];
-  const uint32_t e = tp_publish_and_wait(src0.tp);
+  uint32_t e = tp_publish_and_wait(src0.tp);
+  SinkGlobal sink{out + (size_t)blockIdx.x * hidden, sum_out, scale_out, (int)blockIdx.x};
+  if (src0.tp.two_shot) {
+    // two-shot form (tp_comm.h): chunk = whole rows; shot 1: the kernel's workgroups reduce THIS rank's rows into its gather
+    // region; shot 2: every row adds its reduced projection from the row's owner -- residual += delta, SrcAdd's arithmetic,
+    // the very expression SrcPeerAdd::finish applies to the sum: bit-identical to the one-shot form
+    const TpPeers& tp = src0.tp;
+    const long long count = (long long)gridDim.x * hidden;
+    const long long c0 = (long long)tp.rank * tp.chunk;
+    const long long mine_n = c0 >= count ? 0 : (count - c0 < tp.chunk ? count - c0 : tp.chunk);
+    half_t* gather = const_cast<half_t*>(tp_data_of(tp, tp.rank)) + tp.gather_off;
+    for (long long v = (long long)blockIdx.x * RT + threadIdx.x; v < mine_n / 8; v += (long long)gridDim.x * RT)
+      *reinterpret_cast<v8h*>(gather + v * 8) = tp_sum8(tp, (size_t)(c0 + v * 8), e);
+    if (tp_between_shots(tp, e)) {
+      const long long i0 = (long long)blockIdx.x * hidden;
+      const int owner = (int)(i0 / tp.chunk);
+      const SrcAdd row{src0.res + i0, tp_data_of(tp, owner) + tp.gather_off + (i0 - (long long)owner * tp.chunk), hidden};
+      general_norm_v2_row<RT, RV, FUSE_SUM, SrcAdd, SinkGlobal>(row, gamma, sink, eps, hidden, nv, xs, red);
+      tp_finish(tp, e);
+      return;
+    }
+    e = 0;       // a wait timed out: the row is poisoned below exactly as in the one-shot form
+  }
   SrcPeerAdd src = src0.at_row(blockIdx.x);     // (a local copy: writing the epoch into the kernel argument parked it in scratch)
   src.tp.epoch = e;         // 0 = a peer never arrived: the row is poisoned (NaN), the epoch stays
-  SinkGlobal sink{out + (size_t)blockIdx.x * hidden, sum_out, scale_out, (int)blockIdx.x};
   general_norm_v2_row<RT, RV, FUSE_SUM, SrcPeerAdd, SinkGlobal>(src, gamma, sink, eps, hidden, nv, xs, red);
   tp_finish(src0.tp, e);
 }
@@ -1003,9 +1024,11 @@ extern "C" int omni_attn_merge_f16_amax(void* out_f16, const void* part_ml_f32, 
 extern "C" int omni_tp_add_rms_norm_general_fuse_sum(void* out_i8, void* residual_f16, const void* const* peer_data,
                                                      void* const* peer_flags, int rank, int world,
                                                      long long slot_offset_elems, const void* weight_f16, void* sum_f16,
-                                                     void* scale_f16, float eps, int tokens, int hidden, void* stream) {
+                                                     void* scale_f16, float eps, int tokens, int hidden,
+                                                     long long gather_offset_elems, int algo, void* stream) {
   if (!out_i8 || !residual_f16 || !weight_f16 || !scale_f16 || !peer_data || !peer_flags || tokens < 0 || hidden < 1)
     return OMNI_EINVAL;
+  if (algo < 0 || algo > 2 || (algo == 2 && gather_offset_elems < 0) || hidden % 8 != 0) return OMNI_EINVAL;
   if (world < 1 || world > TP_MAX_WORLD || rank < 0 || rank >= world || slot_offset_elems < 0) return OMNI_EINVAL;
   const int nv = norm_block(hidden, true);
   if (!v2_ok(hidden, nv) || tokens > 256) return OMNI_EINVAL;     // (every token's workgroup must be resident: they meet at a ticket)
@@ -1019,6 +1042,13 @@ extern "C" int omni_tp_add_rms_norm_general_fuse_sum(void* out_i8, void* residua
     src.tp.flags[p] = (uint32_t*)peer_flags[q];
   }
   src.tp.rank = rank; src.tp.world = world; src.tp.slot_off = slot_offset_elems; src.tp.epoch = 1;
+  // two shots (tp_comm.h) from 512 KiB of payload on more than two ranks (algo 0), or forced (algo 2): chunk = whole rows
+  src.tp.gather_off = 0; src.tp.chunk = 0; src.tp.two_shot = 0;
+  if (gather_offset_elems >= 0 && algo != 1 && (algo == 2 || (world > 2 && (long long)tokens * hidden * 2 >= (512 << 10)))) {
+    src.tp.two_shot = 1;
+    src.tp.gather_off = gather_offset_elems;
+    src.tp.chunk = (long long)((tokens + world - 1) / world) * hidden;
+  }
   // this row kernel carries no L2-prefetch riders (its workgroups meet at a ticket and must all be resident): a descriptor
   // armed for "the next row kernel" is dropped here instead of riding on an unrelated launch later
   (void)take_armed_prefetch();

@@ -27,13 +27,28 @@ constexpr int TP_FLAG_WORDS = 64;      // per rank: [0, 8) arrival epochs writte
 constexpr int TP_W_EPOCH = 16;         // completed collectives of this rank
 constexpr int TP_W_TICKET = 17;        // workgroups of the running consumer kernel that finished
 constexpr int TP_W_ERROR = 18;         // != 0: a wait timed out
+constexpr int TP_W_TICKET2 = 19;       // two-shot form: workgroups of the running kernel that finished their part of the chunk
+constexpr int TP_W_ARR2 = 24;          // [24, 32): two-shot form, "rank p's reduced chunk of epoch e is in its gather region"
 
+// Two-shot form (payloads >= 512 KiB on more than two ranks; VERDICT r5: the one-shot form has every rank pull every peer's
+// FULL slot -- 7 x 2 MiB = 14 MiB per all-reduce at TP = 8, bs = 128 -- where reduce-scatter + all-gather moves 3.5 MiB):
+//   shot 1  rank r reduces chunk r of the vector (1/world of it, whole rows for the fused norm) from all peers' slots, in
+//           rank order in f32, ONE rounding, into its own GATHER region (peer-mapped like the slots);
+//   barrier the rank's workgroups meet on a ticket, the last one tells every peer "my chunk of epoch e is reduced";
+//   shot 2  every rank reads the reduced chunks from their owners.
+// Same sums, same single rounding, hence bit-identical to the one-shot form; bytes per rank over the fabric:
+// 2 (world - 1) / world x payload instead of (world - 1) x payload.  The gather region needs no double buffering: a rank
+// overwrites it in collective j + 1 only behind that collective's first barrier, which every peer passes only after its
+// kernel of collective j -- all reads of the region included -- has completed.
 struct TpPeers {
-  const half_t* data[TP_MAX_WORLD];    // rank p's data buffer (two slots), as mapped into THIS process
+  const half_t* data[TP_MAX_WORLD];    // rank p's data buffer (two slots [+ gather region]), as mapped into THIS process
   uint32_t* flags[TP_MAX_WORLD];       // rank p's flag words
   int rank, world;
   long long slot_off;                  // element offset of the slot this call uses
   uint32_t epoch;                      // filled in by the consumer kernel after tp_publish_and_wait (0 = timed out)
+  long long gather_off;                // element offset of the gather region (two-shot form)
+  long long chunk;                     // elements per rank's chunk (multiple of 8; rank r owns [r * chunk, (r + 1) * chunk))
+  int two_shot;
 };
 
 // Peer table lookups by a RUNTIME index: select chains over the constant indices, every element made opaque first (an empty
@@ -100,6 +115,41 @@ __device__ __forceinline__ uint32_t tp_publish_and_wait(const TpPeers& tp) {
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system-scope acquire: the peers' slots are readable from here on
   return s_fail ? 0u : s_epoch;
+}
+
+// Two-shot form, between the shots: every workgroup of the kernel has written its part of this rank's reduced chunk into the
+// gather region.  Release (every storing wave), meet on a ticket, the last arriver tells every peer; then wait until every
+// peer's chunk of epoch e is readable.  Returns false when a wait timed out (the caller poisons its output).
+__device__ __forceinline__ bool tp_between_shots(const TpPeers& tp, uint32_t e) {
+  __shared__ uint32_t s_fail2;
+  if (threadIdx.x == 0) s_fail2 = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // my stores into the gather region are visible to the peers ...
+  __syncthreads();
+  uint32_t* mine = tp_flags_of(tp, tp.rank);
+  if (threadIdx.x == 0) {
+    const uint32_t done = __hip_atomic_fetch_add(mine + TP_W_TICKET2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {                     // ... and so are those of every workgroup that arrived before me
+      __hip_atomic_store(mine + TP_W_TICKET2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int p = 0; p < tp.world; ++p)
+        __hip_atomic_store(tp_flags_of(tp, p) + TP_W_ARR2 + tp.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if ((int)threadIdx.x < tp.world && e != 0) {
+    uint32_t seen = tp_load_sys(mine + TP_W_ARR2 + threadIdx.x);
+    long long spins = 0;
+    while ((int32_t)(seen - e) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      seen = tp_load_sys(mine + TP_W_ARR2 + threadIdx.x);
+      if (++spins > (1ll << 23)) {
+        __hip_atomic_store(mine + TP_W_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_fail2 = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // the peers' gather regions are readable from here on
+  return s_fail2 == 0 && e != 0;
 }
 
 // Epilogue: the last workgroup of the kernel to get here advances this rank's epoch.

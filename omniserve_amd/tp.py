@@ -89,9 +89,11 @@ class PeerComm:
         def __init__(self, ptr, nbytes):
             self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
-    def __init__(self, rank, world, max_elems, device, group=None, loopback=False):
+    def __init__(self, rank, world, max_elems, device, group=None, loopback=False, algo="auto"):
         """loopback=True (single process, measurements only): every "peer" is this rank's own buffer, so a collective of
-        `world` ranks runs with all flags raised by the caller itself -- the kernels' cost without any fabric traffic."""
+        `world` ranks runs with all flags raised by the caller itself -- the kernels' cost without any fabric traffic.
+        algo: "auto" (two shots -- reduce-scatter into a gather region, then all-gather -- from 512 KiB of payload on more
+        than two ranks; one shot otherwise), "one_shot", "two_shot" (csrc/tp_comm.h; same bits either way)."""
         import ctypes
         import torch.distributed as dist
         from . import _lib
@@ -99,8 +101,13 @@ class PeerComm:
             raise ValueError("PeerComm supports up to 8 ranks")
         self.loopback = bool(loopback)
         self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
+        self.algo = {"auto": 0, "one_shot": 1, "two_shot": 2}[algo]
+        if loopback and self.algo == 0:
+            self.algo = 1      # (loopback aliases every peer's gather region to this rank's: one shot only)
         self.slot_elems = (int(max_elems) + 7) // 8 * 8
-        self.data_bytes = 2 * self.slot_elems * 2
+        # [slot 0 | slot 1 | gather region (two-shot form: this rank's reduced chunk; a whole slot keeps any row split legal) | flags]
+        self.gather_off = 2 * self.slot_elems
+        self.data_bytes = 3 * self.slot_elems * 2
         self.nbytes = self.data_bytes + 4 * self.FLAG_WORDS
         lib = _lib.lib()
         with torch.cuda.device(self.device):
@@ -153,7 +160,7 @@ class PeerComm:
         from . import _lib
         n = out.numel()
         rc = _lib.lib().omni_tp_allreduce_f16(out.data_ptr(), self._data, self._flags, self.rank, self.world,
-                                              self._next_slot_off(), n, _lib.current_stream())
+                                              self._next_slot_off(), n, self.gather_off, self.algo, _lib.current_stream())
         _lib.check(rc, "omni_tp_allreduce_f16")
 
     def add_rms_norm(self, out_i8, residual, weight, input_sum, scaling, epsilon):
@@ -165,7 +172,7 @@ class PeerComm:
         rc = _lib.lib().omni_tp_add_rms_norm_general_fuse_sum(
             out_i8.data_ptr(), residual.data_ptr(), self._data, self._flags, self.rank, self.world, self._next_slot_off(),
             weight.data_ptr(), None if input_sum is None else input_sum.data_ptr(), scaling.data_ptr(), float(epsilon),
-            tokens, hidden, _lib.current_stream())
+            tokens, hidden, self.gather_off, self.algo, _lib.current_stream())
         _lib.check(rc, "omni_tp_add_rms_norm_general_fuse_sum")
 
     def check_error(self, clear=False):

@@ -178,7 +178,7 @@ def _spawn2(target, args_of_rank):
     return ret
 
 
-def _peer_allreduce_rank(rank, world, port, shapes, ret):
+def _peer_allreduce_rank(rank, world, port, shapes, algo, ret):
     """PeerComm on its own: a sequence of all-reduces of different sizes, eagerly and from a replayed HIP graph."""
     import torch.distributed as dist
     from omniserve_amd import tp
@@ -187,7 +187,7 @@ def _peer_allreduce_rank(rank, world, port, shapes, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda:0")
-        comm = tp.PeerComm(rank, world, max(shapes), dev)
+        comm = tp.PeerComm(rank, world, max(shapes), dev, algo=algo)
         outs = []
         for rep, n in enumerate(shapes + shapes):                        # eager
             g = torch.Generator(device="cpu").manual_seed(1000 * rep + 17 * n + rank)
@@ -223,7 +223,7 @@ def _peer_allreduce_rank(rank, world, port, shapes, ret):
         dist.destroy_process_group()
 
 
-def _peer_stale_rank(rank, world, port, n, iters, ret):
+def _peer_stale_rank(rank, world, port, n, iters, algo, ret):
     """Every round: fresh values into the slot the peer read LAST time with ordinary cached loads (a torch reduction over
     the peer's mapped buffer = lines of the old contents planted in this process' caches), then the collective."""
     import torch.distributed as dist
@@ -233,7 +233,7 @@ def _peer_stale_rank(rank, world, port, n, iters, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda:0")
-        comm = tp.PeerComm(rank, world, n, dev)
+        comm = tp.PeerComm(rank, world, n, dev, algo=algo)
         peer = torch.as_tensor(tp.PeerComm._Blob(comm._mapped[0], comm.data_bytes), device=dev).view(torch.int16)   # both slots
         out = torch.empty((n,), dtype=torch.float16, device=dev)
         outs, planted = [], []
@@ -254,7 +254,7 @@ def _peer_stale_rank(rank, world, port, n, iters, ret):
         dist.destroy_process_group()
 
 
-def _peer_add_norm_rank(rank, world, port, cases, ret):
+def _peer_add_norm_rank(rank, world, port, cases, algo, ret):
     """PeerComm.add_rms_norm (the all-reduce folded into add + norm + quant) against all_reduce + the reference sequence, for row
     widths that take one, two and four vectors per thread (tp_add_norm_v2_kernel<512, 1 | 2 | 4>)."""
     import torch.distributed as dist
@@ -265,7 +265,8 @@ def _peer_add_norm_rank(rank, world, port, cases, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda:0")
-        comm = tp.PeerComm(rank, world, max(t * h for t, h in cases), dev)
+        comm = tp.PeerComm(rank, world, max(t * h for t, h in cases), dev, algo=algo)
+        ref = tp.PeerComm(rank, world, max(t * h for t, h in cases), dev, algo="one_shot")      # the reference sequence's all-reduce
         outs = []
         for ci, (tokens, hidden) in enumerate(cases):
             n = tokens * hidden
@@ -275,9 +276,9 @@ def _peer_add_norm_rank(rank, world, port, cases, ret):
             resid = (2.0 * torch.randn((tokens, hidden), generator=gs)).half().to(dev)
             gamma = (1.0 + 0.1 * torch.randn((hidden,), generator=gs)).half().to(dev)
             # reference sequence: all-reduce, residual add, rms_norm_general_fuse_sum
-            comm.slot(n).copy_(part)
+            ref.slot(n).copy_(part)
             red = torch.empty((n,), dtype=torch.float16, device=dev)
-            comm.all_reduce(red)
+            ref.all_reduce(red)
             x1 = resid.clone(); x1.add_(red.view(tokens, hidden))
             q1 = torch.empty((tokens, hidden), dtype=torch.int8, device=dev)
             sc1 = torch.empty((tokens,), dtype=torch.float16, device=dev); sm1 = sc1.clone()
@@ -292,19 +293,22 @@ def _peer_add_norm_rank(rank, world, port, cases, ret):
                          bool(torch.equal(sc1.view(torch.int16), sc2.view(torch.int16))),
                          bool(torch.equal(sm1.view(torch.int16), sm2.view(torch.int16))), x2.cpu().numpy()))
         comm.check_error()
+        ref.check_error()
         ret[rank] = outs
         dist.barrier()
         comm.close()
+        ref.close()
     finally:
         dist.destroy_process_group()
 
 
-def test_peer_add_rms_norm_row_widths_two_ranks_one_gpu():
+@pytest.mark.parametrize("algo", ["one_shot", "two_shot"])
+def test_peer_add_rms_norm_row_widths_two_ranks_one_gpu(algo):
     """tp_add_norm_v2_kernel batches the peer loads of all of a thread's vectors (round 4): rows of 4096 / 8192 / 12288
     columns = one / two / four vectors per thread, bit-identical to all-reduce -> add -> rms_norm_general_fuse_sum, same
     residual on both ranks."""
-    cases = [(16, 4096), (128, 8192), (5, 12288), (3, 2048)]
-    ret = _spawn2(_peer_add_norm_rank, (cases,))
+    cases = [(16, 4096), (128, 8192), (5, 12288), (3, 2048), (1, 4096)]      # (two_shot: chunk = ceil(tokens / 2) whole rows;
+    ret = _spawn2(_peer_add_norm_rank, (cases, algo))                          #  one token: rank 1 owns nothing)
     for ci, case in enumerate(cases):
         for rk in range(2):
             same_x, same_q, same_sc, same_sm, _ = ret[rk][ci]
@@ -312,13 +316,14 @@ def test_peer_add_rms_norm_row_widths_two_ranks_one_gpu():
         assert np.array_equal(ret[0][ci][4].view(np.uint16), ret[1][ci][4].view(np.uint16)), case
 
 
-def test_peer_allreduce_two_ranks_one_gpu():
+@pytest.mark.parametrize("algo", ["one_shot", "two_shot"])
+def test_peer_allreduce_two_ranks_one_gpu(algo):
     """The library's own all-reduce over hipIpc-mapped peer buffers (tp.PeerComm), two processes on the one test GPU:
     sums are bit-exact (f32 accumulate in rank order, one rounding) and identical on both ranks, eagerly and replayed from a
     captured graph.  (On this rig the 'peer' memory is the same device: the synchronisation protocol, the slot
     alternation and the graph capture are what is under test -- xGMI traffic is not.)"""
-    shapes = [4096, 8, 128 * 8192, 16 * 4096]
-    ret = _spawn2(_peer_allreduce_rank, (shapes,))
+    shapes = [4096, 8, 128 * 8192, 16 * 4096]      # (two_shot with 8 elements: rank 1's chunk is empty)
+    ret = _spawn2(_peer_allreduce_rank, (shapes, algo))
     for rep, n in enumerate(shapes + shapes):
         parts = []
         for rk in range(2):
@@ -333,14 +338,17 @@ def test_peer_allreduce_two_ranks_one_gpu():
             assert np.array_equal(ret[rk][len(shapes) * 2 + it], want), (it, rk)
 
 
-def test_peer_allreduce_reads_fresh_slots_behind_planted_stale_lines():
+@pytest.mark.parametrize("algo", ["one_shot", "two_shot"])
+def test_peer_allreduce_reads_fresh_slots_behind_planted_stale_lines(algo):
     """VERDICT r4 item 3 for the peer collective: between two uses of a slot the OTHER process reads it with ordinary cached
     loads (so any cache level that could keep a non-coherent copy of it holds the old contents), the owner then overwrites
     it and the collective must return the new sum.  24 rounds x 64 K elements, two processes on the one test GPU (different
     processes' kernels land on different XCDs: the L2s are not shared).  The buffers are fine-grained allocations and the
-    kernels acquire at system scope behind the flag wait (csrc/tp_comm.h); a plain allocation or a missing acquire fails here."""
+    kernels acquire at system scope behind the flag wait (csrc/tp_comm.h); a plain allocation or a missing acquire fails here.
+    two_shot: the same for the gather regions (the planting read covers them: the peer's reduced chunk of the LAST round sits in
+    this process' caches when the next round reads the fresh one)."""
     n, iters = 65536, 24
-    ret = _spawn2(_peer_stale_rank, (n, iters))
+    ret = _spawn2(_peer_stale_rank, (n, iters, algo))
     for rk in range(2):
         outs, planted = ret[rk]
         for it in range(iters):
