@@ -495,6 +495,7 @@ def tp_rank_leg(device, tp=8, batch=128, context=1024, steps=16, warmup=4):
     # the same step with the library's own collective kernels in place (all-reduce folded into add + norm + quant), every
     # "peer" slot aliased to this rank's own buffer: what the collectives cost on the compute side, with no fabric traffic
     dt_loop, _ = run("loopback")
+    dt_loop2, _ = run("loopback2")      # ... and the two-shot form's kernels (reduce-scatter + all-gather, csrc/tp_comm.h)
 
     class _R:      # (keeps the return expression below unchanged)
         @staticmethod
@@ -506,6 +507,7 @@ def tp_rank_leg(device, tp=8, batch=128, context=1024, steps=16, warmup=4):
                 tp, batch, context),
             "ms_per_step_compute_only": round(dt * 1e3, 3), "tokens_per_s_if_collectives_were_free": round(batch / dt, 1),
             "ms_per_step_with_peer_collective_kernels_loopback": round(dt_loop * 1e3, 3),
+            "ms_per_step_with_two_shot_collective_kernels_loopback": round(dt_loop2 * 1e3, 3),
             "gemm_weight_bytes_per_step": r.gemm_weight_bytes_per_step(), "kv_bytes_per_step": kvbytes,
             "roofline_step_compute_only": _step_roofline(cfg, wbytes, kvbytes, dt * 1e3),
             "all_reduce_calls_per_step": 2 * cfg.layers, "all_reduce_payload_bytes_per_step": ar_bytes}

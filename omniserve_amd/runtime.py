@@ -136,10 +136,13 @@ class DecodeRunner:
         # launch per collective, folded into the add + norm kernel where one follows) instead of torch.distributed / RCCL
         self.comm = None
         tp_comm = tp_comm or ""
-        if self.tp_size > 1 and tp_comm in ("peer", "loopback"):      # "loopback": one process, all peers = this rank (timing only)
+        # ("peer": one / two shots by payload, csrc/tp_comm.h; "peer1" / "peer2": forced; "loopback[2]": one process, all peers =
+        #  this rank -- timing only)
+        if self.tp_size > 1 and tp_comm in ("peer", "peer1", "peer2", "loopback", "loopback2"):
             from . import tp
+            algo = {"peer1": "one_shot", "peer2": "two_shot", "loopback2": "two_shot"}.get(tp_comm, "auto")
             self.comm = tp.PeerComm(self.tp_rank, self.tp_size, batch * cfg.hidden, device, tp_group,
-                                    loopback=tp_comm == "loopback")
+                                    loopback=tp_comm.startswith("loopback"), algo=algo)
         if cfg.heads % self.tp_size or cfg.kv_heads % self.tp_size or cfg.inter % (128 * self.tp_size):
             raise ValueError("heads / kv_heads / intermediate size not divisible by the TP degree")
         self.hl, self.kl, self.il = cfg.heads // self.tp_size, cfg.kv_heads // self.tp_size, cfg.inter // self.tp_size

@@ -357,15 +357,17 @@ def test_peer_allreduce_reads_fresh_slots_behind_planted_stale_lines(algo):
         assert all(p != 0 for p in planted)      # (the planting reads really happened)
 
 
-@pytest.mark.parametrize("group_size,graph", [(-1, False), (128, False), (-1, True)])
-def test_tp2_peer_comm_matches_the_collective_path_bitwise(group_size, graph):
+@pytest.mark.parametrize("group_size,graph,comm", [(-1, False, "peer"), (128, False, "peer"), (-1, True, "peer"),
+                                                   (-1, True, "peer2"), (128, False, "peer2")])
+def test_tp2_peer_comm_matches_the_collective_path_bitwise(group_size, graph, comm):
     """DecodeRunner(tp_comm="peer"): the two all-reduces per layer run on PeerComm, folded into the add + norm kernel
     (one launch for all-reduce + residual add + norm + quant).  At world 2 the fp32-accumulated sum has one rounding, as
     the host-staged gloo path of this rig and an fp16 RCCL ring have: hidden states and tokens must be bit-identical to
-    the torch.distributed path, on both ranks, eagerly and with the whole step in one HIP graph."""
+    the torch.distributed path, on both ranks, eagerly and with the whole step in one HIP graph.  "peer2": the two-shot form
+    (each rank reduces its half of the rows into its gather region, then both read the halves) -- same bits."""
     steps = 3
     ref = _spawn2(_run_rank, (group_size, steps))
-    got = _spawn2(_run_rank_peer, (group_size, steps, graph))
+    got = _spawn2(_run_rank_peer, (group_size, steps, graph, comm))
     for rk in range(2):
         xr, tr = ref[(2, rk)]
         xg, tg = got[(2, rk)]
@@ -373,8 +375,8 @@ def test_tp2_peer_comm_matches_the_collective_path_bitwise(group_size, graph):
     assert np.array_equal(got[(2, 0)][0], got[(2, 1)][0])
 
 
-def _run_rank_peer(rank, world, port, group_size, steps, graph, ret):
-    _run_rank(rank, world, port, group_size, steps, ret, tp_comm="peer", graph=graph)
+def _run_rank_peer(rank, world, port, group_size, steps, graph, comm, ret):
+    _run_rank(rank, world, port, group_size, steps, ret, tp_comm=comm, graph=graph)
 
 
 def _run_rank_l2_attn(rank, world, port, group_size, steps, graph, ret):
