@@ -478,7 +478,8 @@ int omni_kv4_prefill_write_fine_grained(
  * (1 / world of the vector; whole rows for the fused norm) into its GATHER region (gather_offset_elems: fp16 offset inside the
  * rank's data buffer, room for ceil(count / world) elements rounded up to 8 (to whole rows); < 0 = there is none), the ranks
  * meet a second time, then everyone reads the reduced chunks from their owners: 2 (world - 1) / world x payload per rank.
- * algo: 0 = two shots from 512 KiB of payload on more than two ranks, 1 = one shot, 2 = two shots. */
+ * algo: 0 = two shots from 4 MiB of payload on more than two ranks (the second rendezvous costs ~16 us: csrc/tp_comm.hip has the
+ * crossover arithmetic), 1 = one shot, 2 = two shots. */
 int omni_tp_alloc(size_t bytes, void** ptr_out);
 int omni_tp_free(void* ptr);
 int omni_tp_ipc_handle(void* ptr, void* handle64);

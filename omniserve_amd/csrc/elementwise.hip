@@ -1042,9 +1042,9 @@ extern "C" int omni_tp_add_rms_norm_general_fuse_sum(void* out_i8, void* residua
     src.tp.flags[p] = (uint32_t*)peer_flags[q];
   }
   src.tp.rank = rank; src.tp.world = world; src.tp.slot_off = slot_offset_elems; src.tp.epoch = 1;
-  // two shots (tp_comm.h) from 512 KiB of payload on more than two ranks (algo 0), or forced (algo 2): chunk = whole rows
+  // two shots (tp_comm.h) from TP_TWO_SHOT_BYTES of payload on more than two ranks (algo 0), or forced (algo 2): chunk = whole rows
   src.tp.gather_off = 0; src.tp.chunk = 0; src.tp.two_shot = 0;
-  if (gather_offset_elems >= 0 && algo != 1 && (algo == 2 || (world > 2 && (long long)tokens * hidden * 2 >= (512 << 10)))) {
+  if (gather_offset_elems >= 0 && algo != 1 && (algo == 2 || (world > 2 && (long long)tokens * hidden * 2 >= TP_TWO_SHOT_BYTES))) {
     src.tp.two_shot = 1;
     src.tp.gather_off = gather_offset_elems;
     src.tp.chunk = (long long)((tokens + world - 1) / world) * hidden;

@@ -29,8 +29,9 @@ constexpr int TP_W_TICKET = 17;        // workgroups of the running consumer ker
 constexpr int TP_W_ERROR = 18;         // != 0: a wait timed out
 constexpr int TP_W_TICKET2 = 19;       // two-shot form: workgroups of the running kernel that finished their part of the chunk
 constexpr int TP_W_ARR2 = 24;          // [24, 32): two-shot form, "rank p's reduced chunk of epoch e is in its gather region"
+constexpr long long TP_TWO_SHOT_BYTES = 4ll << 20;   // algo 0: payloads from here on take two shots (tp_comm.hip has the arithmetic)
 
-// Two-shot form (payloads >= 512 KiB on more than two ranks; VERDICT r5: the one-shot form has every rank pull every peer's
+// Two-shot form (payloads >= 4 MiB on more than two ranks, or forced; VERDICT r5: the one-shot form has every rank pull every peer's
 // FULL slot -- 7 x 2 MiB = 14 MiB per all-reduce at TP = 8, bs = 128 -- where reduce-scatter + all-gather moves 3.5 MiB):
 //   shot 1  rank r reduces chunk r of the vector (1/world of it, whole rows for the fused norm) from all peers' slots, in
 //           rank order in f32, ONE rounding, into its own GATHER region (peer-mapped like the slots);
@@ -123,12 +124,17 @@ __device__ __forceinline__ uint32_t tp_publish_and_wait(const TpPeers& tp) {
 __device__ __forceinline__ bool tp_between_shots(const TpPeers& tp, uint32_t e) {
   __shared__ uint32_t s_fail2;
   if (threadIdx.x == 0) s_fail2 = 0;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // my stores into the gather region are visible to the peers ...
+  // every storing wave drains its own stores, ONE lane per workgroup then releases at system scope (first version: a system
+  // release by every thread and an acq_rel ticket -- one L2 write-back per wave and per arrival: +23 us per collective in the
+  // loopback timing of bench.py's TP leg)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   uint32_t* mine = tp_flags_of(tp, tp.rank);
   if (threadIdx.x == 0) {
-    const uint32_t done = __hip_atomic_fetch_add(mine + TP_W_TICKET2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (done == gridDim.x - 1) {                     // ... and so are those of every workgroup that arrived before me
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");    // this workgroup's part of the gather region is visible to the peers ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t done = __hip_atomic_fetch_add(mine + TP_W_TICKET2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {                     // ... and so is that of every workgroup whose arrival I have counted
       __hip_atomic_store(mine + TP_W_TICKET2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int p = 0; p < tp.world; ++p)
         __hip_atomic_store(tp_flags_of(tp, p) + TP_W_ARR2 + tp.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

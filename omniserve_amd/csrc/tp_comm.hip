@@ -35,11 +35,15 @@ __global__ __launch_bounds__(256) void tp_allreduce2_f16_kernel(half_t* __restri
 
 }  // namespace omni
 
-// algo: 0 = by payload (two shots from 512 KiB on more than two ranks), 1 = one shot, 2 = two shots (needs a gather region)
+// algo: 0 = by payload, 1 = one shot, 2 = two shots (needs a gather region).  By payload: two shots from TP_TWO_SHOT_BYTES on more
+// than two ranks.  The second in-kernel rendezvous (drain + one system release per workgroup, ticket, publish, poll, acquire)
+// measures +16 us per collective (bench.py's TP leg, loopback: 13.6 -> 29.7 us); per link the two-shot form saves
+// payload x (1 - 2 / world) / 153 GB/s: the forms cross at ~3.3 MB on 8 ranks, ~4.9 MB on 4 -- the decode step's 2 MiB
+// (bs = 128) stays one-shot, larger payloads go two-shot.
 static bool want_two_shot(int algo, int world, long long count, long long gather_off) {
   if (gather_off < 0 || algo == 1) return false;
   if (algo == 2) return true;
-  return world > 2 && count * 2 >= (512 << 10);
+  return world > 2 && count * 2 >= omni::TP_TWO_SHOT_BYTES;
 }
 
 static int fill_peers(TpPeers& tp, const void* const* peer_data, void* const* peer_flags, int rank, int world,

@@ -92,7 +92,7 @@ class PeerComm:
     def __init__(self, rank, world, max_elems, device, group=None, loopback=False, algo="auto"):
         """loopback=True (single process, measurements only): every "peer" is this rank's own buffer, so a collective of
         `world` ranks runs with all flags raised by the caller itself -- the kernels' cost without any fabric traffic.
-        algo: "auto" (two shots -- reduce-scatter into a gather region, then all-gather -- from 512 KiB of payload on more
+        algo: "auto" (two shots -- reduce-scatter into a gather region, then all-gather -- from 4 MiB of payload on more
         than two ranks; one shot otherwise), "one_shot", "two_shot" (csrc/tp_comm.h; same bits either way)."""
         import ctypes
         import torch.distributed as dist
