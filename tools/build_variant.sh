@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 NAME=$1; EXTRA=$2; SRC=${3:-omniserve_amd/csrc}
 OBJ=/tmp/variant_$NAME; mkdir -p $OBJ tune_libs
 pids=()
-for f in qgemm_plan qgemm_chn qgemm_grp qgemm_w8 elementwise offpath kv_cache attn_prefill sparse_utils tp_comm row_dtypes; do
+for f in qgemm_plan qgemm_chn qgemm_grp qgemm_w8 elementwise offpath kv_cache attn_prefill sparse_utils tp_comm row_dtypes norm_gemv_fused; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $EXTRA -I$SRC -Iinclude -c $SRC/$f.hip -o $OBJ/$f.o &
   pids+=($!)
 done
