@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 lib = _lib.lib()
 for ns in (0, 2, 3, 4, 5, 6, 8):
     lib.omni_kv4_decode_set_split_override(ns)
-    r = DecodeRunner(LlamaConfig.llama3_8b(-1), 16, 1024, 200, dev, seed=0, use_graph=True, fused=2)
+    r = DecodeRunner(LlamaConfig.llama3_8b(-1), 16, 1024, 200, dev, seed=0, use_graph=True, fused=3)
     for _ in range(8):
         r.step()
     torch.cuda.synchronize()
