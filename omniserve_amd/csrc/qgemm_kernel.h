@@ -150,6 +150,14 @@ __device__ __forceinline__ half_t epilogue(int acc, float sw, float sa, float sz
 #ifndef OMNI_GEMM_RING_CHN
 #define OMNI_GEMM_RING_CHN 4     // a whole chunk ahead; 2 measured 4-6 % slower for the per-channel kernel
 #endif
+#ifndef OMNI_GEMM_RING_W8
+#define OMNI_GEMM_RING_W8 2      // W8A8 on the ragged-shape 128-row tile: k-steps of weights ahead.  2 ends 3 - 7 VGPRs over the budget
+                                 // (parked in scratch outside the loops, tests/test_code_objects_cpu.py) and still measures 5 - 7 %
+                                 // faster than the spill-free ring of 1 (tools/ragged_gemm_ab.py: 1132 vs 1060 TOPS at M = 4100)
+#endif
+#ifndef OMNI_GEMV_EPI_PARK
+#define OMNI_GEMV_EPI_PARK 1     // 64-row GEMV tiles with the in-kernel epilogue: its operands parked in LDS across the K loop
+#endif
 #ifndef OMNI_GEMM_PIPE_B
 #define OMNI_GEMM_PIPE_B 1
 #endif
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(64 * WAVES, OMNI_GEMM_MIN_BLOCKS) void w4a8_gemm_ke
   // (64 VGPRs for a chunk pushed the kernel over 256 VGPRs: 100 B/lane of scratch), so it runs two steps ahead
   // (W8A8 on the 128-row tile: one step ahead -- with two the instantiation spilled 3 - 7 VGPRs to scratch; no product kernel may
   //  spill, tests/test_code_objects_cpu.py.  This is the ragged-shape fallback: the models' shapes run w4a8_gemm_exact_kernel)
-  constexpr int WRING = MODE == MODE_CHN ? OMNI_GEMM_RING_CHN : ((MODE == MODE_W8 && MB == 8) ? 1 : OMNI_GEMM_RING_OTHER);
+  constexpr int WRING = MODE == MODE_CHN ? OMNI_GEMM_RING_CHN : ((MODE == MODE_W8 && MB == 8) ? OMNI_GEMM_RING_W8 : OMNI_GEMM_RING_OTHER);
   uint4 wq[WRING][WL];
 
   // ---- activation staging --------------------------------------------------------------
@@ -831,7 +839,7 @@ __global__ __launch_bounds__((64 * GemvCfg<MB, MODE, VAR>::WAVES * KW * MZ), (((
   // 64-row tiles with the in-kernel epilogue: the operands (2 ABW + MB dwords per lane) are parked in LDS across the K loop --
   // held in registers they pushed these instantiations to 4 - 10 spilled VGPRs (scratch traffic inside the loop); the park
   // happens where the prologue waits for its first activation round anyway (loads return in order)
-  constexpr bool EPI_PARK = MB == 4 && !TO_SLAB && KW == 4;
+  constexpr bool EPI_PARK = OMNI_GEMV_EPI_PARK && MB == 4 && !TO_SLAB && KW == 4;
   constexpr int EPI_WORDS = 8;
   static_assert(!EPI_PARK || (4 * ABW + MB <= EPI_WORDS), "parked epilogue operands");
   __shared__ __attribute__((aligned(16))) uint32_t epi_park[EPI_PARK ? KW * MZ * 64 * EPI_WORDS : 4];
