@@ -380,7 +380,8 @@ constexpr int FVTILE = 32 * FVROW;
 #ifdef OMNI_DEBUG_CLOCKS
 // timeline probe (tools/flash_timeline.py): shader-clock stamps of every wave of three workgroups -- the first, the middle
 // and the last of the grid in dispatch order: [0] entry, [1] page window visible, [2] q in LDS (first batch requested),
-// [3 + i] tile i of the wave done (i < 24), [28] sweep done, [29] combined / stored, [30] exit
+// [3 + i] tile i of the wave done (i < 22), [25] partials stored (single-launch form), [26] stores drained, [27] ticket known,
+// [28] sweep done, [29] combined / stored (single-launch form: merged by the last arriver), [30] exit
 static __device__ unsigned long long omni_dbg_flash[3 * DEC_WAVES * 32];
 #define FLASH_STAMP(i)                                                                                              \
   do {                                                                                                              \
@@ -919,7 +920,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       }
     }
     if constexpr (FG) load_batch(set_tag, i0 + 2 * FB);      // fine-grained instantiations: the whole next-but-one batch
-    if (i0 < 24) FLASH_STAMP(3 + i0);
+    if (i0 < 22) FLASH_STAMP(3 + i0);
   };
   if constexpr (FG || PIPE) {
     load_batch(IntTag<1>{}, FB);      // (batch 0 went out with trip 2)
@@ -1001,8 +1002,10 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   if constexpr (LASTM) {
     // ticket of (sequence b, head group blockIdx.y): the last of the nsplit workgroups merges.  Every storing wave drains
     // its write-through (sc1) stores first; the merging wave reads them with agent-scope (sc1) loads behind the ticket.
+    FLASH_STAMP(25);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    FLASH_STAMP(26);
     uint32_t* tk = p.tickets + (size_t)b * gridDim.y + blockIdx.y;
     if (tid == 0) {
       const uint32_t t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1011,6 +1014,7 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
       red[0] = last ? 1.0f : 0.0f;
     }
     __syncthreads();
+    FLASH_STAMP(27);
     if (red[0] != 0.0f && wave == DEC_WAVES - 1) {      // (the last wave: waves 0 / 1 go on to append the current token)
       const int i = hq0 * DH + lane * VT;                // 8 outputs per lane: G * 128 = up to 512 per workgroup
       if (lane * VT < G * DH) {
