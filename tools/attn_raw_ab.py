@@ -1,5 +1,6 @@
 """Decode step against the form of the dense KV4 decode sweep (omni_kv4_decode_set_raw_override: 0 exact fp16 dequantisation,
-1 raw codes on the matrix cores), alternating on one box: python tools/attn_raw_ab.py [model] [batch ...]"""
+1 raw codes on the matrix cores), alternating on one box: python tools/attn_raw_ab.py [model] [batch ...]
+Needs a library built with tools/experiments/attention_raw_code_sweep.patch applied (the shipped one has no such override)."""
 import os
 import sys
 import time
