@@ -396,6 +396,14 @@ int omni_prefill_attention(void* out_f16, const void* q_f16, const void* k_f16, 
                            const void* cu_seqlens_q_i32, const void* cu_seqlens_k_i32, int batch,
                            int max_seqlen_q, int num_heads, int num_kv_heads, int head_dim, int causal,
                            const void* head_mask_type_i32, const void* streaming_info_i32, void* stream);
+/* Replaces block_sparse_attn.block_streaming_attn_func (imported at ctx_attn_func.py:3-7, wrapped at :47-59; no caller upstream):
+ * omni_prefill_attention (causal) with streaming_info = (sink, local) per q head counted in blocks of 128 tokens --
+ * mask = causal AND (dense OR k_pos / 128 < sink OR q_pos / 128 - k_pos / 128 < local).  Both tables are required. */
+int omni_prefill_attention_block_streaming(void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16,
+                                           int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                           const void* cu_seqlens_q_i32, const void* cu_seqlens_k_i32, int batch,
+                                           int max_seqlen_q, int num_heads, int num_kv_heads, int head_dim,
+                                           const void* head_mask_type_i32, const void* streaming_info_i32, void* stream);
 /* Tuning / test hook: 0 = 16 query rows per wave (16x16x32 MFMA, default), 1 = 32 rows per wave (32x32x16 MFMA). */
 void omni_prefill_set_variant(int variant);
 

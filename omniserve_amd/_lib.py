@@ -14,6 +14,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libomniserve_hip.so")
+_SHIPPED_LIB_PATH = LIB_PATH      # tools/ point LIB_PATH at tuning variants (tune_libs/*.so), possibly built from older sources
 
 _c = ctypes
 _vp, _i, _i64, _sz, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t, _c.c_float
@@ -86,6 +87,7 @@ PROTOTYPES = {
     "omni_kv_min_max_pool": (_i, [_vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "omni_kv_page_selector": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp] + [_i] * 10 + [_vp, _i, _vp]),
     "omni_prefill_attention": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp] + [_i] * 6 + [_vp, _vp, _vp]),
+    "omni_prefill_attention_block_streaming": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp] + [_i] * 5 + [_vp, _vp, _vp]),
     "omni_kv4_decode_attention_partial": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp] + [_i] * 7 + [_vp, _i, _vp, _sz, _c.POINTER(_i), _vp]),
     "omni_attn_merge_quant_fuse_sum": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "omni_kv_decode_attention_fine_grained_partial": (_i, [_vp, _vp, _vp, _i64, _i64] + [_vp] * 8 + [_i] * 16 +
@@ -123,6 +125,8 @@ def lib() -> ctypes.CDLL:
                     "(there is no CPU fallback)" % LIB_PATH)
             h = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
             for name, (res, args) in PROTOTYPES.items():
+                if LIB_PATH != _SHIPPED_LIB_PATH and not hasattr(h, name):
+                    continue           # an A/B variant built before this entry point existed: calling it fails, nothing else does
                 fn = getattr(h, name)  # AttributeError = header/library drift
                 fn.restype = res
                 fn.argtypes = args

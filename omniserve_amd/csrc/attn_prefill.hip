@@ -64,7 +64,13 @@ struct PrefillArgs {
   int causal;
   int q_tiles;                               // > 0: 1-D grid, XCD-aware order (prefill_map_block)
   int xcd_split;                             // 1-D grid: XCDs that share the query tiles of one kv head (1, 2, 4 or 8)
-};
+  int gran_log2;                             // granularity of (sink, local): 0 tokens (token_streaming_attn_func), 7 blocks of 128
+};                                           // tokens (block_streaming_attn_func): see first_local_key below
+
+// Streaming heads see the keys  key < sink << g  and  key >= first_local_key(qpos): the first key of the local window of the
+// query at (bottom-right aligned) position qpos.  g = 0: qpos - local + 1 (the last `local` tokens, itself included); g = 7:
+// the first token of block (qpos >> 7) - local + 1 (the query's own 128-token block and the local - 1 blocks before it).
+__device__ __forceinline__ int first_local_key(int qpos, int local, int g) { return ((qpos >> g) - local + 1) * (1 << g); }
 
 // 1-D grid: workgroups are dealt round-robin to the 8 XCDs (private L2s; the dispatch is static: workgroup w runs on XCD
 // w % 8 whatever the others are doing).  All q heads of a kv head share an XCD's L2, so a K/V tile is fetched from the
@@ -129,8 +135,9 @@ void prefill_attn_kernel(PrefillArgs p) {
   const int q0 = q_first + wave * (16 * PQB);                   // first query row of this wave
   const int off = len_k - len_q;                                // bottom-right aligned causal mask
   const bool streaming = p.head_mask_type != nullptr && p.head_mask_type[h] < 0;
-  const int sink = streaming ? p.streaming_info[2 * h] : 0;
-  const int local = streaming ? p.streaming_info[2 * h + 1] : 0;
+  const int gl = p.gran_log2;
+  const int sink = streaming ? p.streaming_info[2 * h] << gl : 0;      // in tokens
+  const int local = streaming ? p.streaming_info[2 * h + 1] : 0;       // in units of 1 << gl tokens
   const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e)/sqrt(128): scores in the exp2 domain
 
   // B operand of S^T = K Q^T: Q[row][32s + 8*l4 + (0..7)] for the wave's two row blocks
@@ -155,7 +162,7 @@ void prefill_attn_kernel(PrefillArgs p) {
 
   // key range this workgroup needs
   const int k_hi = p.causal ? min(len_k, q_last + off + 1) : len_k;             // exclusive
-  const int win_lo = streaming ? q_first + off - local + 1 : 0;                   // first local key of the first row
+  const int win_lo = streaming ? first_local_key(q_first + off, local, gl) : 0;   // first local key of the first row
   auto skipped = [&](int kb) { return streaming && kb >= sink && kb + PKT <= win_lo; };   // tile inside the masked band
 
   // Tile staging by LDS-DMA (global_load_lds_dwordx4: one 1-KiB piece = 4 key rows per wave-instruction, no staging
@@ -236,7 +243,7 @@ void prefill_attn_kernel(PrefillArgs p) {
     // does any (row, key) pair of this workgroup's tile need the mask?  (workgroup-uniform)
     bool full = (kb + PKT <= len_k) && (q_first + PQROWS <= len_q);
     if (p.causal) full = full && (kb + PKT - 1 <= q_first + off);
-    if (streaming) full = full && ((kb + PKT <= sink) || (q_last + off - kb < local));
+    if (streaming) full = full && ((kb + PKT <= sink) || (kb >= first_local_key(q_last + off, local, gl)));
     // ---- online softmax (per query row = per lane column), probabilities straight into the B operand ----------
     // exp2 domain: p = exp2(s*scale2 - m); the maximum is taken on the raw scores (scale2 > 0) and the scaling rides
     // in the FMA that subtracts it.  Two code paths (workgroup-uniform): tiles that need no mask carry no predicate.
@@ -268,7 +275,7 @@ void prefill_attn_kernel(PrefillArgs p) {
             const int qpos = qrow[j] + off;
             int ok = (int)(key < len_k) & (int)(qrow[j] < len_q);
             ok &= (int)(!p.causal) | (int)(key <= qpos);
-            ok &= (int)(!streaming) | (int)(key < sink) | (int)(qpos - key < local);
+            ok &= (int)(!streaming) | (int)(key < sink) | (int)(key >= first_local_key(qpos, local, gl));
             okv[4 * u + r] = ok != 0;
             tmax = __builtin_fmaxf(tmax, ok ? st[j][u][r] : -1e30f);
           }
@@ -394,8 +401,9 @@ void prefill_attn32_kernel(PrefillArgs p) {
   const int q_last = min(q_first + P32ROWS, len_q) - 1;
   const int off = len_k - len_q;
   const bool streaming = p.head_mask_type != nullptr && p.head_mask_type[h] < 0;
-  const int sink = streaming ? p.streaming_info[2 * h] : 0;
-  const int local = streaming ? p.streaming_info[2 * h + 1] : 0;
+  const int gl = p.gran_log2;
+  const int sink = streaming ? p.streaming_info[2 * h] << gl : 0;      // in tokens
+  const int local = streaming ? p.streaming_info[2 * h + 1] : 0;       // in units of 1 << gl tokens
   const float scale2 = 0.08838834764831845f * 1.4426950408889634f;
   const int qrow = q_first + wave * 32 + l32;               // this lane's query row (lanes l and l + 32 share it)
 
@@ -415,7 +423,7 @@ void prefill_attn32_kernel(PrefillArgs p) {
   float m_run = -1e30f, l_run = 0.0f;
 
   const int k_hi = p.causal ? min(len_k, q_last + off + 1) : len_k;
-  const int win_lo = streaming ? q_first + off - local + 1 : 0;
+  const int win_lo = streaming ? first_local_key(q_first + off, local, gl) : 0;
   auto skipped = [&](int kb) { return streaming && kb >= sink && kb + PKT <= win_lo; };
   auto next_tile = [&](int kb) {
     while (kb < k_hi && skipped(kb)) kb += PKT;
@@ -502,7 +510,7 @@ void prefill_attn32_kernel(PrefillArgs p) {
           const int qpos = qrow + off;
           int ok = (int)(key < len_k) & (int)(qrow < len_q);
           ok &= (int)(!p.causal) | (int)(key <= qpos);
-          ok &= (int)(!streaming) | (int)(key < sink) | (int)(qpos - key < local);
+          ok &= (int)(!streaming) | (int)(key < sink) | (int)(key >= first_local_key(qpos, local, gl));
           okv[u][r] = ok != 0;
           tmax = __builtin_fmaxf(tmax, ok ? st[u][r] : -1e30f);
         }
@@ -566,7 +574,7 @@ void prefill_attn32_kernel(PrefillArgs p) {
   auto is_full = [&](int kb_) {
     bool full = (kb_ + PKT <= len_k) && (q_first + P32ROWS <= len_q);
     if (p.causal) full = full && (kb_ + PKT - 1 <= q_first + off);
-    if (streaming) full = full && ((kb_ + PKT <= sink) || (q_last + off - kb_ < local));
+    if (streaming) full = full && ((kb_ + PKT <= sink) || (kb_ >= first_local_key(q_last + off, local, gl)));
     return full;
   };
   while (kb < k_hi) {
@@ -609,11 +617,11 @@ static thread_local int g_prefill_xcd_split = 0;
 // Tuning hook: XCDs that share one kv head's query tiles when streaming heads are present (0 = default, else 1 / 2 / 4 / 8).
 extern "C" void omni_prefill_set_xcd_split(int w) { g_prefill_xcd_split = (w == 1 || w == 2 || w == 4 || w == 8) ? w : 0; }
 
-extern "C" int omni_prefill_attention(void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16,
-                                      int64_t q_stride, int64_t k_stride, int64_t v_stride,
-                                      const void* cu_seqlens_q_i32, const void* cu_seqlens_k_i32, int batch,
-                                      int max_seqlen_q, int num_heads, int num_kv_heads, int head_dim, int causal,
-                                      const void* head_mask_type_i32, const void* streaming_info_i32, void* stream) {
+static int prefill_attention_common(void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16,
+                                    int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                    const void* cu_seqlens_q_i32, const void* cu_seqlens_k_i32, int batch,
+                                    int max_seqlen_q, int num_heads, int num_kv_heads, int head_dim, int causal,
+                                    const void* head_mask_type_i32, const void* streaming_info_i32, int gran_log2, void* stream) {
   if (!out_f16 || !q_f16 || !k_f16 || !v_f16 || !cu_seqlens_q_i32 || !cu_seqlens_k_i32) return OMNI_EINVAL;
   if (head_dim != PDH || batch < 1 || num_heads < 1 || num_kv_heads < 1 || num_heads % num_kv_heads != 0 ||
       max_seqlen_q < 1 || q_stride % 8 != 0 || k_stride % 8 != 0 || v_stride % 8 != 0 || k_stride < 0 || v_stride < 0 ||
@@ -626,6 +634,7 @@ extern "C" int omni_prefill_attention(void* out_f16, const void* q_f16, const vo
   a.cu_q = (const int*)cu_seqlens_q_i32; a.cu_k = (const int*)cu_seqlens_k_i32;
   a.head_mask_type = (const int*)head_mask_type_i32; a.streaming_info = (const int*)streaming_info_i32;
   a.num_heads = num_heads; a.num_kv_heads = num_kv_heads; a.causal = causal;
+  a.gran_log2 = gran_log2;
   const bool form32 = g_prefill_variant == 1;
   const int rows_per_wg = form32 ? P32ROWS : PQROWS;
   const int q_tiles = (max_seqlen_q + rows_per_wg - 1) / rows_per_wg;
@@ -649,4 +658,30 @@ extern "C" int omni_prefill_attention(void* out_f16, const void* q_f16, const vo
   if (form32) hipLaunchKernelGGL(prefill_attn32_kernel, grid, dim3(64 * P32W), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(prefill_attn_kernel, grid, dim3(64 * PWAVES), 0, (hipStream_t)stream, a);
   return omni_launch_status();
+}
+
+extern "C" int omni_prefill_attention(void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16,
+                                      int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                      const void* cu_seqlens_q_i32, const void* cu_seqlens_k_i32, int batch,
+                                      int max_seqlen_q, int num_heads, int num_kv_heads, int head_dim, int causal,
+                                      const void* head_mask_type_i32, const void* streaming_info_i32, void* stream) {
+  return prefill_attention_common(out_f16, q_f16, k_f16, v_f16, q_stride, k_stride, v_stride, cu_seqlens_q_i32, cu_seqlens_k_i32,
+                                  batch, max_seqlen_q, num_heads, num_kv_heads, head_dim, causal, head_mask_type_i32,
+                                  streaming_info_i32, 0, stream);
+}
+
+// block_sparse_attn.block_streaming_attn_func (ctx_attn_func.py:47-59): the same causal attention with streaming_info =
+// (sink, local) per q head counted in BLOCKS of 128 tokens (the package's m / n block size): a streaming head's query in block i
+// sees the first `sink` key blocks and the key blocks i - local + 1 .. i (causal inside its own).  Semantics inferred like the
+// token form's (the package is not vendored; the reference's only call site is dead code).
+extern "C" int omni_prefill_attention_block_streaming(void* out_f16, const void* q_f16, const void* k_f16, const void* v_f16,
+                                                      int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                                      const void* cu_seqlens_q_i32, const void* cu_seqlens_k_i32, int batch,
+                                                      int max_seqlen_q, int num_heads, int num_kv_heads, int head_dim,
+                                                      const void* head_mask_type_i32, const void* streaming_info_i32,
+                                                      void* stream) {
+  if (!head_mask_type_i32 || !streaming_info_i32) return OMNI_EINVAL;
+  return prefill_attention_common(out_f16, q_f16, k_f16, v_f16, q_stride, k_stride, v_stride, cu_seqlens_q_i32, cu_seqlens_k_i32,
+                                  batch, max_seqlen_q, num_heads, num_kv_heads, head_dim, 1, head_mask_type_i32,
+                                  streaming_info_i32, 7, stream);
 }

@@ -3,15 +3,25 @@
 The arithmetic lives in the un-vendored, un-pinned third-party package `block_sparse_attn`
 (github mit-han-lab/Block-Sparse-Attention; absent from /root/reference and from pyproject.toml).
 This restates its published semantics -- FlashAttention-2 varlen causal attention, and the
-"token streaming" Lambda mask of DuoAttention/LServe (sink + local tokens) -- anchored on the
+"token streaming" Lambda mask of DuoAttention/LServe (sink + local tokens; "block streaming": the same rule on 128-token
+blocks, ctx_attn_func.py:47-59, dead code upstream) -- anchored on the
 reference's call sites (omniserve/modeling/layers/ctx_attn/ctx_attn_func.py:39-45,68-73,
 ctx_attn_init.py:28-50).  PARITY UNPINNED (no reference tests or golden vectors exist at that boundary).
 """
 import numpy as np
 
 
-def varlen_attention(q, k, v, cu_q, cu_k, causal=True, head_mask_type=None, streaming_info=None):
-    """q [Lq,Hq,D], k,v [Lk,Hkv,D] fp16 -> out fp16 [Lq,Hq,D].  f64 softmax reference."""
+def streaming_mask(qi, ki, sink, local, block=1):
+    """Keys a streaming head's query may see besides causality.  block = 1: token_streaming_attn_func (the first `sink` tokens
+    and the last `local` tokens, the query's own included); block = 128: block_streaming_attn_func, the same rule on 128-token
+    block indices (the first `sink` key blocks, the query's own block and the local - 1 blocks before it).  qi: bottom-right
+    aligned query positions [lq, 1], ki: key positions [1, lk]."""
+    return ((ki // block) < sink) | (((qi // block) - (ki // block)) < local)
+
+
+def varlen_attention(q, k, v, cu_q, cu_k, causal=True, head_mask_type=None, streaming_info=None, block=1):
+    """q [Lq,Hq,D], k,v [Lk,Hkv,D] fp16 -> out fp16 [Lq,Hq,D].  f64 softmax reference.  block: granularity of streaming_info
+    (streaming_mask)."""
     q = np.asarray(q, np.float16); k = np.asarray(k, np.float16); v = np.asarray(v, np.float16)
     Lq, Hq, D = q.shape
     Hk = k.shape[1]
@@ -33,7 +43,7 @@ def varlen_attention(q, k, v, cu_q, cu_k, causal=True, head_mask_type=None, stre
                 mask &= ki <= qi
             if head_mask_type is not None and int(head_mask_type[h]) < 0:
                 sink, local = int(streaming_info[2 * h]), int(streaming_info[2 * h + 1])
-                mask &= (ki < sink) | ((qi - ki) < local)
+                mask &= streaming_mask(qi, ki, sink, local, block)
             s = np.where(mask, s, -np.inf)
             m = s.max(axis=1, keepdims=True)
             p = np.exp(s - m)

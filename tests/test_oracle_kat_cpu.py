@@ -165,6 +165,20 @@ def test_prefill_attention_oracle_lambda_mask():        # causal & (d
             assert np.abs(out[i, h].astype(np.float64) - want).max() < 2e-3
 
 
+def test_prefill_attention_oracle_block_streaming_mask():      # block_streaming_attn_func: the Lambda rule on 128-token block indices
+    qi = np.arange(400)[:, None]
+    ki = np.arange(400)[None, :]
+    assert np.array_equal(oa.streaming_mask(qi, ki, 4, 8, 1), (ki < 4) | ((qi - ki) < 8))       # block = 1 is the token rule
+    m = oa.streaming_mask(qi, ki, 1, 2, 128) & (ki <= qi)
+    # query 300 (block 2): the sink block 0 (keys 0..127), block 1 (the one local block before its own) and its own block up to itself
+    assert m[300, :301].all()
+    # query 399 (block 3): sink block 0, blocks 2 and 3 -- block 1 (keys 128..255) is masked
+    assert m[399, :128].all() and not m[399, 128:256].any() and m[399, 256:400].all()
+    # one local block = the query's own block only
+    m1 = oa.streaming_mask(qi, ki, 0, 1, 128) & (ki <= qi)
+    assert not m1[130, :128].any() and m1[130, 128:131].all()
+
+
 # ---- the overloads off the Llama path (oracle/elementwise.py, second half) ----------------------------------------------
 def test_fma32_is_a_single_rounding():       # nvcc contracts a*b+c (fused_kernels.cu:35-36, layernorm_kernels.cu:384-391)
     from fractions import Fraction

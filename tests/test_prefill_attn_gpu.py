@@ -20,7 +20,7 @@ def kernel_form(request):
     _lib.lib().omni_prefill_set_variant(0)
 
 
-def _case(seq_lens, Hq, Hk, seed, streaming=None, strided=True):
+def _case(seq_lens, Hq, Hk, seed, streaming=None, strided=True, block=False):
     import block_sparse_attn as bsa
     rng = np.random.default_rng(seed)
     L = int(sum(seq_lens))
@@ -42,8 +42,9 @@ def _case(seq_lens, Hq, Hk, seed, streaming=None, strided=True):
         hmt, sink, local = streaming
         hm = np.repeat(np.asarray(hmt, np.int32), Hq // Hk)
         si = np.asarray([sink, local] * Hq, np.int32)
-        out = bsa.token_streaming_attn_func(qd, kd, vd, cu_d, cu_d, to_dev(hm), to_dev(si), max(seq_lens), max(seq_lens))
-        want = oa.varlen_attention(q, k, v, cu, cu, True, hm, si)
+        fn = bsa.block_streaming_attn_func if block else bsa.token_streaming_attn_func
+        out = fn(qd, kd, vd, cu_d, cu_d, to_dev(hm), to_dev(si), max(seq_lens), max(seq_lens))
+        want = oa.varlen_attention(q, k, v, cu, cu, True, hm, si, block=128 if block else 1)
     torch.cuda.synchronize()
     got = out.cpu().numpy().astype(np.float32)
     ref = want.astype(np.float32)
@@ -63,6 +64,14 @@ def test_dense_contiguous_inputs():
 def test_token_streaming_heads(seq_lens, sink, local):
     # kv heads alternate dense (0) / streaming (-1), expanded to q heads like ctx_attn_init.py:28-47
     _case(seq_lens, 8, 4, seed=len(seq_lens) + sink, streaming=([0, -1, -1, 0], sink, local))
+
+
+@pytest.mark.parametrize("seq_lens,sink,local", [([300], 1, 1), ([1000, 129], 1, 2), ([40], 1, 1), ([700, 128, 127], 2, 3),
+                                                 ([1500], 0, 2)])
+def test_block_streaming_heads(seq_lens, sink, local):
+    """block_streaming_attn_func: (sink, local) in blocks of 128 tokens; sequences shorter than one block, lengths on and next to
+    block boundaries, no sink at all."""
+    _case(seq_lens, 8, 4, seed=len(seq_lens) + 7 * sink + local, streaming=([0, -1, -1, 0], sink, local), block=True)
 
 
 # ---- long sequences: the regimes the published prefill numbers come from (XCD-ordered 1-D grid, whole-tile skipping of
