@@ -377,6 +377,16 @@ constexpr int FVTILE = 32 * FVROW;
 // group), and the LAST arriver merges the splits (row_kernels.h: SrcAttnMerge, the merge kernels' own arithmetic), stores
 // the fp16 output and raises its row maxima: the attention is ONE launch (it also carries the armed L2 prefetch on extra
 // z slices of its grid, as the merge kernel did).
+#if (OMNI_FLASH_ABLATE & 64)
+// timing experiment (tools/attn_long.py with OMNI_DBG_POOL=1; results are wrong unless the pools are laid out in table order): trip 1
+// without its loads -- page pointers from arithmetic on a pool base and the length from a constant, both read through the scalar
+// cache -- i.e. what a persistent workgroup that fetched the next item's length / page window during its current sweep would see
+static __device__ unsigned long long omni_dbg_pool[4];      // K pool base, V pool base, page bytes, cached tokens per sequence
+extern "C" int omni_debug_set_pool(unsigned long long kbase, unsigned long long vbase, unsigned long long page_bytes, unsigned long long tlen) {
+  const unsigned long long h[4] = {kbase, vbase, page_bytes, tlen};
+  return hipMemcpyToSymbol(HIP_SYMBOL(omni_dbg_pool), h, sizeof(h)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef OMNI_DEBUG_CLOCKS
 // timeline probe (tools/flash_timeline.py): shader-clock stamps of every wave of three workgroups -- the first, the middle
 // and the last of the grid in dispatch order: [0] entry, [1] page window visible, [2] q in LDS (first batch requested),
@@ -492,11 +502,19 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
         my_page = tab[pg];
       }
     } else {
+#if (OMNI_FLASH_ABLATE & 64)
+      my_page = (int64_t)(omni_dbg_pool[tid < 40 ? 0 : 1] + (unsigned long long)(b * p.max_blocks + (pg < p.max_blocks ? pg : 0)) * omni_dbg_pool[2]);
+#else
       if (pg < p.max_blocks) my_page = tab[pg];   // entries past the sequence's pages are never dereferenced
+#endif
     }
   }
   // the sequence's first K / V page: always allocated (an empty split reads it, unused)
+#if (OMNI_FLASH_ABLATE & 64)
+  const int64_t dummy_ptr = (int64_t)omni_dbg_pool[tid < 40 ? 0 : 1];
+#else
   const int64_t dummy_ptr = tid < 80 ? (tid < 40 ? ktab : vtab)[0] : 0;
+#endif
   constexpr int QIT = ((G + 1) * 64 + DEC_THREADS - 1) / DEC_THREADS;
   half_t qa[QIT], qbv[QIT];
   half_t vcur_r = (half_t)0.0f;
@@ -569,7 +587,11 @@ __global__ __launch_bounds__(DEC_THREADS, OMNI_FLASH_MIN_BLOCKS) void kv4_decode
   if constexpr (FG) {
     if (dyn) dyn_last = dyn[p.fg.num_dyn - 1];
   }
+#if (OMNI_FLASH_ABLATE & 64)
+  const int tlen = (int)omni_dbg_pool[3];
+#else
   const int tlen = p.lengths[b] - 1;
+#endif
   int nvirt = tlen, gap = 0;   // attended cached tokens; streaming: virtual i >= sink is token i + gap
   if constexpr (FG) {
     if (streaming) {

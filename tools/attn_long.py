@@ -37,5 +37,11 @@ else:
 if os.environ.get("OMNI_NSPLIT"):      # planner override (tuning): KV splits per (sequence, head group)
     from omniserve_amd import _lib as _l
     _l.lib().omni_kv4_decode_set_split_override(int(os.environ["OMNI_NSPLIT"]))
+if os.environ.get("OMNI_DBG_POOL"):      # -DOMNI_FLASH_ABLATE=64 builds: trip 1 without its loads (page pointers by arithmetic)
+    import ctypes
+    from omniserve_amd import _lib as _l
+    h = ctypes.CDLL(_l.LIB_PATH)
+    h.omni_debug_set_pool.argtypes = [ctypes.c_ulonglong] * 4
+    assert h.omni_debug_set_pool(pools.k.data_ptr(), pools.v.data_ptr(), pools.page_bytes, Tc) == 0
 us = timed(fn, iters=iters)
 print("%s decode attention B=%d T=%d: %.1f us, %.0f GB/s" % (mode, B, Tc, us, nbytes / us / 1e3))
