@@ -404,7 +404,8 @@ int omni_prefill_attention_block_streaming(void* out_f16, const void* q_f16, con
                                            const void* cu_seqlens_q_i32, const void* cu_seqlens_k_i32, int batch,
                                            int max_seqlen_q, int num_heads, int num_kv_heads, int head_dim,
                                            const void* head_mask_type_i32, const void* streaming_info_i32, void* stream);
-/* Tuning / test hook: 0 = 16 query rows per wave (16x16x32 MFMA, default), 1 = 32 rows per wave (32x32x16 MFMA). */
+/* Tuning / test hook: 0 = 16 query rows per wave (16x16x32 MFMA, default), 1 = 32 rows per wave (32x32x16 MFMA), 2 = the 16-row
+ * form on the 8-wave ping-pong schedule (waves 4-7 one segment behind waves 0-3; same results within the attention tolerance). */
 void omni_prefill_set_variant(int variant);
 
 /* Tuning hook: over how many XCDs the query tiles of one kv head are spread when streaming heads are present

@@ -361,6 +361,250 @@ void prefill_attn_kernel(PrefillArgs p) {
 #undef PREFILL_DMA_TILE
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Ping-pong form of the 16-row kernel (omni_prefill_set_variant(2)).  Same tiles, layouts and arithmetic; what changes is WHEN the
+// two halves of the workgroup do what.  In the form above all eight waves run S -> softmax -> P.V in step behind one barrier per
+// tile, so on every SIMD the softmax's VALU issue and the MFMAs of the wave pair ADD UP instead of overlapping (profiles/r02_f:
+// MFMA busy 40 % + VALU issue 57 %).  Here a tile is two segments behind two barriers, and waves 4-7 run one segment behind
+// waves 0-3 (wave w and wave w + 4 share SIMD w):
+//       segment 2i + 1                        segment 2i + 2
+//   waves 0-3:  P.V(i), S(i+1)        |  softmax(i+1)                      (matrix | VALU)
+//   waves 4-7:  softmax(i)            |  P.V(i), S(i+1)                    (VALU | matrix)
+// so a SIMD always has one wave in a matrix segment beside one in the softmax.  K(i+1) and V(i) are read in segments 2i + 1 and
+// 2i + 2: with the two-slot rings the DMAs of V(i+1) and K(i+2) go out at the start of segment 2i + 1 (their slots -- V(i-1)'s and
+// K(i)'s -- were last read in segment 2i) and are waited for (vmcnt(0), every wave its own pieces) in front of the barrier that
+// opens segment 2i + 3: one tile of flight, as above.  The DMAs are hidden from hipcc (lds_dma16_untracked): it otherwise waits lgkmcnt(0) in front of every consumer of a
+// ds_read while one is in flight, and here the operand reads of P.V and S run beside the flight.
+#define PP_DMA_ROWS(base_, stride_, swz_, kb_, t_, pitch_)                                                          \
+  do {                                                                                                              \
+    int ln_ = lane;                                                                                                 \
+    asm volatile("" : "+v"(ln_));                                                                                   \
+    const int ss_ = ln_ & 15, lr_ = ln_ >> 4;                                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < PPT; ++i_) {                                                            \
+      const int row_ = 4 * PPT * wave + 4 * i_ + lr_;                                                               \
+      const uint32_t kr_ = (uint32_t)((kb_) + row_ < len_k ? (kb_) + row_ : (len_k - 1));                           \
+      lds_dma16_untracked((base_) + ((uint64_t)kr_ * (stride_) + (uint32_t)((ss_ ^ (swz_)) << 4)),                  \
+                          (t_) + (4 * PPT * wave + 4 * i_) * (pitch_));                                             \
+    }                                                                                                               \
+  } while (0)
+#define PP_DMA_K(kb_, kt_) PP_DMA_ROWS(kbase, kstride_b, (row_ & 15), kb_, kt_, PKROW)
+#define PP_DMA_V(kb_, vt_) PP_DMA_ROWS(vbase, vstride_b, (2 * (row_ & 7)), kb_, vt_, PVROW)
+
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4), amdgpu_num_vgpr(128)))
+void prefill_attn_pp_kernel(PrefillArgs p) {
+  static_assert(PQB == 1 && PWAVES == 8, "the ping-pong form is written for 8 waves x 16 rows");
+  __shared__ __attribute__((aligned(16))) uint8_t ktile0[PKTILE];
+  __shared__ __attribute__((aligned(16))) uint8_t ktile1[PKTILE];
+  __shared__ __attribute__((aligned(16))) uint8_t vtile0[PVTILE];
+  __shared__ __attribute__((aligned(16))) uint8_t vtile1[PVTILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  int b = blockIdx.z, h = blockIdx.y, qt = gridDim.x - 1 - blockIdx.x;
+  if (p.q_tiles > 0 && !prefill_map_block(p, b, h, qt)) return;
+  const int hk = h / (p.num_heads / p.num_kv_heads);
+  const int q_begin = p.cu_q[b], len_q = p.cu_q[b + 1] - q_begin;
+  const int k_begin = p.cu_k[b], len_k = p.cu_k[b + 1] - k_begin;
+  const int q_first = qt * PQROWS;
+  if (q_first >= len_q) return;
+  const int q_last = min(q_first + PQROWS, len_q) - 1;
+  const int q0 = q_first + wave * 16;
+  const int off = len_k - len_q;
+  const bool streaming = p.head_mask_type != nullptr && p.head_mask_type[h] < 0;
+  const int gl = p.gran_log2;
+  const int sink = streaming ? p.streaming_info[2 * h] << gl : 0;
+  const int local = streaming ? p.streaming_info[2 * h + 1] : 0;
+  const float scale2 = 0.08838834764831845f * 1.4426950408889634f;
+  const int qrow = q0 + l15;
+  v8h qb[4];
+  {
+    const int qr_c = qrow < len_q ? qrow : (len_q - 1);
+    const half_t* qp = p.q + (size_t)(q_begin + qr_c) * p.q_stride + (size_t)h * PDH + 8 * l4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qb[s] = *reinterpret_cast<const v8h*>(qp + 32 * s);
+  }
+  v4f oacc[8];
+  float m_run = -1e30f, l_run = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) oacc[c] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const int k_hi = p.causal ? min(len_k, q_last + off + 1) : len_k;
+  const int win_lo = streaming ? first_local_key(q_first + off, local, gl) : 0;
+  auto skipped = [&](int kb) { return streaming && kb >= sink && kb + PKT <= win_lo; };
+  auto next_tile = [&](int kb) {
+    while (kb < k_hi && skipped(kb)) kb += PKT;
+    return kb;
+  };
+  const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k + (size_t)k_begin * p.k_stride + (size_t)hk * PDH);
+  const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v + (size_t)k_begin * p.v_stride + (size_t)hk * PDH);
+  const uint32_t kstride_b = (uint32_t)(p.k_stride * 2), vstride_b = (uint32_t)(p.v_stride * 2);
+  const int trow = 4 * l4 + (l15 >> 2);
+  const int tr_a0 = (trow * PVROW + (l15 & 3) * 8) | ((trow & 7) << 5);
+
+  // ---- the three stages of a tile (the 16-row kernel's own code) ---------------------------------------------------------
+  auto stage_s = [&](const uint8_t* kt, v4f (&st)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) st[u] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int key = 16 * u + l15;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const v8h a = *reinterpret_cast<const v8h*>(kt + key * PKROW + (((4 * s + l4) ^ l15) << 4));
+        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qb[s], st[u], 0, 0, 0);
+      }
+    }
+  };
+  auto stage_softmax = [&](int kb, const v4f (&st)[4], v8h (&pb)[2]) {
+    bool full = (kb + PKT <= len_k) && (q_first + PQROWS <= len_q);
+    if (p.causal) full = full && (kb + PKT - 1 <= q_first + off);
+    if (streaming) full = full && ((kb + PKT <= sink) || (kb >= first_local_key(q_last + off, local, gl)));
+    float tmax = -1e30f, m_new, alpha, psum = 0.0f;
+    if (full) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tmax = __builtin_fmaxf(tmax, st[u][r]);
+      tmax = rows4_max(tmax);
+      m_new = __builtin_fmaxf(m_run, tmax * scale2);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e >> 2][e & 3], scale2, -m_new));
+        pb[e >> 3][e & 7] = (half_t)pe;
+        psum += pe;
+      }
+    } else {
+      bool okv[16];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb + 16 * u + 4 * l4 + r;
+          const int qpos = qrow + off;
+          int ok = (int)(key < len_k) & (int)(qrow < len_q);
+          ok &= (int)(!p.causal) | (int)(key <= qpos);
+          ok &= (int)(!streaming) | (int)(key < sink) | (int)(key >= first_local_key(qpos, local, gl));
+          okv[4 * u + r] = ok != 0;
+          tmax = __builtin_fmaxf(tmax, ok ? st[u][r] : -1e30f);
+        }
+      tmax = rows4_max(tmax);
+      m_new = __builtin_fmaxf(m_run, tmax * scale2);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pe = okv[e] ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[e >> 2][e & 3], scale2, -m_new)) : 0.0f;
+        pb[e >> 3][e & 7] = (half_t)pe;
+        psum += pe;
+      }
+    }
+    l_run = l_run * alpha + psum;
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) oacc[c] *= alpha;
+    }
+    m_run = m_new;
+  };
+  auto stage_pv = [&](const uint8_t* vt, const v8h (&pb)[2]) {
+    v8h a16[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kk = i >> 3, c = i & 7;
+      const uint8_t* src = vt + (32 * kk) * PVROW + (tr_a0 ^ (c << 5));
+      const pv4hp lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src));
+      const pv4hp hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) pv4hp*)(__attribute__((address_space(3))) void*)(src + 16 * PVROW));
+      a16[i] = (v8h){(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
+                     (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[i], pb[i >> 3], oacc[i & 7], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+  };
+  // barrier that opens a B segment: this wave's DMA pieces have landed, then everybody's
+  auto barrier_landed = [&]() {
+    lds_dma_wait_all();
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- prologue: K(0), V(0), K(1) ---------------------------------------------------------------------------------------
+  int kc = next_tile(0);                                     // tile i
+  int kn = kc < k_hi ? next_tile(kc + PKT) : k_hi;           // tile i + 1
+  int kn2 = kn < k_hi ? next_tile(kn + PKT) : k_hi;          // tile i + 2
+  if (kc < k_hi) { PP_DMA_K(kc, ktile0); PP_DMA_V(kc, vtile0); }
+  if (kn < k_hi) PP_DMA_K(kn, ktile1);
+  barrier_landed();
+  v4f st[4];
+  v8h pb[2];
+  const bool first_half = wave < PWAVES / 2;
+  // ONE instruction stream for both halves -- S(0); then per tile: softmax(i) | barrier | P.V(i), S(i+1) | barrier -- with waves
+  // 4-7 held back by one extra barrier behind S(0) (waves 0-3 run the matching one behind their last tile): from then on every
+  // barrier pairs a softmax segment of one half with a matrix segment of the other.  What differs per half is only where the
+  // DMAs are issued and waited for (both at the same points of the WORKGROUP's timeline, see the kernel's header).
+  auto issue_dma = [&](uint8_t* v_slot, uint8_t* k_slot) {       // V(i + 1) -> the slot of V(i - 1), K(i + 2) -> the slot of K(i)
+    if (kn < k_hi) PP_DMA_V(kn, v_slot);
+    if (kn2 < k_hi) PP_DMA_K(kn2, k_slot);
+  };
+  auto tile = [&](auto parity) {
+    constexpr int B = decltype(parity)::value;
+    uint8_t* kt_cur = B ? ktile1 : ktile0;
+    uint8_t* kt_nxt = B ? ktile0 : ktile1;
+    uint8_t* vt_cur = B ? vtile1 : vtile0;
+    uint8_t* vt_oth = B ? vtile0 : vtile1;
+    if (!first_half) issue_dma(vt_oth, kt_cur);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_softmax(kc, st, pb);
+    __builtin_amdgcn_sched_barrier(0);
+    if (first_half) lds_dma_wait_all();
+    __builtin_amdgcn_s_barrier();
+    if (first_half) issue_dma(vt_oth, kt_cur);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_pv(vt_cur, pb);                                    // P.V(i)
+    __builtin_amdgcn_sched_barrier(0);
+    if (kn < k_hi) stage_s(kt_nxt, st);                      // S(i + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (!first_half) lds_dma_wait_all();
+    __builtin_amdgcn_s_barrier();
+    kc = kn; kn = kn2;
+    kn2 = kn2 < k_hi ? next_tile(kn2 + PKT) : k_hi;
+  };
+  if (kc < k_hi) {
+    stage_s(ktile0, st);                                     // S(0)
+    __builtin_amdgcn_sched_barrier(0);
+    if (!first_half) __builtin_amdgcn_s_barrier();
+    while (true) {
+      tile(IntTag<0>{});
+      if (kc >= k_hi) break;
+      tile(IntTag<1>{});
+      if (kc >= k_hi) break;
+    }
+    if (first_half) __builtin_amdgcn_s_barrier();
+  }
+  // ---- finish ----
+  {
+    const float l = rows4_sum(l_run);
+    if (qrow < len_q) {
+      const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+      half_t* op = p.out + ((size_t)(q_begin + qrow) * p.num_heads + h) * PDH + 4 * l4;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
+        const v4h_t o = {(half_t)(oacc[c][0] * inv), (half_t)(oacc[c][1] * inv), (half_t)(oacc[c][2] * inv),
+                         (half_t)(oacc[c][3] * inv)};
+        *reinterpret_cast<v4h_t*>(op + c * 16) = o;
+      }
+    }
+  }
+}
+#undef PP_DMA_K
+#undef PP_DMA_V
+#undef PP_DMA_ROWS
+
+// ------------------------------------------------------------------------------------------------------------------------
 // 32-row form (v_mfma_f32_32x32x16_f16).  Same tiles, same LDS-DMA staging, same online softmax; what changes is the
 // shape of a wave's work: 32 query rows x 64 keys per tile instead of 16 x 64.
 //   * S^T = K Q^T per 32-key block: A = K rows from LDS (lane l: key l%32, 16 B of dims 16s + 8*(l/32)), B = Q in
@@ -609,7 +853,7 @@ using namespace omni;
 
 static thread_local int g_prefill_variant = OMNI_PREFILL_MFMA32;
 // Tuning / test hook: 0 = the 16-row form (default), 1 = the 32-row form.  Same results within the attention tolerance.
-extern "C" void omni_prefill_set_variant(int variant) { g_prefill_variant = variant == 1 ? 1 : 0; }
+extern "C" void omni_prefill_set_variant(int variant) { g_prefill_variant = (variant == 1 || variant == 2) ? variant : 0; }
 #ifndef OMNI_PREFILL_XCD_SPLIT_MASKED
 #define OMNI_PREFILL_XCD_SPLIT_MASKED 8
 #endif
@@ -656,6 +900,7 @@ static int prefill_attention_common(void* out_f16, const void* q_f16, const void
     }
   }
   if (form32) hipLaunchKernelGGL(prefill_attn32_kernel, grid, dim3(64 * P32W), 0, (hipStream_t)stream, a);
+  else if (g_prefill_variant == 2) hipLaunchKernelGGL(prefill_attn_pp_kernel, grid, dim3(64 * PWAVES), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(prefill_attn_kernel, grid, dim3(64 * PWAVES), 0, (hipStream_t)stream, a);
   return omni_launch_status();
 }

@@ -10,10 +10,10 @@ from tests.util import assert_attention_close, dev, to_dev
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[0, 1], ids=["rows16", "rows32"])
+@pytest.fixture(autouse=True, params=[0, 1, 2], ids=["rows16", "rows32", "pingpong"])
 def kernel_form(request):
     """Every case runs on both forms of the kernel: 16 query rows per wave (16x16x32 MFMA, the default) and 32 rows per wave
-    (32x32x16 MFMA, csrc/attn_prefill.hip: prefill_attn32_kernel)."""
+    (32x32x16 MFMA, csrc/attn_prefill.hip: prefill_attn32_kernel), and the ping-pong schedule of the 16-row form (prefill_attn_pp_kernel)."""
     from omniserve_amd import _lib
     _lib.lib().omni_prefill_set_variant(request.param)
     yield request.param

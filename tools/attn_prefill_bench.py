@@ -17,6 +17,9 @@ from flash_attn.flash_attn_interface import flash_attn_varlen_func  # noqa: E402
 
 dev = torch.device("cuda:0")
 Hq, Hk, D = 32, 8, 128
+if os.environ.get("OMNI_PREFILL_VARIANT"):      # 0: 16-row form, 1: 32-row form, 2: ping-pong schedule of the 16-row form
+    _lib.lib().omni_prefill_set_variant(int(os.environ["OMNI_PREFILL_VARIANT"]))
+    print("variant", os.environ["OMNI_PREFILL_VARIANT"])
 
 
 def run(L, mixed, reps=3):
